@@ -1,0 +1,38 @@
+# Builds the product library (HIP, gfx950) and the CPU oracle (test infrastructure).
+#   make            -> volren_amd/libvolren_amd.so  oracle/liboracle.so  volren_amd/volren
+# The HIP sources are cross-compiled; no GPU is needed to build.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+CSRC     := volren_amd/csrc
+# -ffp-contract=off: the renderer's fp32 arithmetic is specified operation by operation (vr_math.h)
+CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result -Iinclude
+HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
+OBJDIR   := build
+SRCS_CPP := grids.cpp imageio.cpp environment.cpp transferfunc.cpp renderer.cpp capi.cpp
+OBJS     := $(OBJDIR)/vr_kernels.o $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
+HDRS     := $(wildcard $(CSRC)/*.h) include/volren_amd.h
+
+all: volren_amd/libvolren_amd.so volren_amd/volren oracle
+
+$(OBJDIR)/vr_kernels.o: $(CSRC)/vr_kernels.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+volren_amd/libvolren_amd.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -lz
+
+volren_amd/volren: $(CSRC)/main.cpp volren_amd/libvolren_amd.so $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -x hip $(CSRC)/main.cpp -o $@ -Lvolren_amd -lvolren_amd -Wl,-rpath,'$$ORIGIN' -lz
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(OBJDIR) volren_amd/libvolren_amd.so volren_amd/volren
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the volume path-tracing hot path on MI355X.
+
+A "step" is one full frame of BASELINE.json configs[1] ("c2": data/smoke.brick, no transfer function, 1024x1024,
+1024 spp, 100 bounces, fov 40, seed 42): W*H*spp pixel-samples through the fused HIP path-tracing kernel, scene
+resident in HBM before the timed region.  Metric: Msamples/s = W*H*spp / wall time of the sample loop.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the frame's 16x16 tiles are sharded over the ranks
+(diagonal interleave), every rank renders its tiles, and the accumulated radiance is exchanged with ONE RCCL
+all_gather of the compact per-rank tile buffers per frame.  Total work is fixed, so scaling is "strong".
+
+Adds to the JSON line:
+  roofline     -- algorithmic HBM bytes (SURVEY.md 8d formula, event counts from the oracle's instrumented counters on
+                  the same config) / HIP-event duration of the path-tracing kernel, vs 8 TB/s.
+  cpu_baseline -- the CPU oracle ("port") timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def tile_owner_lists(w, h, n_ranks):
+    """Diagonal interleave of 16x16 tiles: owner(tx, ty) = (tx + ty) mod N.  Returns one raster-id list per rank."""
+    tiles_x, tiles_y = (w + 15) // 16, (h + 15) // 16
+    lists = [[] for _ in range(n_ranks)]
+    for ty in range(tiles_y):
+        for tx in range(tiles_x):
+            lists[(tx + ty) % n_ranks].append(ty * tiles_x + tx)
+    return lists
+
+
+def algorithmic_bytes_per_sample(counters, spp, use_tf, has_emission):
+    """B = 4*N_dda + b_tap*T*N_coll + b_em*N_coll_sv + 200*N_nee + 48*N_esc + 16/spp."""
+    n = float(counters["samples"])
+    n_dda = (counters["n_dda_sv"] + counters["n_dda_tr"]) / n
+    n_coll = (counters["n_coll_sv"] + counters["n_coll_tr"]) / n
+    n_coll_sv = counters["n_coll_sv"] / n
+    n_nee = counters["n_nee"] / n
+    n_esc = counters["n_esc"] / n
+    taps = 8 if use_tf else 1
+    b = 4.0 * n_dda + 9.0 * taps * n_coll + (9.0 if has_emission else 0.0) * n_coll_sv + 200.0 * n_nee + 48.0 * n_esc + 16.0 / spp
+    return b, dict(N_dda=n_dda, N_coll=n_coll, N_coll_sv=n_coll_sv, N_nee=n_nee, N_esc=n_esc,
+                   primary_miss=counters["n_primary_miss"] / n)
+
+
+def cpu_baseline_and_counters(config, w, h, budget_s):
+    """Oracle on the host cores: low-resolution full view of the same scene (same camera, so the same mix of
+    box-missing and cloud pixels), spp chosen to fill ~budget_s seconds."""
+    import scenes
+    from oracle import binding as ob
+    cw = ch = 256
+    o = scenes.oracle_scene(config, cw, ch)
+    t0 = time.time()
+    o.render(2)
+    rate = cw * ch * 2 / max(time.time() - t0, 1e-6)
+    spp = int(max(2, min(512, budget_s * rate / (cw * ch))))
+    o2 = scenes.oracle_scene(config, cw, ch)
+    t0 = time.time()
+    o2.render(spp)
+    dt = time.time() - t0
+    cores = ob.lib().orc_num_threads()
+    return dict(value=cw * ch * spp / dt / 1e6, unit="Msamples/s", cores=int(cores), kind="port",
+                sample="%s scene at %dx%d, %d spp (%.1f s of oracle/liboracle.so, OpenMP over rows)" % (config, cw, ch, spp, dt)), o2.counters.as_dict()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "readme"])
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    import torch
+    import scenes
+    import volren_amd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the renderer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w, h, spp = args.width, args.height, args.spp
+    r = scenes.hip_scene(args.config, w, h, device=local_rank)
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)
+
+    tile_lists = tile_owner_lists(w, h, world)
+    mine = tile_lists[rank]
+    packed = gathered = tiles_dev = all_tiles_dev = None
+    if world > 1:
+        r.set_tiles(mine)
+        n_max = max(len(t) for t in tile_lists)
+        pad = [t + [-1] * (n_max - len(t)) for t in tile_lists]           # -1 = padding entry (skipped by unpack)
+        tiles_dev = torch.tensor(mine + [mine[-1]] * (n_max - len(mine)), dtype=torch.int32, device="cuda")
+        all_tiles_dev = torch.tensor(sum(pad, []), dtype=torch.int32, device="cuda")
+        packed = torch.empty(n_max * 256 * 4, dtype=torch.float32, device="cuda")
+        gathered = torch.empty(world * n_max * 256 * 4, dtype=torch.float32, device="cuda")
+
+    kernel_ms = []
+
+    def step():
+        r.reset()
+        r.render(spp, sync=False)                                           # ONE fused launch: all spp of all owned tiles
+        if world > 1:
+            n_max = packed.numel() // 1024
+            r.pack_tiles(tiles_dev.data_ptr(), n_max, packed.data_ptr())
+            dist.all_gather_into_tensor(gathered, packed)                   # RCCL over xGMI, once per frame
+            r.unpack_tiles(all_tiles_dev.data_ptr(), world * n_max, gathered.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    r.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(None)                                              # filled below without syncing inside the loop
+    barrier()
+    elapsed = time.perf_counter() - t0
+    r.synchronize()                                                         # also raises if the kernel watchdog tripped
+    last_ms = r.last_kernel_ms()                                            # HIP events around the last path-tracing launch
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    samples_per_step = float(w) * h * spp
+    value = samples_per_step * args.steps / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        use_tf = args.config == "c3"
+        cpu = None
+        counters = None
+        if world == 1 and args.cpu_budget > 0:
+            cpu, counters = cpu_baseline_and_counters(args.config, w, h, args.cpu_budget)
+        else:
+            _, counters = cpu_baseline_and_counters(args.config, w, h, 0.5)
+        b_sample, events = algorithmic_bytes_per_sample(counters, spp, use_tf, False)
+        my_samples = len(mine) * 256.0 * spp if world > 1 else samples_per_step
+        achieved = b_sample * my_samples / (last_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Msamples/s (pixels x spp / s), volume path tracing",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else ""),
+            "config": {"workload": "BASELINE configs[%d] '%s': smoke.brick%s, %dx%d, %d spp, seed 42, fov 40" % (
+                {"c1": 0, "c2": 1, "c3": 2}.get(args.config, -1), args.config, " + lut.txt" if use_tf else ", no transfer function", w, h, spp),
+                "parallelism": "tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame" % world if world > 1 else "1 GPU, 1 fused launch/frame"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "pathtrace_kernel<%s>" % ("true" if use_tf else "false"), "kernel_ms": last_ms,
+                         "bytes_per_sample": b_sample, "events_per_sample": events},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

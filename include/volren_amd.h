@@ -1,0 +1,126 @@
+/*
+ * volren_amd.h -- C ABI of libvolren_amd.so, the MI355X (gfx950, HIP) drop-in for the offline path-tracing path of
+ * nihofm/volren.
+ *
+ * The reference exposes this path as an in-process C++ object API (struct RendererOpenGL, class Environment,
+ * class TransferFunction) that is bound to Python by pybind11 (src/bindings.cpp:64-209).  This header is the same
+ * surface flattened to C so that any FFI (ctypes, cgo, JNI, N-API, or a pybind11 module like the reference's
+ * `volpy`) can bind it: plain pointers and sizes, int return codes (0 = ok, non-zero = the std::runtime_error the
+ * C++ method threw; text via vr_last_error()).  Each entry point names the reference interface it replaces
+ * (paths relative to the reference repository).  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions kept from the reference: framebuffers are RGBA32F with row 0 at the BOTTOM (GL image order); matrices
+ * are column-major (glm); `sample` counts completed samples per pixel; the running mean of
+ * shader/pathtracer_brick.glsl:36 is what the framebuffer holds.
+ *
+ * There is no CPU path: every compute entry point fails with VR_ERR_NO_DEVICE when no HIP device is present.
+ */
+#ifndef VOLREN_AMD_H
+#define VOLREN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_OK 0
+#define VR_ERR 1              /* std::runtime_error / std::out_of_range from the C++ layer */
+#define VR_ERR_NO_DEVICE 2
+#define VR_ERR_ARG 3
+
+typedef struct vr_renderer vr_renderer;
+
+/* text of the last error on this thread ("" if none) */
+const char* vr_last_error(void);
+/* library version string */
+const char* vr_version(void);
+/* number of HIP devices visible (does not initialise a device context) */
+int vr_device_count(void);
+
+/* --- lifetime: std::make_shared<RendererOpenGL>() + RendererOpenGL::init()  (src/main.cpp:445-446, src/renderer.cpp:29-50)
+ *     device: HIP device ordinal; width/height: Context::resolution() (src/renderer.cpp:47) */
+int vr_create(vr_renderer** out, int device, int width, int height);
+void vr_destroy(vr_renderer* r);
+/* RendererOpenGL::resize (src/renderer.cpp:52-54); clears the framebuffer */
+int vr_resize(vr_renderer* r, int width, int height);
+
+/* --- scene loading: load_volume / load_envmap / load_transferfunc of src/main.cpp:37-81 (same side effects:
+ *     load_volume sets density_scale=1, scale_and_move_to_unit_cube(), commit(), sample=0; load_envmap resets
+ *     transform/strength; load_transferfunc sets show_environment=false) */
+int vr_load_volume(vr_renderer* r, const char* path);              /* .brick file, or a folder of .brick frames */
+int vr_load_envmap(vr_renderer* r, const char* path);              /* Radiance .hdr */
+int vr_load_transferfunc(vr_renderer* r, const char* path);        /* "%f, %f, %f, %f" rows */
+
+/* --- scene from memory: voldata::DenseGrid(w,h,d,float*) + Volume(grid) (src/main.cpp:470-472, bindings.cpp Volume ctors);
+ *     transform: grid index->model, 16 floats column-major (NULL = identity).  name: "density" | "temperature" | "flame" | "flames".
+ *     unit_cube != 0 applies load_volume's density_scale=1 + scale_and_move_to_unit_cube().  Follow with vr_commit(). */
+int vr_set_volume_dense(vr_renderer* r, const char* name, const float* voxels, int nx, int ny, int nz, const float* transform, int unit_cube);
+/* voldata::BrickGrid fields as stored in a .brick file; mips may be NULL/0 */
+int vr_set_volume_brick(vr_renderer* r, const char* name, const float* transform, const uint32_t n_bricks[3], const float min_maj[2],
+                        const uint32_t* indirection, const uint32_t* range, const uint32_t atlas_dim[3], const uint8_t* atlas,
+                        int n_mips, const uint32_t* const* mips, const uint32_t (*mip_dims)[3], int unit_cube);
+/* Environment(Texture2D) (src/environment.cpp:11-33): float RGB, rows top first */
+int vr_set_envmap(vr_renderer* r, const float* rgb, int width, int height);
+/* TransferFunction(std::vector<glm::vec4>) (src/transferfunc.cpp:19-22); n = 0 removes the transfer function */
+int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
+
+/* --- public fields of RendererOpenGL / Environment / TransferFunction / camera (src/renderer.h:30-62, environment.h:20-21,
+ *     transferfunc.h:39, src/main.cpp:360-435).  Names: "sample" "sppx" "seed" "bounces" "show_environment" "tonemapping"
+ *     "integrator" "grid_frame_counter" (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
+ *     "emission_scale" "vol_clip_min"(3) "vol_clip_max"(3) "env_strength" "env_transform"(9) "env_rot"(1, degrees about +y,
+ *     main.cpp:382) "tf_window_left" "tf_window_width" "cam_pos"(3) "cam_dir"(3) "cam_up"(3) "cam_fov" "volume_transform"(16) (float) */
+int vr_set_int(vr_renderer* r, const char* name, int value);
+int vr_get_int(vr_renderer* r, const char* name, int* value);
+int vr_set_float(vr_renderer* r, const char* name, const float* values, int count);
+int vr_get_float(vr_renderer* r, const char* name, float* values, int count);
+
+/* RendererOpenGL::commit / reset / scale_and_move_to_unit_cube (src/renderer.cpp:56-76,155-157,227-242) */
+int vr_commit(vr_renderer* r);
+int vr_reset(vr_renderer* r);
+int vr_scale_and_move_to_unit_cube(vr_renderer* r);
+
+/* --- the hot path.  vr_trace = RendererOpenGL::trace (src/renderer.cpp:78-145): ONE more sample per pixel.
+ *     vr_render = the Python binding's render(spp) loop (src/bindings.cpp:124-132) / the offline loop (src/main.cpp:533-537)
+ *     fused into one launch: `spp` more samples per pixel (spp <= 0: up to sppx).  Both are asynchronous on the renderer's
+ *     stream; vr_synchronize waits and reports a tripped kernel watchdog as an error. */
+int vr_trace(vr_renderer* r);
+int vr_render(vr_renderer* r, int spp);
+int vr_synchronize(vr_renderer* r);
+/* duration of the last path-tracing launch in ms, measured with HIP events on the renderer's stream (waits for it) */
+int vr_last_kernel_ms(vr_renderer* r, double* ms);
+
+/* --- results.  vr_framebuffer = fbo_data() without the alpha drop (src/bindings.cpp:141-148): W*H*4 floats, row 0 bottom.
+ *     vr_draw = RendererOpenGL::draw (src/renderer.cpp:147-153) into a separate tonemapped buffer (shader/tonemap.glsl);
+ *     vr_save_png = tonemap + Texture2D::save_ldr of the offline loop (src/main.cpp:540-555): RGBA8 PNG, top row first. */
+int vr_framebuffer(vr_renderer* r, float* rgba_out);
+int vr_framebuffer_device(vr_renderer* r, void** device_ptr);
+int vr_draw(vr_renderer* r);
+int vr_display(vr_renderer* r, float* rgba_out);
+int vr_save_png(vr_renderer* r, const char* path);
+
+/* --- additions for multi-GPU and measurement (no reference counterpart) */
+/* restrict rendering to these 16x16 tiles (raster tile ids, row 0 = bottom); n = 0 -> whole frame */
+int vr_set_tiles(vr_renderer* r, const int32_t* tile_ids, int n);
+/* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
+int vr_set_stream(vr_renderer* r, void* hip_stream);
+/* pack the owned tiles of the framebuffer into a compact device buffer (n_tiles*256*4 floats) / scatter a gathered buffer back */
+int vr_pack_tiles(vr_renderer* r, const int32_t* tile_ids_device, int n_tiles, void* packed_device);
+int vr_unpack_tiles(vr_renderer* r, const int32_t* tile_ids_device, int n_tiles, const void* packed_device);
+/* the uniform block the next launch would use (struct vr::Uniforms of volren_amd/csrc/vr_scene.h, `bytes` must match) */
+int vr_get_uniforms(vr_renderer* r, void* out, int bytes);
+int vr_uniforms_size(void);
+/* importance pyramid of the current environment (floats, level 0 first); count from vr_impmap_floats */
+int vr_impmap_floats(vr_renderer* r);
+int vr_get_impmap(vr_renderer* r, float* out, int count);
+/* scheduler thresholds of the path-tracing kernel (8 ints, see volren_amd/csrc/vr_kernels.hip) */
+int vr_set_sched(const int32_t thresholds[8]);
+/* unit-test probe of the device math (volren_amd/csrc/vr_math.h): host arrays in/out */
+int vr_math_probe(int fn, const float* a, const float* b, float* out, int n);
+/* host-side helpers exposed for tests: dense->brick encoder statistics */
+int vr_encode_dense_stats(const float* voxels, int nx, int ny, int nz, uint32_t n_bricks_out[3], uint64_t* brick_counter, float min_maj_out[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLREN_AMD_H */

@@ -1,0 +1,123 @@
+// tests/hostkernel/host_kernel.cpp -- TEST HARNESS ONLY, never part of the product.
+//
+// Compiles the device code of the path tracer (volren_amd/csrc/vr_trace.h, vr_math.h -- the same headers the HIP
+// kernel is built from) with the host compiler so that the lane state machine can be checked against the CPU
+// oracle, and run under ASan/UBSan, in the GPU-less build container.  It is built and loaded by
+// tests/test_host_kernel.py only; the product library (libvolren_amd.so) has no CPU path.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../volren_amd/csrc/vr_trace.h"
+
+using namespace vr;
+
+namespace {
+struct HostGrid {
+    std::vector<BrickRec> recs;
+    std::vector<uint8_t> atlas;
+    std::vector<float> majorant;
+    GridView view{};
+};
+
+void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t nb[3], const uint32_t* indirection, const uint32_t* range,
+                const uint32_t ad[3], const uint8_t* atlas, int n_mips, const uint32_t* const* mips, bool density) {
+    const size_t n = (size_t)nb[0] * nb[1] * nb[2];
+    const uint32_t sx = ad[0] / 8, sy = ad[1] / 8, sz = ad[2] / 8;
+    const size_t slots = (size_t)sx * sy * sz;
+    g.atlas.assign((slots + 1) * 512, 0);
+    for (uint32_t pz = 0; pz < sz; ++pz) for (uint32_t py = 0; py < sy; ++py) for (uint32_t px = 0; px < sx; ++px)
+        for (uint32_t z = 0; z < 8; ++z) for (uint32_t y = 0; y < 8; ++y)
+            memcpy(&g.atlas[(((size_t)pz * sy + py) * sx + px) * 512 + z * 64 + y * 8],
+                   atlas + (((size_t)(pz * 8 + z) * ad[1] + (py * 8 + y)) * ad[0] + px * 8), 8);
+    g.recs.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t ind = indirection[i], rg = range[i];
+        const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
+        const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
+        g.recs[i].slot = (px < sx && py < sy && pz < sz) ? (uint32_t)(((size_t)pz * sy + py) * sx + px) : (uint32_t)slots;
+        g.recs[i].rmin = lo; g.recs[i].rdiff = hi - lo; g.recs[i].range = rg;
+    }
+    std::vector<uint32_t> words(range, range + n);
+    g.view.mip_off[0] = 0;
+    for (int m = 1; m <= 3; ++m) g.view.mip_off[m] = 0;
+    for (int m = 1; m <= n_mips; ++m) {
+        const uint32_t rnd = (1u << m) - 1u;
+        const size_t cnt = (size_t)((nb[0] + rnd) >> m) * ((nb[1] + rnd) >> m) * ((nb[2] + rnd) >> m);
+        g.view.mip_off[m] = (int32_t)words.size();
+        words.insert(words.end(), mips[m - 1], mips[m - 1] + cnt);
+    }
+    g.majorant.resize(words.size());
+    if (density) {
+        SceneParams P{}; P.u = u; P.tf_lut = lut;
+        for (size_t i = 0; i < words.size(); ++i) {          // == majorant_kernel of vr_kernels.hip
+            float m = u.vol_density_scale * half2float(words[i] >> 16);
+            if (u.use_tf) { float rgba[4]; tf_lookup(P, m * u.vol_inv_majorant, rgba); m = u.vol_majorant * rgba[3]; }
+            g.majorant[i] = m;
+        }
+    }
+    g.view.bricks = g.recs.data(); g.view.atlas = g.atlas.data(); g.view.majorant = g.majorant.data();
+    for (int i = 0; i < 3; ++i) g.view.nb[i] = (int32_t)nb[i];
+    g.view.n_mips = n_mips;
+}
+}  // namespace
+
+extern "C" {
+
+struct hk_grid_desc {
+    uint32_t nb[3]; uint32_t atlas_dim[3]; int32_t n_mips;
+    const uint32_t* indirection; const uint32_t* range; const uint8_t* atlas; const uint32_t* mips[3];
+};
+
+int hk_uniforms_size() { return (int)sizeof(Uniforms); }
+
+// env_rgb: texture order (row 0 bottom), 3 floats per texel.  Returns the number of lane steps executed.
+long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_grid_desc* emission, const float* lut,
+                    const float* env_rgb, int env_w, int env_h, const float* impmap, int imp_dim,
+                    float* fb, int x0, int y0, int x1, int y1, int first_sample, int n_samples) {
+    const Uniforms& u = *up;
+    SceneParams P{};
+    P.u = u;
+    HostGrid dg, eg;
+    build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true);
+    P.density = dg.view;
+    if (emission && u.has_emission) {
+        build_grid(eg, u, lut, emission->nb, emission->indirection, emission->range, emission->atlas_dim, emission->atlas, emission->n_mips, emission->mips, false);
+        P.emission = eg.view;
+        // emission_from_density = vol_emission_inv_transform * vol_density_transform (same product as hostmath.h)
+        const float* a = u.vol_emission_inv_transform; const float* b = u.vol_density_transform;
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r)
+            P.emission_from_density[4 * c + r] = a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1] + a[8 + r] * b[4 * c + 2] + a[12 + r] * b[4 * c + 3];
+    }
+    P.tf_lut = lut;
+    std::vector<float> env((size_t)env_w * env_h * 4);
+    for (size_t i = 0; i < (size_t)env_w * env_h; ++i) { env[4 * i] = env_rgb[3 * i]; env[4 * i + 1] = env_rgb[3 * i + 1]; env[4 * i + 2] = env_rgb[3 * i + 2]; env[4 * i + 3] = 1.f; }
+    P.envmap = env.data(); P.env_w = env_w; P.env_h = env_h;
+    P.impmap = impmap; P.imp_dim = imp_dim;
+    P.cam_z = -0.5f / tan_(0.5f * kPi * u.cam_fov / 180.f);
+    long long steps = 0;
+    const int W = u.resolution[0];
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            Lane l;
+            float* px = fb + 4 * ((size_t)y * W + x);
+            lane_init(l, x, y, first_sample, n_samples, px);
+            while (l.state != ST_DONE) {
+                if (u.use_tf) lane_step<true>(l, P); else lane_step<false>(l, P);
+                if (++steps > (1ll << 40)) return -1;
+            }
+            px[0] = l.acc[0]; px[1] = l.acc[1]; px[2] = l.acc[2]; px[3] = l.acc[3];
+        }
+    return steps;
+}
+
+float hk_math(int fn, float x, float y) {
+    switch (fn) {
+    case 0: return log_(x); case 1: return sin_(x); case 2: return cos_(x); case 3: return tan_(x);
+    case 4: return acos_(x); case 5: return atan2_(x, y); case 6: return exp_(x); case 7: return pow_(x, y);
+    case 8: return asin_(x);
+    case 13: { float s, c; sincos_(x, s, c); return s * y + c; }
+    default: return nan_();
+    }
+}
+}

@@ -1,0 +1,79 @@
+"""Scene set-ups shared by the tests, bench.py and smoke(): the BASELINE.json configs on the oracle renderer and on
+the HIP renderer, configured identically."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, "tests", "fixtures")
+SMOKE = os.path.join(FIX, "smoke.brick")
+HDR = os.path.join(FIX, "table_mountain_2_puresky_1k.hdr")
+LUT = os.path.join(FIX, "lut.txt")
+
+# name -> settings.  c1/c2/c3 are BASELINE.json configs[0..2]; "readme" is README.md:72-73 of the reference.
+CONFIGS = {
+    "c1": dict(bounces=4, cam_fov=40.0),
+    "c2": dict(bounces=100, cam_fov=40.0),
+    "c3": dict(bounces=100, cam_fov=40.0, lut=True),
+    "readme": dict(bounces=128, cam_fov=40.0, albedo=0.8, phase=0.3, density=100.0, env_strength=3.0, env_rot=270.0,
+                   exposure=3.0, gamma=2.0),
+}
+
+
+def configure(r, name, is_oracle):
+    """Apply a config in the reference's command-line order (paths first, then overrides: main.cpp:360-435)."""
+    cfg = CONFIGS[name]
+    r.load_volume(SMOKE)
+    r.load_envmap(HDR)
+    if cfg.get("lut"):
+        r.load_transferfunc(LUT)
+    r.bounces = cfg["bounces"]
+    r.cam_fov = cfg["cam_fov"]
+    if "albedo" in cfg:
+        r.albedo = (cfg["albedo"],) * 3
+    if "phase" in cfg:
+        r.phase = cfg["phase"]
+    if "density" in cfg:
+        r.density_scale = cfg["density"]
+    if "env_strength" in cfg:
+        r.env_strength = cfg["env_strength"]
+    if "env_rot" in cfg:
+        if is_oracle:
+            r.set_env_rot(cfg["env_rot"])
+        else:
+            r.env_rot = cfg["env_rot"]
+    if "exposure" in cfg:
+        r.tonemap_exposure = cfg["exposure"]
+        r.tonemap_gamma = cfg["gamma"]
+    return r
+
+
+def oracle_scene(name, w, h):
+    from oracle import binding as ob
+    return configure(ob.OracleRenderer(w, h), name, True)
+
+
+def hip_scene(name, w, h, device=0):
+    import volren_amd
+    return configure(volren_amd.Renderer(w, h, device=device), name, False)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-30)))
+
+
+def synthetic_density(n, seed=1234, blobs=24):
+    """Deterministic smoke-like dense field [z][y][x] in [0, 5], ~25 % non-zero (SURVEY 8d, C4 generator, small)."""
+    rs = np.random.RandomState(seed)
+    z, y, x = np.meshgrid(*(np.linspace(0, 1, n, dtype=np.float32),) * 3, indexing="ij")
+    f = np.zeros((n, n, n), np.float32)
+    for _ in range(blobs):
+        c = rs.uniform(0.2, 0.8, 3).astype(np.float32)
+        s = np.float32(rs.uniform(0.05, 0.15))
+        a = np.float32(rs.uniform(0.3, 1.0))
+        f += a * np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (2 * s * s))
+    thr = np.quantile(f, 0.75)
+    f = np.maximum(f - thr, 0)
+    return (f * (5.0 / f.max())).astype(np.float32)

@@ -1,0 +1,37 @@
+// environment.h -- mirror of the reference's Environment (src/environment.h:7-23): an HDR environment map plus
+// the 512x512 importance map whose mip pyramid is the hierarchical CDF sampled by sample_environment
+// (common.glsl:100-146).  Device memory replaces the two GL textures.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "devmem.h"
+#include "hostmath.h"
+
+namespace vr {
+
+class Environment {
+public:
+    explicit Environment(const std::string& path);                       // Radiance .hdr
+    Environment(const float* rgb_top_first, int w, int h);               // Environment(Texture2D) equivalent
+    virtual ~Environment();
+
+    explicit operator bool() const { return envmap && impmap; }
+    uint32_t num_mip_levels() const;
+    uint32_t dimension() const;
+
+    // data (names as in the reference)
+    mat3 transform;
+    float strength;
+    DeviceBufferPtr envmap;      // RGBA32F texels, row 0 = bottom of the image (GL texture order)
+    DeviceBufferPtr impmap;      // R32F pyramid: 512^2, 256^2, ..., 1
+    int width = 0, height = 0;
+
+    std::vector<float> download_impmap() const;
+
+private:
+    void build(const float* rgb_top_first, int w, int h);
+};
+
+}  // namespace vr

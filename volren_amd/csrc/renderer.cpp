@@ -1,0 +1,333 @@
+// renderer.cpp -- RendererHIP (see renderer.h).  Host marshalling follows src/renderer.cpp:29-50 (init),
+// :56-76 (commit), :78-145 (trace), :159-225 (grid upload), :227-242 (unit cube).
+#include "renderer.h"
+
+#include <cfloat>
+#include <cstring>
+#include <iostream>
+
+#include "vr_device.h"
+
+namespace vr {
+
+void set_sched_thresholds(const int32_t thr[8]);   // vr_kernels.hip (tuning hook)
+
+mat3 Camera::view_inverse() const {
+    const vec3 f = normalize(dir);
+    const vec3 s = normalize(cross(f, up));
+    const vec3 u = cross(s, f);
+    mat3 r(0.0f);
+    r.m[0] = s.x; r.m[1] = s.y; r.m[2] = s.z;
+    r.m[3] = u.x; r.m[4] = u.y; r.m[5] = u.z;
+    r.m[6] = -f.x; r.m[7] = -f.y; r.m[8] = -f.z;
+    return r;
+}
+
+RendererHIP::~RendererHIP() {
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+}
+
+void RendererHIP::init() {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        throw std::runtime_error("RendererHIP::init: no HIP device available (this renderer has no CPU path)");
+    if (!volume) volume = std::make_shared<Volume>();
+    if (!environment) {
+        const float white[3] = { 1.f, 1.f, 1.f };             // renderer.cpp:36-38: 1x1 white background
+        environment = std::make_shared<Environment>(white, 1, 1);
+    }
+    if (!ev0_) { VR_HIP(hipEventCreate(&ev0_)); VR_HIP(hipEventCreate(&ev1_)); }
+    if (!status_) {
+        status_ = make_device_buffer(sizeof(uint32_t));
+        VR_HIP(hipMemset(status_->get(), 0, sizeof(uint32_t)));
+    }
+    if (!color && resolution.x > 0 && resolution.y > 0) resize((uint32_t)resolution.x, (uint32_t)resolution.y);
+}
+
+void RendererHIP::resize(uint32_t w, uint32_t h) {
+    if (w == 0 || h == 0) throw std::runtime_error("RendererHIP::resize: empty framebuffer");
+    resolution = { (int)w, (int)h };
+    color = make_device_buffer((size_t)w * h * 4 * sizeof(float));
+    display.reset();
+    VR_HIP(hipMemset(color->get(), 0, color->size_bytes()));
+    if (!tiles_host_.empty()) set_tiles(tiles_host_);
+}
+
+void RendererHIP::reset() { sample = 0; }
+
+// ---------------------------------------------------------------------------------------------------
+void RendererHIP::commit() {
+    density_grids.clear();
+    emission_grids.clear();
+    majorant_emission = 0.f;
+    maj_key_ = MajKey{};
+    std::cout << "Preparing brick grids for HIP..." << std::endl;
+    for (const auto& frame : volume->grids) {
+        Volume::GridPtr density_grid = frame.at("density");       // throws std::out_of_range like the reference
+        density_grids.push_back(brick_grid_to_device(Volume::to_brick_grid(density_grid)));
+        Volume::GridPtr emission_grid;
+        for (const char* name : { "flame", "flames", "temperature" }) {
+            auto it = frame.find(name);
+            if (it != frame.end()) { emission_grid = it->second; break; }
+        }
+        if (emission_grid) {
+            emission_grids.push_back(brick_grid_to_device(Volume::to_brick_grid(emission_grid)));
+            majorant_emission = std::max(majorant_emission, emission_grid->minorant_majorant().second);
+        }
+    }
+}
+
+BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>& g) {
+    BrickGridHIP out;
+    const uvec3 nb = g->n_bricks;
+    const size_t n_bricks = (size_t)nb.x * nb.y * nb.z;
+    if (n_bricks == 0) throw std::runtime_error("brick_grid_to_device: empty grid");
+    if (g->range_mipmaps.size() > 3) throw std::runtime_error("brick_grid_to_device: at most 3 range mips are supported");
+    out.nb[0] = (int)nb.x; out.nb[1] = (int)nb.y; out.nb[2] = (int)nb.z;
+    out.transform = g->transform;
+    // atlas: 3D texture of 8^3 blocks -> brick-major slots of 512 contiguous bytes, plus one all-zero slot that
+    // absorbs pointers outside the atlas (GL: undefined fetch)
+    const uvec3 ad = g->atlas.stride;
+    const uint32_t sx = ad.x / 8, sy = ad.y / 8, sz = ad.z / 8;
+    const size_t n_slots = (size_t)sx * sy * sz;
+    const uint32_t zero_slot = (uint32_t)n_slots;
+    std::vector<uint8_t> atlas((n_slots + 1) * 512, 0);
+    for (uint32_t pz = 0; pz < sz; ++pz)
+        for (uint32_t py = 0; py < sy; ++py)
+            for (uint32_t px = 0; px < sx; ++px) {
+                uint8_t* dst = &atlas[(((size_t)pz * sy + py) * sx + px) * 512];
+                for (uint32_t z = 0; z < 8; ++z)
+                    for (uint32_t y = 0; y < 8; ++y)
+                        memcpy(dst + z * 64 + y * 8, &g->atlas.data[g->atlas.index(px * 8, py * 8 + y, pz * 8 + z)], 8);
+            }
+    std::vector<BrickRec> recs(n_bricks);
+    for (size_t i = 0; i < n_bricks; ++i) {
+        const uint32_t ind = g->indirection.data[i], rg = g->range.data[i];
+        const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
+        const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
+        BrickRec r;
+        r.slot = (px < sx && py < sy && pz < sz) ? (uint32_t)(((size_t)pz * sy + py) * sx + px) : zero_slot;
+        r.rmin = lo;
+        r.rdiff = hi - lo;
+        r.range = rg;
+        recs[i] = r;
+    }
+    // range words of all mips, mip m has ceil(nb / 2^m) cells per axis
+    std::vector<uint32_t> words(g->range.data);
+    out.n_mips = (int)g->range_mipmaps.size();
+    out.mip_off[0] = 0;
+    for (int m = 1; m <= 3; ++m) out.mip_off[m] = 0;
+    for (int m = 1; m <= out.n_mips; ++m) {
+        const auto& mm = g->range_mipmaps[m - 1];
+        const uint32_t rnd = (1u << m) - 1u;
+        if (mm.stride.x != ((nb.x + rnd) >> m) || mm.stride.y != ((nb.y + rnd) >> m) || mm.stride.z != ((nb.z + rnd) >> m))
+            throw std::runtime_error("brick_grid_to_device: range mip dimensions are not ceil(n_bricks / 2^m)");
+        out.mip_off[m] = (int32_t)words.size();
+        words.insert(words.end(), mm.data.begin(), mm.data.end());
+    }
+    out.n_cells = (int32_t)words.size();
+    out.bricks = make_device_buffer(recs.size() * sizeof(BrickRec));
+    out.bricks->upload(recs.data(), recs.size() * sizeof(BrickRec));
+    out.atlas = make_device_buffer(atlas.size());
+    out.atlas->upload(atlas.data(), atlas.size());
+    out.range_words = make_device_buffer(words.size() * sizeof(uint32_t));
+    out.range_words->upload(words.data(), words.size() * sizeof(uint32_t));
+    out.majorant = make_device_buffer(words.size() * sizeof(float));
+    return out;
+}
+
+void RendererHIP::scale_and_move_to_unit_cube() {
+    // max AABB over the whole volume (animation); FLT_MIN start value is the reference's quirk (renderer.cpp:229)
+    vec3 bb_min(FLT_MAX), bb_max(FLT_MIN);
+    for (const auto& frame : volume->grids) {
+        const auto grid = frame.at("density");
+        const uvec3 e = grid->index_extent();
+        bb_min = vmin(bb_min, transform_point(grid->transform, vec3(0.f, 0.f, 0.f)));
+        bb_max = vmax(bb_max, transform_point(grid->transform, vec3((float)e.x, (float)e.y, (float)e.z)));
+    }
+    const vec3 extent = bb_max - bb_min;
+    const float size = std::fmax(extent.x, std::fmax(extent.y, extent.z));
+    if (size != 1.f) {
+        volume->transform = scale_then_translate(1.f / size, -bb_min - extent * 0.5f);
+        density_scale *= size;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+static void copy3(float* dst, vec3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+
+static GridView make_view(const BrickGridHIP& g) {
+    GridView v;
+    v.bricks = g.bricks->as<BrickRec>();
+    v.atlas = g.atlas->as<uint8_t>();
+    v.majorant = g.majorant->as<float>();
+    for (int i = 0; i < 3; ++i) v.nb[i] = g.nb[i];
+    for (int i = 0; i < 4; ++i) v.mip_off[i] = g.mip_off[i];
+    v.n_mips = g.n_mips;
+    return v;
+}
+
+void RendererHIP::fill_params(SceneParams& P) {
+    if (!volume || volume->grids.empty() || density_grids.empty())
+        throw std::runtime_error("RendererHIP::trace: no volume committed");
+    if (volume->grid_frame_counter >= density_grids.size())
+        throw std::runtime_error("RendererHIP::trace: grid_frame_counter out of range (commit() after changing the volume)");
+    memset(&P, 0, sizeof P);
+    Uniforms& u = P.u;
+    u.bounces = bounces;
+    u.seed = seed;
+    u.show_environment = show_environment ? 1 : 0;
+    // camera
+    copy3(u.cam_pos, camera.pos);
+    u.cam_fov = camera.fov_degree;
+    const mat3 ct = camera.view_inverse();
+    memcpy(u.cam_transform, ct.m, sizeof ct.m);
+    P.cam_z = -0.5f / tan_(0.5f * kPi * camera.fov_degree / 180.f);
+    // volume
+    const auto [bb_min, bb_max] = volume->AABB();
+    const auto [mn, maj] = volume->minorant_majorant();
+    copy3(u.vol_bb_min, bb_min + vol_clip_min * (bb_max - bb_min));
+    copy3(u.vol_bb_max, bb_min + vol_clip_max * (bb_max - bb_min));
+    u.vol_minorant = mn * density_scale;
+    u.vol_majorant = maj * density_scale;
+    u.vol_inv_majorant = 1.f / (maj * density_scale);
+    copy3(u.vol_albedo, albedo);
+    u.vol_phase_g = phase;
+    u.vol_density_scale = density_scale;
+    u.vol_emission_scale = emission_scale;
+    u.vol_emission_norm = majorant_emission > 0.f ? 1.f / std::fmax(majorant_emission, 1e-4f) : 1.f;
+    // density brick grid data
+    const BrickGridHIP& density = density_grids[volume->grid_frame_counter];
+    const mat4 dt = volume->transform * density.transform;
+    const mat4 dti = inverse(dt);
+    memcpy(u.vol_density_transform, dt.m, sizeof dt.m);
+    memcpy(u.vol_density_inv_transform, dti.m, sizeof dti.m);
+    P.density = make_view(density);
+    // emission brick grid data
+    if (volume->grid_frame_counter < emission_grids.size()) {
+        const BrickGridHIP& emission = emission_grids[volume->grid_frame_counter];
+        const mat4 et = volume->transform * emission.transform;
+        const mat4 eti = inverse(et);
+        memcpy(u.vol_emission_transform, et.m, sizeof et.m);
+        memcpy(u.vol_emission_inv_transform, eti.m, sizeof eti.m);
+        const mat4 efd = eti * dt;
+        memcpy(P.emission_from_density, efd.m, sizeof efd.m);
+        P.emission = make_view(emission);
+        u.has_emission = 1;
+    }
+    // transfer function
+    if (transferfunc) {
+        u.use_tf = 1;
+        u.tf_size = transferfunc->size();
+        u.tf_window_left = transferfunc->window_left;
+        u.tf_window_width = transferfunc->window_width;
+        P.tf_lut = transferfunc->lut_ssbo->as<float>();
+    }
+    // environment
+    const mat3 eit = inverse(environment->transform);
+    memcpy(u.env_transform, environment->transform.m, sizeof eit.m);
+    memcpy(u.env_inv_transform, eit.m, sizeof eit.m);
+    u.env_strength = environment->strength;
+    u.env_imp_inv_dim[0] = u.env_imp_inv_dim[1] = 1.f / (float)environment->dimension();
+    u.env_imp_base_mip = (int)std::floor(std::log2((float)environment->dimension()));
+    P.envmap = environment->envmap->as<float>();
+    P.env_w = environment->width; P.env_h = environment->height;
+    P.impmap = environment->impmap->as<float>();
+    P.imp_dim = (int)environment->dimension();
+    u.resolution[0] = resolution.x; u.resolution[1] = resolution.y;
+    u.integrator = integrator;
+}
+
+void RendererHIP::update_majorants(const SceneParams& P, BrickGridHIP& g) {
+    MajKey k;
+    k.density_scale = density_scale;
+    k.tf = transferfunc.get();
+    k.tf_version = transferfunc ? transferfunc->version : 0;
+    k.wl = transferfunc ? transferfunc->window_left : 0.f;
+    k.ww = transferfunc ? transferfunc->window_width : 0.f;
+    k.frame = volume->grid_frame_counter;
+    if (k.density_scale == maj_key_.density_scale && k.tf == maj_key_.tf && k.tf_version == maj_key_.tf_version &&
+        k.wl == maj_key_.wl && k.ww == maj_key_.ww && k.frame == maj_key_.frame)
+        return;
+    launch_majorants(P, g.range_words->as<uint32_t>(), g.n_cells, g.majorant->as<float>(), stream);
+    VR_HIP(hipGetLastError());
+    maj_key_ = k;
+}
+
+void RendererHIP::set_tiles(const std::vector<int32_t>& tile_ids) {
+    tiles_host_ = tile_ids;
+    tiles_dev_.reset();
+    if (tile_ids.empty()) return;
+    if (resolution.x > 0) {
+        const int n_all = ((resolution.x + 15) / 16) * ((resolution.y + 15) / 16);
+        for (int32_t t : tile_ids)
+            if (t < 0 || t >= n_all) throw std::runtime_error("set_tiles: tile id out of range");   // never launch out-of-bounds tiles
+    }
+    tiles_dev_ = make_device_buffer(tile_ids.size() * sizeof(int32_t));
+    tiles_dev_->upload(tile_ids.data(), tile_ids.size() * sizeof(int32_t));
+}
+
+void RendererHIP::launch(int n) {
+    if (n <= 0) return;
+    if (!color) throw std::runtime_error("RendererHIP::trace: no framebuffer (call resize first)");
+    SceneParams P;
+    fill_params(P);
+    update_majorants(P, density_grids[volume->grid_frame_counter]);
+    const int tiles_x = (resolution.x + 15) / 16, tiles_y = (resolution.y + 15) / 16;
+    const int32_t* tiles = tiles_dev_ ? tiles_dev_->as<int32_t>() : nullptr;
+    const int n_tiles = tiles_dev_ ? (int)tiles_host_.size() : tiles_x * tiles_y;
+    VR_HIP(hipEventRecord(ev0_, stream));
+    launch_pathtrace(P, color->as<float>(), tiles, n_tiles, sample + 1, n, status_->as<uint32_t>(), stream);
+    VR_HIP(hipGetLastError());
+    VR_HIP(hipEventRecord(ev1_, stream));
+    timing_pending_ = true;
+    sample += n;
+}
+
+void RendererHIP::trace() { launch(1); }
+
+void RendererHIP::render(int n) {
+    if (n <= 0) n = sppx - sample;
+    launch(n);
+}
+
+void RendererHIP::draw() {
+    if (!color) return;
+    if (!display || display->size_bytes() != color->size_bytes()) display = make_device_buffer(color->size_bytes());
+    VR_HIP(hipMemcpyAsync(display->get(), color->get(), color->size_bytes(), hipMemcpyDeviceToDevice, stream));
+    if (tonemapping) {
+        launch_tonemap(display->as<float>(), resolution.x, resolution.y, tonemap_exposure, tonemap_gamma, stream);
+        VR_HIP(hipGetLastError());
+    }
+}
+
+double RendererHIP::last_kernel_ms() {
+    if (timing_pending_) {
+        VR_HIP(hipEventSynchronize(ev1_));
+        float ms = 0.f;
+        VR_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+        last_ms_ = (double)ms;
+        timing_pending_ = false;
+    }
+    return last_ms_;
+}
+
+void RendererHIP::synchronize() const { VR_HIP(hipStreamSynchronize(stream)); }
+
+void RendererHIP::download(float* rgba) const {
+    if (!color) throw std::runtime_error("RendererHIP::download: no framebuffer");
+    color->download(rgba, color->size_bytes(), stream);
+}
+void RendererHIP::download_display(float* rgba) const {
+    if (!display) throw std::runtime_error("RendererHIP::download_display: draw() first");
+    display->download(rgba, display->size_bytes(), stream);
+}
+
+uint32_t RendererHIP::watchdog_status() {
+    uint32_t s = 0;
+    status_->download(&s, sizeof s, stream);
+    return s;
+}
+
+}  // namespace vr

@@ -1,0 +1,126 @@
+// renderer.h -- RendererHIP: the MI355X drop-in for the reference's RendererOpenGL (src/renderer.h:16-63).
+// Same public fields, same call protocol (mutate fields -> commit() after changing the volume -> reset() ->
+// trace() once per sample, result = running mean in `color`, RGBA32F, row 0 at the bottom).  Differences that
+// are visible to a caller are additions only:
+//   * render(spp): all remaining samples in ONE fused launch (what bindings.cpp:124-132 loops over trace());
+//     trace() itself still advances by exactly one sample,
+//   * the camera and the resolution are explicit members instead of cppgl globals
+//     (current_camera(), Context::resolution(): renderer.cpp:47,93-95,137),
+//   * set_tiles(): restrict a renderer to a subset of 16x16 framebuffer tiles (multi-GPU sharding).
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "devmem.h"
+#include "environment.h"
+#include "grids.h"
+#include "transferfunc.h"
+#include "vr_scene.h"
+
+namespace vr {
+
+// stand-in for cppgl's camera (pos/dir/up/fov_degree are what the renderer reads: renderer.cpp:93-95)
+struct Camera {
+    vec3 pos{ 1.f, 0.f, 1.f };                 // main.cpp:458
+    vec3 dir{ -0.70710678f, 0.f, -0.70710678f };
+    vec3 up{ 0.f, 1.f, 0.f };
+    float fov_degree = 70.f;                   // cppgl default (unverified): always pass --cam_fov
+    mat3 view_inverse() const;                 // inverse(mat3(lookAt(pos, pos+dir, up))): columns right, up, -forward
+};
+
+// replaces BrickGridGL (renderer.h:9-14): the three textures become three device arrays (+ majorant cache)
+struct BrickGridHIP {
+    DeviceBufferPtr bricks;        // BrickRec per brick
+    DeviceBufferPtr atlas;         // brick-major u8 voxels, 512 B per slot
+    DeviceBufferPtr range_words;   // fp16x2 range of every cell of mips 0..n_mips (input of the majorant kernel)
+    DeviceBufferPtr majorant;      // effective majorants (float), same indexing as range_words
+    int32_t nb[3] = { 0, 0, 0 };
+    int32_t mip_off[4] = { 0, 0, 0, 0 };
+    int32_t n_mips = 0;
+    int32_t n_cells = 0;
+    mat4 transform;
+};
+
+struct RendererHIP {
+    // Renderer interface
+    void init();
+    void resize(uint32_t w, uint32_t h);
+    void commit();
+    void trace();
+    void draw();
+    void reset();
+
+    // all of `n` further samples in one launch (n <= 0: up to sppx)
+    void render(int n = 0);
+
+    // helper to convert brick grid to device arrays
+    BrickGridHIP brick_grid_to_device(const std::shared_ptr<BrickGrid>& grid);
+    // scale and move volume to fit into [-0.5, 0.5] unit cube
+    void scale_and_move_to_unit_cube();
+
+    // General settings
+    int sample = 0;
+    int sppx = 1024;
+    int seed = 42;
+    int bounces = 100;
+    float tonemap_exposure = 5.f;
+    float tonemap_gamma = 2.2f;
+    bool tonemapping = true;
+    bool show_environment = true;
+
+    // Volume settings
+    vec3 albedo = vec3(0.9f);           // volume albedo
+    float phase = 0.f;                  // volume phase (henyey-greenstein g parameter)
+    float density_scale = 1.f;          // volume density scaling factor
+    float emission_scale = 100.f;       // volume emission scaling factor
+
+    // device data
+    DeviceBufferPtr color;              // RGBA32F running mean, W*H texels, row 0 = bottom
+    DeviceBufferPtr display;            // tonemapped copy written by draw()
+    std::vector<BrickGridHIP> density_grids;
+    std::vector<BrickGridHIP> emission_grids;
+    float majorant_emission = 0.f;
+
+    // Volume data
+    std::shared_ptr<Volume> volume;
+
+    // Volume clip planes
+    vec3 vol_clip_min = vec3(0.f);
+    vec3 vol_clip_max = vec3(1.f);
+
+    // Scene data
+    std::shared_ptr<Environment> environment;
+    std::shared_ptr<TransferFunction> transferfunc;
+
+    // ---- additions ----
+    Camera camera;
+    ivec2 resolution{ 0, 0 };
+    hipStream_t stream = nullptr;
+    int integrator = 0;                               // 0: DDA tracking (both reference kernels)
+
+    void set_tiles(const std::vector<int32_t>& tile_ids);     // empty = whole frame
+    void fill_params(SceneParams& P);                          // renderer.cpp:88-138
+    void download(float* rgba) const;                          // color -> host
+    void download_display(float* rgba) const;
+    void synchronize() const;
+    double last_kernel_ms();                                    // HIP-event time of the last launch (waits for it)
+    uint32_t watchdog_status();
+    ~RendererHIP();
+
+private:
+    void update_majorants(const SceneParams& P, BrickGridHIP& g);
+    void launch(int n);
+    std::vector<int32_t> tiles_host_;
+    DeviceBufferPtr tiles_dev_;
+    DeviceBufferPtr status_;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    double last_ms_ = 0.0;
+    bool timing_pending_ = false;
+    // majorant cache key
+    struct MajKey { float density_scale = -1.f; uint64_t tf_version = ~0ull; float wl = 0, ww = 0; const void* tf = nullptr; size_t frame = ~(size_t)0; } maj_key_;
+};
+
+using Renderer = RendererHIP;
+
+}  // namespace vr

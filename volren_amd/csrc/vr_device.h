@@ -1,0 +1,37 @@
+// vr_device.h -- host-callable launchers of the HIP kernels in vr_kernels.hip (all asynchronous on `stream`).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vr_scene.h"
+
+namespace vr {
+
+// Path tracing: runs samples first_sample .. first_sample+n_samples-1 (1-based, the reference's current_sample)
+// for every pixel of the listed 16x16 tiles and updates the RGBA32F running mean in `fb` (W*H texels, row 0 at
+// the bottom).  tiles == nullptr: all tiles of the frame.  status[0] is set non-zero if a wavefront trips the
+// step watchdog.
+void launch_pathtrace(const SceneParams& P, float* fb, const int32_t* tiles, int32_t n_tiles,
+                      int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream);
+
+// env_setup.glsl:18-34 + glGenerateMipmap (environment.cpp:27-31): importance pyramid of a dim x dim map
+void launch_build_impmap(const float* envmap_rgba, int32_t env_w, int32_t env_h, int32_t dim, float* pyramid, hipStream_t stream);
+
+// effective majorant of every cell of every range mip:
+//   m = density_scale * float(range.y);  with a LUT: m = vol_majorant * tf_lookup(m * vol_inv_majorant).a
+// (common.glsl:278-281, 425, 472)
+void launch_majorants(const SceneParams& P, const uint32_t* range_words_all_mips, int32_t n_cells, float* out, hipStream_t stream);
+
+// tonemap.glsl:29-36 in place
+void launch_tonemap(float* fb, int32_t w, int32_t h, float exposure, float gamma, hipStream_t stream);
+
+// multi-GPU shard helpers: copy owned 16x16 tiles frame <-> compact tile-major buffer (256 texels per tile)
+void launch_pack_tiles(const float* fb, int32_t w, int32_t h, const int32_t* tiles, int32_t n_tiles, float* packed, hipStream_t stream);
+void launch_unpack_tiles(const float* packed, const int32_t* tiles, int32_t n_tiles, float* fb, int32_t w, int32_t h, hipStream_t stream);
+
+// unit-test probe: out[i] = f(a[i], b[i]) with the device build of vr_math.h
+// fn: 0 log 1 sin 2 cos 3 tan 4 acos 5 atan2 6 exp 7 pow 8 asin 9 a/b 10 sqrt 11 fma(a,b,a) 12 float(u8)/255
+void launch_math_probe(int32_t fn, const float* a, const float* b, float* out, int32_t n, hipStream_t stream);
+
+}  // namespace vr

@@ -1,0 +1,54 @@
+// vr_scene.h -- the kernel argument block: the reference's uniforms (src/renderer.cpp:88-138) plus device views
+// of the scene arrays.  Plain data, shared by the host marshalling code and the kernels.
+#pragma once
+
+#include <stdint.h>
+
+namespace vr {
+
+// One brick of a voldata::BrickGrid, repacked for HBM (DESIGN.md "Data layout"):
+//   slot  : index of the brick's 8x8x8 u8 block in the brick-major atlas (512 contiguous bytes per slot)
+//   rmin  : float(range.x); rdiff = float(range.y) - float(range.x)  (both exact/IEEE, done once at commit)
+//   range : the file's 2 x fp16 word, low = min, high = max (GL_RG16F in renderer.cpp:181-183), kept for reference
+// one 16-byte load per tap;
+// replaces the indirection (RGB10_A2UI) + range + 3D-atlas texture triple of common.glsl:268-275.
+struct alignas(16) BrickRec { uint32_t slot; float rmin; float rdiff; uint32_t range; };
+
+struct GridView {
+    const BrickRec* bricks;      // n_bricks.x*y*z, x fastest
+    const uint8_t* atlas;        // slots * 512 bytes, voxel (x&7) + 8*(y&7) + 64*(z&7)
+    const float* majorant;       // all mips, flat: "effective" majorant = density_scale * range.y, TF-remapped when a LUT is bound
+    int32_t nb[3];               // bricks per axis (mip 0); mip m has ceil(nb / 2^m) cells per axis
+    int32_t mip_off[4];          // float offset of each mip level inside `majorant`
+    int32_t n_mips;              // range mips available above level 0 (reference: 3)
+};
+
+struct Uniforms {                // names follow the GLSL uniforms
+    int32_t bounces, seed, show_environment;
+    float cam_pos[3], cam_fov, cam_transform[9];
+    float vol_bb_min[3], vol_bb_max[3];
+    float vol_minorant, vol_majorant, vol_inv_majorant;
+    float vol_albedo[3], vol_phase_g, vol_density_scale, vol_emission_scale, vol_emission_norm;
+    float vol_density_transform[16], vol_density_inv_transform[16];
+    float vol_emission_transform[16], vol_emission_inv_transform[16];
+    uint32_t tf_size; float tf_window_left, tf_window_width;
+    float env_transform[9], env_inv_transform[9], env_strength, env_imp_inv_dim[2];
+    int32_t env_imp_base_mip;
+    int32_t resolution[2];
+    int32_t use_tf, has_emission, integrator;
+};
+
+struct SceneParams {
+    Uniforms u;
+    GridView density;
+    GridView emission;
+    float emission_from_density[16];   // vol_emission_inv_transform * vol_density_transform (common.glsl:325)
+    const float* tf_lut;               // tf_size x vec4 (std430 SSBO binding 4)
+    const float* envmap;               // env_w*env_h texels, RGBA32F (A unused), row 0 = v~0
+    int32_t env_w, env_h;
+    const float* impmap;               // importance pyramid, level 0 (dim^2) first, 2x2 box mips after it
+    int32_t imp_dim;
+    float cam_z;                       // -.5f / tan(.5f * M_PI * cam_fov / 180.f), common.glsl:78 (uniform per frame)
+};
+
+}  // namespace vr
