@@ -372,8 +372,8 @@ class OracleRenderer:
         if self.lut is not None:
             p.tf_size = self.lut.shape[0]
             p.use_tf = 1
-        p.tf_window_left = self.tf_window_left
-        p.tf_window_width = self.tf_window_width
+            p.tf_window_left = self.tf_window_left        # transferfunc->set_uniforms: only with a LUT (renderer.cpp:126)
+            p.tf_window_width = self.tf_window_width
         p.env_transform[:] = self.env_transform.tolist()
         inv = np.zeros(9, np.float32)
         lib().orc_mat3_inverse(fptr(self.env_transform), fptr(inv))

