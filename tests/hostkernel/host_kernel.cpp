@@ -96,18 +96,45 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
     P.impmap = impmap; P.imp_dim = imp_dim;
     P.cam_z = -0.5f / tan_(0.5f * kPi * u.cam_fov / 180.f);
     long long steps = 0;
-    const int W = u.resolution[0];
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) {
-            Lane l;
-            float* px = fb + 4 * ((size_t)y * W + x);
-            lane_init(l, x, y, first_sample, n_samples, px);
-            while (l.state != ST_DONE) {
-                if (u.use_tf) lane_step<true>(l, P); else lane_step<false>(l, P);
-                if (++steps > (1ll << 40)) return -1;
+    const int W = u.resolution[0], H = u.resolution[1];
+    // wave-sized work units exactly like the HIP kernel: 8x8 tile x chunk of samples -> sample buffer -> running mean
+    const int spu = n_samples < 32 ? n_samples : 32;
+    std::vector<float> sbuf((size_t)spu * 64 * 4);
+    for (int ty = y0 & ~7; ty < y1; ty += 8)
+        for (int tx = x0 & ~7; tx < x1; tx += 8)
+            for (int c0 = 0; c0 < n_samples; c0 += spu) {
+                WorkUnit wu;
+                wu.px0 = tx; wu.py0 = ty; wu.first_sample = first_sample + c0;
+                const int sc = (n_samples - c0) < spu ? (n_samples - c0) : spu;
+                wu.n_items = sc * 64; wu.base = 0u; wu.out = sbuf.data();
+                // 64 lanes advanced round-robin: exercises the item hand-out in a different order than the GPU does
+                struct ColdHost {
+                    float v[C_COUNT];
+                    float ld(int32_t f) const { return v[f]; }
+                    void st(int32_t f, float x) { v[f] = x; }
+                };
+                Hot lanes[64];
+                ColdHost cold[64] = {};
+                for (auto& l : lanes) hot_init(l);
+                uint32_t next_item = 0;
+                bool live = true;
+                while (live) {
+                    live = false;
+                    for (int i = 0; i < 64; ++i) {
+                        Hot& l = lanes[i];
+                        if (l.state == ST_DONE) continue;
+                        live = true;
+                        if (u.use_tf) lane_step<true>(l, cold[i], P, wu, next_item); else lane_step<false>(l, cold[i], P, wu, next_item);
+                        if (++steps > (1ll << 40)) return -1;
+                    }
+                }
+                for (int p = 0; p < 64; ++p) {
+                    const int x = tx + (p & 7), y = ty + (p >> 3);
+                    if (x < x0 || x >= x1 || y < y0 || y >= y1 || x >= W || y >= H) continue;
+                    float* px = fb + 4 * ((size_t)y * W + x);
+                    for (int k = 0; k < sc; ++k) accumulate_sample(px, &sbuf[4 * ((size_t)k * 64 + p)], first_sample + c0 + k);
+                }
             }
-            px[0] = l.acc[0]; px[1] = l.acc[1]; px[2] = l.acc[2]; px[3] = l.acc[3];
-        }
     return steps;
 }
 

@@ -1,0 +1,23 @@
+import sys, json, time
+import os; sys.path[:0]=[os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))]
+import numpy as np, scenes, volren_amd as va
+cfg = sys.argv[1] if len(sys.argv)>1 else "c2"
+w=h=int(sys.argv[2]) if len(sys.argv)>2 else 512
+spp=int(sys.argv[3]) if len(sys.argv)>3 else 64
+thr = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv)>4 else None
+r = scenes.hip_scene(cfg,w,h)
+if thr: va.set_sched(thr+[0])
+r.render(spp); r.reset()
+va.sched_stats(True)
+r.render(spp); ms=r.last_kernel_ms()
+st = va.sched_stats(False, read=True)
+print(cfg,w,h,spp,"thr",thr,"ms %.2f  Msamples/s %.1f"%(ms, w*h*spp/ms/1e3))
+ns = w*h*spp
+tot_exec=0
+for k in va.renderer.STATE_NAMES:
+    e,l = st[k]; tot_exec+=e
+    cyc = st["cycles"][k]
+    print("  %-8s exec %10d  lanes/exec %5.1f  lane-steps/sample %6.2f  exec/wave-sample %6.2f  cyc/exec %7.0f  share %5.1f%%"%(k,e,l/max(e,1),l/ns,e/(ns/64), cyc/max(e,1), 100.0*cyc/max(st["wave_cycles"],1)))
+print("  wave lifetime cycles/wave-sample %.0f ; unaccounted (scheduler) %.1f%%"%(st["wave_cycles"]/(ns/64), 100.0*(1-sum(st["cycles"].values())/max(st["wave_cycles"],1))))
+print("  avg resident waves (at 2.4 GHz) %.0f  (waves launched %d)"%(st["wave_cycles"]/(ms*2.4e6), st["waves"]))
+print("  iterations/wave-sample %.1f  blocks/iter %.2f"%(st["iterations"]/(ns/64), tot_exec/st["iterations"]))

@@ -12,7 +12,7 @@
 #include "renderer.h"
 #include "vr_device.h"
 
-namespace vr { void set_sched_thresholds(const int32_t thr[8]); }
+namespace vr { void set_sched_thresholds(const int32_t thr[8]); void set_stats_buffer(unsigned long long* dev); }
 
 struct vr_renderer {
     vr::RendererHIP impl;
@@ -387,6 +387,22 @@ int vr_set_sched(const int32_t thr[8]) {
     if (!thr) return fail(VR_ERR_ARG, "null argument");
     vr::set_sched_thresholds(thr);
     return VR_OK;
+}
+
+// scheduler statistics of the path-tracing kernel: enable != 0 allocates/zeros 18 device counters; out (18 x u64, may be
+// NULL) receives [executions, active lanes] x 7 states, then [14],[15] unused, [16] wave iterations, [17] waves
+int vr_sched_stats(int enable, unsigned long long* out) {
+    static unsigned long long* dev = nullptr;
+    return guard([&] {
+        if (out && dev) { VR_HIP(hipDeviceSynchronize()); VR_HIP(hipMemcpy(out, dev, 26 * 8, hipMemcpyDeviceToHost)); }
+        if (enable) {
+            if (!dev) VR_HIP(hipMalloc((void**)&dev, 26 * 8));
+            VR_HIP(hipMemset(dev, 0, 26 * 8));
+            vr::set_stats_buffer(dev);
+        } else {
+            vr::set_stats_buffer(nullptr);
+        }
+    });
 }
 
 int vr_math_probe(int fn, const float* a, const float* b, float* out, int n) {

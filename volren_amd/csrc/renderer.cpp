@@ -2,6 +2,7 @@
 // :56-76 (commit), :78-145 (trace), :159-225 (grid upload), :227-242 (unit cube).
 #include "renderer.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cstring>
 #include <iostream>
@@ -39,8 +40,8 @@ void RendererHIP::init() {
     }
     if (!ev0_) { VR_HIP(hipEventCreate(&ev0_)); VR_HIP(hipEventCreate(&ev1_)); }
     if (!status_) {
-        status_ = make_device_buffer(sizeof(uint32_t));
-        VR_HIP(hipMemset(status_->get(), 0, sizeof(uint32_t)));
+        status_ = make_device_buffer(2 * sizeof(uint32_t));          // [0] watchdog flag, [1] work-queue head
+        VR_HIP(hipMemset(status_->get(), 0, 2 * sizeof(uint32_t)));
     }
     if (!color && resolution.x > 0 && resolution.y > 0) resize((uint32_t)resolution.x, (uint32_t)resolution.y);
 }
@@ -277,9 +278,19 @@ void RendererHIP::launch(int n) {
     const int tiles_x = (resolution.x + 15) / 16, tiles_y = (resolution.y + 15) / 16;
     const int32_t* tiles = tiles_dev_ ? tiles_dev_->as<int32_t>() : nullptr;
     const int n_tiles = tiles_dev_ ? (int)tiles_host_.size() : tiles_x * tiles_y;
+    // per-sample radiances live in a device pool; split the request so that one sub-launch fits the pool
+    const size_t per_sample = pathtrace_pool_floats(n_tiles, 1) * sizeof(float);
+    int per_launch = (int)std::max<size_t>(1, sample_pool_bytes / per_sample);
+    if (per_launch > 32) per_launch -= per_launch % 32;          // whole sample chunks (32 is a multiple of every unit size)
+    per_launch = std::min(per_launch, n);
+    const size_t need = pathtrace_pool_floats(n_tiles, per_launch) * sizeof(float);
+    if (!pool_ || pool_->size_bytes() < need) { pool_.reset(); pool_ = make_device_buffer(need); }
     VR_HIP(hipEventRecord(ev0_, stream));
-    launch_pathtrace(P, color->as<float>(), tiles, n_tiles, sample + 1, n, status_->as<uint32_t>(), stream);
-    VR_HIP(hipGetLastError());
+    for (int done = 0; done < n; done += per_launch) {
+        const int m = std::min(per_launch, n - done);
+        launch_pathtrace(P, color->as<float>(), pool_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, sample + 1 + done, m, status_->as<uint32_t>(), stream);
+        VR_HIP(hipGetLastError());
+    }
     VR_HIP(hipEventRecord(ev1_, stream));
     timing_pending_ = true;
     sample += n;

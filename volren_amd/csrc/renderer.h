@@ -98,6 +98,7 @@ struct RendererHIP {
     ivec2 resolution{ 0, 0 };
     hipStream_t stream = nullptr;
     int integrator = 0;                               // 0: DDA tracking (both reference kernels)
+    size_t sample_pool_bytes = (size_t)2 << 30;       // HBM budget of the per-sample radiance pool (16 B per pixel-sample)
 
     void set_tiles(const std::vector<int32_t>& tile_ids);     // empty = whole frame
     void fill_params(SceneParams& P);                          // renderer.cpp:88-138
@@ -114,6 +115,7 @@ private:
     std::vector<int32_t> tiles_host_;
     DeviceBufferPtr tiles_dev_;
     DeviceBufferPtr status_;
+    DeviceBufferPtr pool_;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     double last_ms_ = 0.0;
     bool timing_pending_ = false;

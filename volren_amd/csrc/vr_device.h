@@ -9,10 +9,12 @@
 namespace vr {
 
 // Path tracing: runs samples first_sample .. first_sample+n_samples-1 (1-based, the reference's current_sample)
-// for every pixel of the listed 16x16 tiles and updates the RGBA32F running mean in `fb` (W*H texels, row 0 at
-// the bottom).  tiles == nullptr: all tiles of the frame.  status[0] is set non-zero if a wavefront trips the
-// step watchdog.
-void launch_pathtrace(const SceneParams& P, float* fb, const int32_t* tiles, int32_t n_tiles,
+// for every pixel of the listed 16x16 tiles (kernel 1: per-sample radiances into `sample_pool`) and folds them in
+// sample order into the RGBA32F running mean `fb` (kernel 2; W*H texels, row 0 at the bottom).
+// tiles == nullptr: all tiles of the frame (n_tiles = their count).  sample_pool must hold
+// pathtrace_pool_floats(n_tiles, n_samples) floats; unit_counter is one device word (the work queue head).  status[0] is set non-zero if a wavefront trips the watchdog.
+size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples);
+void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream);
 
 // env_setup.glsl:18-34 + glGenerateMipmap (environment.cpp:27-31): importance pyramid of a dim x dim map

@@ -8,6 +8,9 @@
 // No LDS, no cross-lane data exchange: lanes only vote.  MFMA is not used (there is no dense contraction).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "vr_device.h"
 #include "vr_trace.h"
 
@@ -18,82 +21,219 @@ struct SchedParams {
     uint32_t max_iters;        // watchdog: scheduler iterations per wavefront
 };
 
-template <bool USE_TF>
-__global__ void __launch_bounds__(256)
-pathtrace_kernel(const SceneParams P, float* __restrict__ fb, const int32_t* __restrict__ tiles,
-                 int32_t first_sample, int32_t n_samples, const SchedParams S, uint32_t* __restrict__ status) {
-    const int32_t W = P.u.resolution[0], H = P.u.resolution[1];
-    const int32_t tiles_x = (W + 15) >> 4;
-    const int32_t tile = tiles ? tiles[blockIdx.x] : (int32_t)blockIdx.x;
-    const int32_t tx = tile % tiles_x, ty = tile / tiles_x;
-    const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int32_t px = tx * 16 + ((wave & 1) << 3) + (lane & 7);
-    const int32_t py = ty * 16 + ((wave >> 1) << 3) + (lane >> 3);
-    const bool valid = px < W && py < H;
+// Persistent wavefronts.  The frame's work is cut into units = one 8x8 pixel tile x `spu` consecutive samples
+// (64*spu items); unit u = ((chunk * n_tiles + tile_slot) * 4 + sub_tile) and its items occupy slots
+// [u*64*spu, (u+1)*64*spu) of the sample buffer.  Every wavefront pulls units from one global counter and refills
+// idle lanes item by item, WITHOUT waiting for its other lanes to finish: the only drain is at the end of the launch.
+struct LaunchDesc {
+    const int32_t* tiles;     // 16x16 tile ids (raster, row 0 = bottom) or nullptr = all tiles
+    int32_t n_tiles, first_sample, n_samples, spu;
+    uint32_t n_units;
+    uint32_t* unit_counter;   // zeroed before the launch
+};
 
-    Lane l;
-    float texel[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-    float4* fb4 = reinterpret_cast<float4*>(fb);
-    if (valid && first_sample > 1) {
-        const float4 c = fb4[(size_t)py * W + px];
-        texel[0] = c.x; texel[1] = c.y; texel[2] = c.z; texel[3] = c.w;
-    }
-    lane_init(l, px, py, first_sample, n_samples, texel);
-    if (!valid) l.state = ST_DONE;
+__device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, uint32_t u, float* sbuf) {
+    const uint32_t per_chunk = (uint32_t)D.n_tiles * 4u;
+    const uint32_t chunk = u / per_chunk, rem = u - chunk * per_chunk;
+    const uint32_t slot = rem >> 2, sub = rem & 3u;
+    const int32_t tiles_x = (W + 15) >> 4;
+    const int32_t tile = D.tiles ? D.tiles[slot] : (int32_t)slot;
+    const int32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    WorkUnit wu;
+    wu.px0 = tx * 16 + (int32_t)((sub & 1u) << 3);
+    wu.py0 = ty * 16 + (int32_t)((sub >> 1) << 3);
+    wu.first_sample = D.first_sample + (int32_t)chunk * D.spu;
+    wu.n_items = min(D.spu, D.n_samples - (int32_t)chunk * D.spu) * 64;
+    wu.base = u * (uint32_t)(D.spu * 64);
+    wu.out = sbuf;
+    return wu;
+}
+
+#ifndef VR_WAVES_PER_SIMD
+#define VR_WAVES_PER_SIMD 4
+#endif
+template <bool USE_TF, bool STATS>
+__global__ void __launch_bounds__(256, VR_WAVES_PER_SIMD)
+pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, const LaunchDesc D, const SchedParams S,
+                 uint32_t* __restrict__ status, unsigned long long* __restrict__ stats) {
+    const int32_t W = P.u.resolution[0];
+    const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+
+    WorkUnit wu;
+    wu.px0 = wu.py0 = 0; wu.first_sample = 1; wu.n_items = 0; wu.base = 0u; wu.out = sbuf;
+    uint32_t cursor = 0u;             // next item of the current unit (wave-uniform)
+    bool exhausted = false;           // the global queue has no more units
+
+    // cold path state of the workgroup's 4 wavefronts: [wave][field][lane] dwords, lanes on consecutive banks
+    __shared__ float cold_mem[4 * C_COUNT * 64];
+    struct ColdLDS {
+        float* base;
+        __device__ __forceinline__ float ld(int32_t f) const { return base[f * 64]; }
+        __device__ __forceinline__ void st(int32_t f, float v) { base[f * 64] = v; }
+    } c{ cold_mem + wave * (C_COUNT * 64) + lane };
+
+    Hot l;
+    hot_init(l);
 
     uint32_t iters = 0u;
+    // optional scheduler statistics (wave-uniform counters in scalar registers): executions and active lanes per state
+    uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
+#define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
+#define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
+    // Scheduler.  The hot pair MARCH/COLLIDE runs as ONE block per iteration (up to S.thr[ST_COLLIDE] march steps, then
+    // the collision code for every lane that reached one).  The rarer states are gated: a state's code runs when at least
+    // thr[state] lanes wait in it, or when the hot pair is running low on lanes (fewer than thr[ST_MARCH]) -- then every
+    // non-empty state is flushed.  Gates use fresh ballots in flow order (ESCAPE -> POSTNEE -> NEW -> NEE -> hot pair), so
+    // a lane can pass through several states in one iteration.
     for (;;) {
-        const int32_t st = l.state;
-        const int32_t n_new = __popcll(__ballot(st == ST_NEW));
-        const int32_t n_begin = __popcll(__ballot(st == ST_BEGIN));
-        const int32_t n_march = __popcll(__ballot(st == ST_MARCH));
-        const int32_t n_collide = __popcll(__ballot(st == ST_COLLIDE));
-        const int32_t n_nee = __popcll(__ballot(st == ST_NEE));
-        const int32_t n_post = __popcll(__ballot(st == ST_POSTNEE));
-        const int32_t n_escape = __popcll(__ballot(st == ST_ESCAPE));
-        if ((n_new | n_begin | n_march | n_collide | n_nee | n_post | n_escape) == 0) break;
+        const int32_t n_hot = __popcll(__ballot(l.state == ST_MARCH || l.state == ST_COLLIDE));
+        if (__ballot(l.state != ST_DONE) == 0ull) break;
         if (++iters > S.max_iters) {
             if (lane == 0) atomicOr(status, 1u);
             break;
         }
-        // most populated state always runs (progress guarantee); the others when they pass their threshold
-        int32_t best = ST_NEW, nbest = n_new;
-        if (n_begin > nbest) { best = ST_BEGIN; nbest = n_begin; }
-        if (n_march > nbest) { best = ST_MARCH; nbest = n_march; }
-        if (n_collide > nbest) { best = ST_COLLIDE; nbest = n_collide; }
-        if (n_nee > nbest) { best = ST_NEE; nbest = n_nee; }
-        if (n_post > nbest) { best = ST_POSTNEE; nbest = n_post; }
-        if (n_escape > nbest) { best = ST_ESCAPE; nbest = n_escape; }
-
-        if (n_new >= S.thr[ST_NEW] || best == ST_NEW) { if (l.state == ST_NEW) do_new(l, P); }
-        if (n_begin >= S.thr[ST_BEGIN] || best == ST_BEGIN) { if (l.state == ST_BEGIN) do_begin(l, P); }
-        if (n_march >= S.thr[ST_MARCH] || best == ST_MARCH) { if (l.state == ST_MARCH) do_march(l, P); }
-        if (n_collide >= S.thr[ST_COLLIDE] || best == ST_COLLIDE) { if (l.state == ST_COLLIDE) do_collide<USE_TF>(l, P); }
-        if (n_nee >= S.thr[ST_NEE] || best == ST_NEE) { if (l.state == ST_NEE) do_nee(l, P); }
-        if (n_post >= S.thr[ST_POSTNEE] || best == ST_POSTNEE) { if (l.state == ST_POSTNEE) do_postnee(l, P); }
-        if (n_escape >= S.thr[ST_ESCAPE] || best == ST_ESCAPE) { if (l.state == ST_ESCAPE) do_escape(l, P); }
+        const bool flush = n_hot < S.thr[ST_MARCH];
+        int32_t n;
+        n = __popcll(__ballot(l.state == ST_ESCAPE));
+        if (n > 0 && (flush || n >= S.thr[ST_ESCAPE])) { VR_STAT(ST_ESCAPE, n); if (l.state == ST_ESCAPE) do_escape(l, c, P, wu); VR_STAT_END(ST_ESCAPE); }
+        n = __popcll(__ballot(l.state == ST_POSTNEE));
+        if (n > 0 && (flush || n >= S.thr[ST_POSTNEE])) { VR_STAT(ST_POSTNEE, n); if (l.state == ST_POSTNEE) do_postnee(l, c, P, wu); VR_STAT_END(ST_POSTNEE); }
+        {   // lanes without work take the next items of the current unit; an empty unit is replaced from the global queue
+            const uint64_t want = __ballot(l.state == ST_NEW);
+            n = __popcll(want);
+            if (n > 0 && (flush || n >= S.thr[ST_NEW])) {
+                if (cursor == (uint32_t)wu.n_items && !exhausted) {
+                    uint32_t u = 0u;
+                    if (lane == 0) u = atomicAdd(D.unit_counter, 1u);
+                    u = __builtin_amdgcn_readfirstlane(u);
+                    if (u >= D.n_units) exhausted = true;
+                    else { wu = make_unit(D, W, u, sbuf); cursor = 0u; }
+                }
+                const uint32_t left = (uint32_t)wu.n_items - cursor;
+                if (left == 0u) {           // queue exhausted: these lanes are finished
+                    if (l.state == ST_NEW) l.state = ST_DONE;
+                } else {
+                    VR_STAT(ST_NEW, n);
+                    if (l.state == ST_NEW) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                        if (rank < left) do_new(l, c, P, wu, cursor + rank);      // the others stay in ST_NEW for the next unit
+                    }
+                    VR_STAT_END(ST_NEW);
+                    cursor += min((uint32_t)n, left);
+                }
+            }
+        }
+        n = __popcll(__ballot(l.state == ST_NEE));
+        if (n > 0 && (flush || n >= S.thr[ST_NEE])) { VR_STAT(ST_NEE, n); if (l.state == ST_NEE) do_nee(l, c, P); VR_STAT_END(ST_NEE); }
+        for (int32_t k = 0; k < S.thr[ST_COLLIDE]; ++k) {
+            n = __popcll(__ballot(l.state == ST_MARCH));
+            if (n == 0) break;
+            VR_STAT(ST_MARCH, n);
+            if (l.state == ST_MARCH) do_march(l, P);
+            VR_STAT_END(ST_MARCH);
+        }
+        n = __popcll(__ballot(l.state == ST_COLLIDE));
+        if (n > 0) { VR_STAT(ST_COLLIDE, n); if (l.state == ST_COLLIDE) do_collide<USE_TF>(l, c, P); VR_STAT_END(ST_COLLIDE); }
     }
-    if (valid) fb4[(size_t)py * W + px] = make_float4(l.acc[0], l.acc[1], l.acc[2], l.acc[3]);
+    if (STATS && stats && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < ST_DONE; ++k) { atomicAdd(&stats[2 * k], (unsigned long long)st_exec[k]); atomicAdd(&stats[2 * k + 1], (unsigned long long)st_lanes[k]); }
+        atomicAdd(&stats[16], (unsigned long long)iters);
+        atomicAdd(&stats[17], 1ull);
+#pragma unroll
+        for (int k = 0; k < ST_DONE; ++k) atomicAdd(&stats[18 + k], st_cyc[k]);
+        atomicAdd(&stats[25], __builtin_readcyclecounter() - t_start);
+    }
+#undef VR_STAT
+#undef VR_STAT_END
 }
 
-static SchedParams g_sched = { { 24, 16, 8, 16, 16, 16, 24, 0 }, 0u };
+// Running mean over the samples of one launch, in sample order (pathtracer_brick.glsl:36): one thread per pixel.
+__global__ void __launch_bounds__(256)
+accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const int32_t* __restrict__ tiles, int32_t n_tiles,
+                  int32_t W, int32_t H, int32_t first_sample, int32_t n_samples, int32_t spu) {
+    const int32_t tiles_x = (W + 15) >> 4;
+    const int32_t tile = tiles ? tiles[blockIdx.x] : (int32_t)blockIdx.x;
+    const int32_t wave = threadIdx.x >> 6, p = threadIdx.x & 63;
+    const int32_t px = (tile % tiles_x) * 16 + ((wave & 1) << 3) + (p & 7);
+    const int32_t py = (tile / tiles_x) * 16 + ((wave >> 1) << 3) + (p >> 3);
+    if (px >= W || py >= H) return;
+    float4* texel = reinterpret_cast<float4*>(fb) + (size_t)py * W + px;
+    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (first_sample > 1) { const float4 c = *texel; acc[0] = c.x; acc[1] = c.y; acc[2] = c.z; acc[3] = c.w; }
+    const float4* sb = reinterpret_cast<const float4*>(sbuf);
+    for (int32_t k = 0; k < n_samples; ++k) {
+        const int32_t chunk = k / spu, sl = k - chunk * spu;
+        const size_t unit = ((size_t)chunk * n_tiles + blockIdx.x) * 4u + (uint32_t)wave;
+        const float4 v = sb[unit * (size_t)(spu * 64) + (size_t)sl * 64u + (uint32_t)p];
+        const float L[4] = { v.x, v.y, v.z, v.w };
+        accumulate_sample(acc, L, first_sample + k);
+    }
+    *texel = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// thr[]: NEW, (unused), MARCH (= flush level of the hot pair), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE
+static SchedParams g_sched = { { 16, 4, 24, 2, 12, 12, 16, 0 }, 0u };
+static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
+static int32_t g_samples_per_unit = 4;
+static int32_t g_blocks_per_cu = 0;                 // 0 = from the occupancy query
+
+void set_stats_buffer(unsigned long long* dev) { g_stats = dev; }
+void set_samples_per_unit(int32_t n) { g_samples_per_unit = n < 1 ? 1 : n; }
 
 void set_sched_thresholds(const int32_t thr[ST_COUNT]) {
     for (int i = 0; i < ST_COUNT; ++i) g_sched.thr[i] = thr[i];
 }
 
-void launch_pathtrace(const SceneParams& P, float* fb, const int32_t* tiles, int32_t n_tiles,
+static void tuning_from_env() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char* e = getenv("VR_SPU")) set_samples_per_unit(atoi(e));      // diagnostics only
+    if (const char* e = getenv("VR_BLOCKS_PER_CU")) g_blocks_per_cu = atoi(e);
+}
+
+size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples) {
+    tuning_from_env();
+    const int32_t spu = n_samples < g_samples_per_unit ? n_samples : g_samples_per_unit;
+    const int32_t chunks = (n_samples + spu - 1) / spu;
+    return (size_t)chunks * (size_t)n_tiles * 4u * (size_t)spu * 64u * 4u;
+}
+
+template <typename K>
+static int resident_blocks(K kernel) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (g_blocks_per_cu > 0) per_cu = g_blocks_per_cu;
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    return cus * per_cu;
+}
+
+void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream) {
     if (n_tiles <= 0 || n_samples <= 0) return;
+    tuning_from_env();
     SchedParams S = g_sched;
-    // a sample needs a few hundred scheduler iterations at the very worst (bounces x steps); generous cap
-    const uint64_t cap = (uint64_t)n_samples * 200000ull + 1000000ull;
-    S.max_iters = cap > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)cap;
-    const dim3 grid((unsigned)n_tiles), block(256);
-    if (P.u.use_tf)
-        hipLaunchKernelGGL(pathtrace_kernel<true>, grid, block, 0, stream, P, fb, tiles, first_sample, n_samples, S, status);
-    else
-        hipLaunchKernelGGL(pathtrace_kernel<false>, grid, block, 0, stream, P, fb, tiles, first_sample, n_samples, S, status);
+    LaunchDesc D;
+    D.tiles = tiles; D.n_tiles = n_tiles; D.first_sample = first_sample; D.n_samples = n_samples;
+    D.spu = n_samples < g_samples_per_unit ? n_samples : g_samples_per_unit;
+    const int32_t chunks = (n_samples + D.spu - 1) / D.spu;
+    D.n_units = (uint32_t)chunks * (uint32_t)n_tiles * 4u;
+    D.unit_counter = unit_counter;
+    S.max_iters = 0xFFFFFFF0u;       // watchdog: every path is bounded by `bounces` and the grid extent; cap the loop anyway
+    auto kernel = P.u.use_tf ? (g_stats ? pathtrace_kernel<true, true> : pathtrace_kernel<true, false>)
+                             : (g_stats ? pathtrace_kernel<false, true> : pathtrace_kernel<false, false>);
+    static int blocks_cache[4] = { 0, 0, 0, 0 };
+    int& blocks = blocks_cache[(P.u.use_tf ? 2 : 0) + (g_stats ? 1 : 0)];
+    if (blocks == 0 || g_blocks_per_cu > 0) blocks = resident_blocks(kernel);
+    const uint32_t waves_needed = (D.n_units + 3u) / 4u;
+    const dim3 grid((unsigned)std::min<uint32_t>((uint32_t)blocks, waves_needed > 0 ? waves_needed : 1u)), block(256);
+    (void)hipMemsetAsync(unit_counter, 0, sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, P, sample_pool, D, S, status, g_stats);
+    hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)n_tiles), block, 0, stream, sample_pool, fb, tiles, n_tiles,
+                       P.u.resolution[0], P.u.resolution[1], first_sample, n_samples, D.spu);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -9,8 +9,10 @@
 // all lanes that are in it (scheduler in vr_kernels.hip), so that
 //   * the DDA march step is shared by camera/scatter segments (sample_volumeDDA, :458-501) and shadow
 //     segments (transmittanceDDA, :412-455): both are "mode" flags of one loop body,
-//   * a lane that finishes a path immediately starts its next sample (fused spp loop, the running mean
-//     mix(old, new, 1/s) of pathtracer_brick.glsl:36 is kept in registers), and
+//   * lanes are not tied to pixels: a wavefront owns a pool of (pixel, sample) items (one 8x8 tile x a chunk of
+//     samples) and a lane that finishes a path immediately pulls the next item, so no lane idles because its
+//     pixel was cheap; per-sample radiances go to a sample buffer and a second tiny kernel applies the running
+//     mean mix(old, new, 1/s) of pathtracer_brick.glsl:36 in sample order (bit-identical to sequential dispatches), and
 //   * rare, expensive events (NEE environment sampling, new-sample setup with the 32-round TEA hash, escape
 //     lookups) are batched until enough lanes want them.
 // The order in which lanes run their states never changes a result: every lane owns its RNG state.
@@ -22,36 +24,47 @@
 namespace vr {
 
 enum LaneState : int32_t {
-    ST_NEW = 0,      // accumulate previous result, start next sample: seed, camera ray
-    ST_BEGIN = 1,    // start a segment: clip box, index-space ray, first optical depth
+    ST_NEW = 0,      // needs a work item: seed, camera ray, first segment set-up
+    ST_BEGIN = 1,    // (folded into NEW / NEE / POSTNEE: begin_segment) -- kept as an index for scheduler parameters
     ST_MARCH = 2,    // one DDA step over the majorant mips
     ST_COLLIDE = 3,  // tentative collision: density lookup, real/null decision
     ST_NEE = 4,      // real scatter: advance, sample the environment, set up the shadow segment
-    ST_POSTNEE = 5,  // shadow segment done: add direct light, bounce cap, roulette, phase sample
-    ST_ESCAPE = 6,   // path left the volume: environment lookup + MIS, finish the sample
+    ST_POSTNEE = 5,  // shadow segment done: add direct light, bounce cap, roulette, phase sample, next segment
+    ST_ESCAPE = 6,   // path left the volume: environment lookup + MIS, write the sample
     ST_DONE = 7,
     ST_COUNT = 8
 };
 
-struct Lane {
-    int32_t px, py;          // pixel (y up, like GL)
-    int32_t s, s_end;        // current 1-based sample, last sample to run
-    float acc[4];            // running mean (the RGBA32F texel)
-    uint32_t seed;
-    v3 pos, dir, thr, L;
-    uint32_t n_paths;
-    float f_p;
-    // segment
-    v3 ipos, idir, ri;
-    float t, far, tau, mip, majorant;
-    int32_t shadow;          // 0: sample_volumeDDA segment, 1: transmittanceDDA segment
-    // pending next-event estimate
-    v3 w_i, sh_a, sh_Le;
-    float sh_pdf, Tr;
-    int32_t has_nee;
-    int32_t state;
-    uint32_t steps;          // watchdog
+// the pool of work items of one wavefront: pixel p = item & 63 of the 8x8 tile at (px0, py0), sample
+// first_sample + (item >> 6) (1-based like the reference's current_sample)
+struct WorkUnit {
+    int32_t px0, py0;
+    int32_t first_sample;
+    int32_t n_items;
+    uint32_t base;           // index of the unit's first item in the sample buffer
+    float* out;              // sample buffer: RGBA32F per item, trace_path's vec4(L, alpha), unsanitised
 };
+
+// Per-lane state is split by temperature.
+// Hot: what the DDA march / collision loop touches every iteration -- lives in registers.
+struct Hot {
+    uint32_t seed;
+    v3 ipos, idir, ri;       // index-space ray of the current segment
+    float t, far, tau, mip, majorant, Tr;
+    int32_t shadow;          // 0: sample_volumeDDA segment, 1: transmittanceDDA segment
+    int32_t state;
+};
+// Cold: path state that only the rare events (new sample, scatter, escape) read or write.  On the GPU it is parked
+// in LDS ([field][lane] dwords, conflict-free) so that it does not occupy registers while the lane marches; the
+// host harness backs it with a plain array.  `Cold` is any type with float ld(int) / void st(int, float).
+enum ColdField : int32_t {
+    C_POS = 0, C_DIR = 3, C_THR = 6, C_L = 9, C_SHA = 12, C_SHLE = 15, C_SHPDF = 18, C_FP = 19, C_NPATHS = 20, C_ITEM = 21,
+    C_COUNT = 22
+};
+template <class Cold> VR_HD v3 ld3(const Cold& c, int32_t f) { return v3{ c.ld(f), c.ld(f + 1), c.ld(f + 2) }; }
+template <class Cold> VR_HD void st3(Cold& c, int32_t f, v3 v) { c.st(f, v.x); c.st(f + 1, v.y); c.st(f + 2, v.z); }
+template <class Cold> VR_HD uint32_t ldu(const Cold& c, int32_t f) { return f2u(c.ld(f)); }
+template <class Cold> VR_HD void stu(Cold& c, int32_t f, uint32_t v) { c.st(f, u2f(v)); }
 
 // ---------------------------------------------------------------------------------------------------
 // RNG  (common.glsl:40-67)
@@ -287,86 +300,93 @@ VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
 // ---------------------------------------------------------------------------------------------------
 // state bodies
 
-VR_HD void lane_init(Lane& l, int32_t px, int32_t py, int32_t first_sample, int32_t n_samples, const float* texel) {
-    l.px = px; l.py = py;
-    l.s = first_sample - 1; l.s_end = first_sample + n_samples - 1;
-    l.acc[0] = texel[0]; l.acc[1] = texel[1]; l.acc[2] = texel[2]; l.acc[3] = texel[3];
-    l.state = ST_NEW; l.steps = 0u; l.n_paths = 0u;
-    l.L = v3{ 0, 0, 0 }; l.thr = v3{ 1, 1, 1 }; l.f_p = 0.0f; l.seed = 0u;
-    l.pos = l.dir = l.ipos = l.idir = l.ri = l.w_i = l.sh_a = l.sh_Le = v3{ 0, 0, 0 };
-    l.t = l.far = l.tau = l.mip = l.majorant = l.sh_pdf = l.Tr = 0.0f;
-    l.shadow = 0; l.has_nee = 0;
+VR_HD void hot_init(Hot& h) {
+    h.seed = 0u;
+    h.ipos = h.idir = h.ri = v3{ 0, 0, 0 };
+    h.t = h.far = h.tau = h.mip = h.majorant = h.Tr = 0.0f;
+    h.shadow = 0;
+    h.state = ST_NEW;
 }
 
-// result of trace_path is (L, clamp(n_paths,0,1)); pathtracer_brick.glsl:36 running mean
-VR_HD void finish_sample(Lane& l) {
-    const float a = 1.0f / (float)l.s;
-    l.acc[0] = mix_(l.acc[0], sanitize(l.L.x), a);
-    l.acc[1] = mix_(l.acc[1], sanitize(l.L.y), a);
-    l.acc[2] = mix_(l.acc[2], sanitize(l.L.z), a);
-    l.acc[3] = mix_(l.acc[3], l.n_paths > 0u ? 1.0f : 0.0f, a);
-    l.state = ST_NEW;
+// result of trace_path: vec4(L, clamp(n_paths, 0, 1)) -> the item's slot of the sample buffer
+VR_HD void write_sample(const WorkUnit& wu, uint32_t item, v3 L, uint32_t n_paths) {
+    float* o = wu.out + 4u * (size_t)item;
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<float4*>(o) = make_float4(L.x, L.y, L.z, n_paths > 0u ? 1.0f : 0.0f);
+#else
+    o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = n_paths > 0u ? 1.0f : 0.0f;
+#endif
 }
 
-// pathtracer_brick.glsl:27-30 + common.glsl:76-80
-VR_HD void do_new(Lane& l, const SceneParams& P) {
-    if (l.s >= l.s_end) { l.state = ST_DONE; return; }
-    l.s += 1;
-    const int32_t W = P.u.resolution[0], H = P.u.resolution[1];
-    l.seed = tea32((uint32_t)P.u.seed * (uint32_t)(l.py * W + l.px), (uint32_t)l.s);
-    const float jx = rng(l.seed), jy = rng(l.seed);
-    const float fx = (((float)l.px + jx) - (float)W * 0.5f) / (float)H;
-    const float fy = (((float)l.py + jy) - (float)H * 0.5f) / (float)H;
-    l.dir = normalize(mat3_mul(P.u.cam_transform, normalize(v3{ fx, fy, P.cam_z })));
-    l.pos = v3{ P.u.cam_pos[0], P.u.cam_pos[1], P.u.cam_pos[2] };
-    l.L = v3{ 0, 0, 0 }; l.thr = v3{ 1, 1, 1 };
-    l.n_paths = 0u; l.f_p = 0.0f;
-    l.shadow = 0;
-    l.state = ST_BEGIN;
+// pathtracer_brick.glsl:36: color = mix(color, sanitize(L), 1.f / current_sample)
+VR_HD void accumulate_sample(float acc[4], const float L[4], int32_t current_sample) {
+    const float a = 1.0f / (float)current_sample;
+    acc[0] = mix_(acc[0], sanitize(L[0]), a);
+    acc[1] = mix_(acc[1], sanitize(L[1]), a);
+    acc[2] = mix_(acc[2], sanitize(L[2]), a);
+    acc[3] = mix_(acc[3], sanitize(L[3]), a);
 }
 
-// head of sample_volumeDDA / transmittanceDDA (common.glsl:413-421, 459-468)
-VR_HD void do_begin(Lane& l, const SceneParams& P) {
-    const v3 d = l.shadow ? l.w_i : l.dir;
+// head of sample_volumeDDA / transmittanceDDA (common.glsl:413-421, 459-468) for the ray (pos, d)
+VR_HD void begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t shadow) {
+    h.shadow = shadow;
+    h.Tr = 1.0f;          // both set before the branch on purpose: conditional stores to different fields make the
+    h.mip = 3.0f;         // compiler address-select between them, which forces the state into scratch memory
     float tnear, tfar;
-    if (!intersect_box(l.pos, d, P.u.vol_bb_min, P.u.vol_bb_max, tnear, tfar)) {
-        if (l.shadow) { l.Tr = 1.0f; l.state = ST_POSTNEE; }
-        else l.state = ST_ESCAPE;
+    if (!intersect_box(pos, d, P.u.vol_bb_min, P.u.vol_bb_max, tnear, tfar)) {
+        h.state = shadow ? ST_POSTNEE : ST_ESCAPE;
         return;
     }
-    l.ipos = mat4_point(P.u.vol_density_inv_transform, l.pos);
-    l.idir = mat4_dir(P.u.vol_density_inv_transform, d);
-    l.ri = v3{ 1.0f / l.idir.x, 1.0f / l.idir.y, 1.0f / l.idir.z };
-    l.t = tnear + 1e-6f;
-    l.far = tfar;
-    l.Tr = 1.0f;
-    l.tau = neg_log_1m(rng(l.seed));
-    l.mip = 3.0f;
-    l.state = ST_MARCH;
+    h.ipos = mat4_point(P.u.vol_density_inv_transform, pos);
+    h.idir = mat4_dir(P.u.vol_density_inv_transform, d);
+    h.ri = v3{ 1.0f / h.idir.x, 1.0f / h.idir.y, 1.0f / h.idir.z };
+    h.t = tnear + 1e-6f;
+    h.far = tfar;
+    h.tau = neg_log_1m(rng(h.seed));
+    h.state = ST_MARCH;
+}
+
+// pathtracer_brick.glsl:27-30 + common.glsl:76-80; the lane has just been given `item` (< n_items)
+template <class Cold>
+VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uint32_t item) {
+    const int32_t W = P.u.resolution[0], H = P.u.resolution[1];
+    const int32_t px = wu.px0 + (int32_t)(item & 7u), py = wu.py0 + (int32_t)((item >> 3) & 7u);
+    const int32_t smp = wu.first_sample + (int32_t)(item >> 6);
+    if (px >= W || py >= H) return;                 // pixel outside a ragged frame: stay in ST_NEW, take the next item
+    h.seed = tea32((uint32_t)P.u.seed * (uint32_t)(py * W + px), (uint32_t)smp);
+    const float jx = rng(h.seed), jy = rng(h.seed);
+    const float fx = (((float)px + jx) - (float)W * 0.5f) / (float)H;
+    const float fy = (((float)py + jy) - (float)H * 0.5f) / (float)H;
+    const v3 dir = normalize(mat3_mul(P.u.cam_transform, normalize(v3{ fx, fy, P.cam_z })));
+    const v3 pos = v3{ P.u.cam_pos[0], P.u.cam_pos[1], P.u.cam_pos[2] };
+    st3(c, C_POS, pos); st3(c, C_DIR, dir);
+    st3(c, C_L, v3{ 0, 0, 0 }); st3(c, C_THR, v3{ 1, 1, 1 });
+    stu(c, C_NPATHS, 0u); c.st(C_FP, 0.0f); stu(c, C_ITEM, wu.base + item);    // C_ITEM: global slot in the sample buffer
+    begin_segment(h, P, pos, dir, 0);
 }
 
 // loop body of both DDA trackers up to the collision test (common.glsl:422-435, 469-482)
-VR_HD void do_march(Lane& l, const SceneParams& P) {
-    if (!(l.t < l.far)) { l.state = l.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
-    const v3 curr = axpy(l.ipos, l.t, l.idir);
-    const int32_t m = round_half_even(l.mip);
+VR_HD void do_march(Hot& h, const SceneParams& P) {
+    if (!(h.t < h.far)) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    const v3 curr = axpy(h.ipos, h.t, h.idir);
+    const int32_t m = round_half_even(h.mip);
     const float majorant = majorant_at(P.density, curr, m);
-    const float dt = step_dda(curr, l.ri, m);
-    l.t += dt;
-    l.tau -= majorant * dt;
-    l.mip = min_(l.mip + 0.25f, 3.0f);
-    if (l.tau > 0.0f) return;
-    l.t += l.tau / majorant;
-    if (l.t >= l.far) { l.state = l.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
-    l.majorant = majorant;
-    l.state = ST_COLLIDE;
+    const float dt = step_dda(curr, h.ri, m);
+    h.t += dt;
+    h.tau -= majorant * dt;
+    h.mip = min_(h.mip + 0.25f, 3.0f);
+    if (h.tau > 0.0f) return;
+    h.t += h.tau / majorant;
+    if (h.t >= h.far) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    h.majorant = majorant;
+    h.state = ST_COLLIDE;
 }
 
 // tentative collision (common.glsl:436-452, 483-498)
-template <bool USE_TF>
-VR_HD void do_collide(Lane& l, const SceneParams& P) {
+template <bool USE_TF, class Cold>
+VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
     const Uniforms& u = P.u;
-    const v3 ip = axpy(l.ipos, l.t, l.idir);
+    const v3 ip = axpy(h.ipos, h.t, h.idir);
     float d;
     float rgba[4] = { 0, 0, 0, 0 };
     if (USE_TF) {
@@ -374,110 +394,130 @@ VR_HD void do_collide(Lane& l, const SceneParams& P) {
         d = u.vol_majorant * rgba[3];
     } else {
         int32_t tx, ty, tz;
-        tricubic_tap(ip, l.seed, tx, ty, tz);
+        tricubic_tap(ip, h.seed, tx, ty, tz);
         d = u.vol_density_scale * brick_value(P.density, tx, ty, tz);
     }
-    if (!l.shadow) {
+    if (!h.shadow) {
         // Le += throughput * (1 - albedo) * lookup_emission(...) * d * vol_inv_majorant  (9 draws, always)
         if (u.has_emission) {
             const v3 ie = mat4_point(P.emission_from_density, ip);
             int32_t ex, ey, ez;
-            tricubic_tap(ie, l.seed, ex, ey, ez);
+            tricubic_tap(ie, h.seed, ex, ey, ez);
             const float tt = brick_value(P.emission, ex, ey, ez) * u.vol_emission_norm;
             const v3 e3 = v3{ tt, sqr(tt), sqr(sqr(tt)) };
             const v3 em = v3{ u.vol_emission_scale * sqr(e3.x), u.vol_emission_scale * sqr(e3.y), u.vol_emission_scale * sqr(e3.z) };
             const v3 oma = v3{ 1.0f - u.vol_albedo[0], 1.0f - u.vol_albedo[1], 1.0f - u.vol_albedo[2] };
-            l.L = l.L + (((l.thr * oma) * em) * d) * u.vol_inv_majorant;
+            st3(c, C_L, ld3(c, C_L) + (((ld3(c, C_THR) * oma) * em) * d) * u.vol_inv_majorant);
         } else {
-            rng_skip9(l.seed);
+            rng_skip9(h.seed);
         }
-        if (rng(l.seed) * l.majorant < d) {
-            l.thr = l.thr * v3{ u.vol_albedo[0], u.vol_albedo[1], u.vol_albedo[2] };
-            if (USE_TF) l.thr = l.thr * v3{ rgba[0], rgba[1], rgba[2] };
-            l.state = ST_NEE;
+        if (rng(h.seed) * h.majorant < d) {
+            v3 thr = ld3(c, C_THR) * v3{ u.vol_albedo[0], u.vol_albedo[1], u.vol_albedo[2] };
+            if (USE_TF) thr = thr * v3{ rgba[0], rgba[1], rgba[2] };
+            st3(c, C_THR, thr);
+            h.state = ST_NEE;
             return;
         }
     } else {
-        if (rng(l.seed) * l.majorant < d) {
-            l.Tr *= max_(0.0f, 1.0f - u.vol_majorant / l.majorant);
-            if (l.Tr < 0.1f) {
-                const float prob = 1.0f - l.Tr;
-                if (rng(l.seed) < prob) { l.Tr = 0.0f; l.state = ST_POSTNEE; return; }
-                l.Tr /= 1.0f - prob;
+        if (rng(h.seed) * h.majorant < d) {
+            h.Tr *= max_(0.0f, 1.0f - u.vol_majorant / h.majorant);
+            if (h.Tr < 0.1f) {
+                const float prob = 1.0f - h.Tr;
+                if (rng(h.seed) < prob) { h.Tr = 0.0f; h.state = ST_POSTNEE; return; }
+                h.Tr /= 1.0f - prob;
             }
         }
     }
-    l.tau = neg_log_1m(rng(l.seed));
-    l.mip = max_(0.0f, l.mip - 2.0f);
-    l.state = ST_MARCH;
+    h.tau = neg_log_1m(rng(h.seed));
+    h.mip = max_(0.0f, h.mip - 2.0f);
+    h.state = ST_MARCH;
 }
 
-// real collision: common.glsl:611-626 up to the transmittance call
-VR_HD void do_nee(Lane& l, const SceneParams& P) {
-    l.pos = axpy(l.pos, l.t, l.dir);
-    const float r0 = rng(l.seed), r1 = rng(l.seed);
+// real collision: common.glsl:611-626 up to (and including the set-up of) the transmittance call
+template <class Cold>
+VR_HD void do_nee(Hot& h, Cold& c, const SceneParams& P) {
+    const v3 dir = ld3(c, C_DIR);
+    const v3 pos = axpy(ld3(c, C_POS), h.t, dir);
+    st3(c, C_POS, pos);
+    const float r0 = rng(h.seed), r1 = rng(h.seed);
     float pdf;
-    sample_environment(P, r0, r1, l.w_i, l.sh_Le, pdf);
-    l.sh_pdf = pdf;
+    v3 w_i, Le;
+    sample_environment(P, r0, r1, w_i, Le, pdf);
+    c.st(C_SHPDF, pdf);
     if (pdf > 0.0f) {
-        l.f_p = phase_hg(dot(-l.dir, l.w_i), P.u.vol_phase_g);
-        const float mis = P.u.show_environment > 0 ? power_heuristic(pdf, l.f_p) : 1.0f;
-        l.sh_a = (l.thr * mis) * l.f_p;
-        l.has_nee = 1;
-        l.shadow = 1;
-        l.state = ST_BEGIN;
+        const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
+        const float mis = P.u.show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
+        c.st(C_FP, f_p);
+        st3(c, C_SHA, (ld3(c, C_THR) * mis) * f_p);
+        st3(c, C_SHLE, Le);
+        begin_segment(h, P, pos, w_i, 1);
     } else {
-        l.has_nee = 0;
-        l.state = ST_POSTNEE;
+        c.st(C_SHPDF, 0.0f);           // marks "no next-event estimate" for do_postnee (pdf <= 0 or NaN)
+        h.shadow = 0;
+        h.state = ST_POSTNEE;
     }
 }
 
-// common.glsl:625-641
-VR_HD void do_postnee(Lane& l, const SceneParams& P) {
-    if (l.has_nee) {
-        const v3 a = ((l.sh_a * l.Tr) * l.sh_Le) / l.sh_pdf;
-        l.L = l.L + a;
+// common.glsl:625-641, then the head of the next sample_volumeDDA call
+template <class Cold>
+VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
+    v3 L = ld3(c, C_L);
+    const float sh_pdf = c.ld(C_SHPDF);
+    if (sh_pdf > 0.0f) {
+        L = L + ((ld3(c, C_SHA) * h.Tr) * ld3(c, C_SHLE)) / sh_pdf;
+        st3(c, C_L, L);
     }
-    l.shadow = 0;
-    if (++l.n_paths >= (uint32_t)P.u.bounces) { finish_sample(l); return; }
-    const float rr = luma(l.thr);
+    const uint32_t n_paths = ldu(c, C_NPATHS) + 1u;
+    if (n_paths >= (uint32_t)P.u.bounces) { write_sample(wu, ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
+    v3 thr = ld3(c, C_THR);
+    const float rr = luma(thr);
     if (rr < 0.1f) {
         const float prob = 1.0f - rr;
-        if (rng(l.seed) < prob) { finish_sample(l); return; }
-        l.thr = l.thr / (1.0f - prob);
+        if (rng(h.seed) < prob) { write_sample(wu, ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
+        thr = thr / (1.0f - prob);
+        st3(c, C_THR, thr);
     }
-    const float s0 = rng(l.seed), s1 = rng(l.seed);
-    const v3 sd = sample_phase_hg(l.dir, P.u.vol_phase_g, s0, s1);
-    l.f_p = phase_hg(dot(-l.dir, sd), P.u.vol_phase_g);
-    l.dir = sd;
-    l.state = ST_BEGIN;
+    stu(c, C_NPATHS, n_paths);
+    const v3 dir = ld3(c, C_DIR);
+    const float s0 = rng(h.seed), s1 = rng(h.seed);
+    const v3 sd = sample_phase_hg(dir, P.u.vol_phase_g, s0, s1);
+    c.st(C_FP, phase_hg(dot(-dir, sd), P.u.vol_phase_g));
+    st3(c, C_DIR, sd);
+    begin_segment(h, P, ld3(c, C_POS), sd, 0);
 }
 
 // common.glsl:644-651
-VR_HD void do_escape(Lane& l, const SceneParams& P) {
+template <class Cold>
+VR_HD void do_escape(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
+    v3 L = ld3(c, C_L);
+    const uint32_t n_paths = ldu(c, C_NPATHS);
     if (P.u.show_environment > 0) {
-        const v3 Le = lookup_environment(P, l.dir);
+        const v3 Le = lookup_environment(P, ld3(c, C_DIR));
         float mis = 1.0f;
-        if (l.n_paths > 0u) {
+        if (n_paths > 0u) {
             const float avg_w = imp_fetch(P, 0, 0, P.u.env_imp_base_mip);
             const float pdf_env = (luma(Le) / avg_w) * kInv4Pi;
-            mis = power_heuristic(l.f_p, pdf_env);
+            mis = power_heuristic(c.ld(C_FP), pdf_env);
         }
-        l.L = l.L + (l.thr * mis) * Le;
+        L = L + (ld3(c, C_THR) * mis) * Le;
     }
-    finish_sample(l);
+    write_sample(wu, ldu(c, C_ITEM), L, n_paths);
+    h.state = ST_NEW;
 }
 
-template <bool USE_TF>
-VR_HD void lane_step(Lane& l, const SceneParams& P) {
-    switch (l.state) {
-    case ST_NEW: do_new(l, P); break;
-    case ST_BEGIN: do_begin(l, P); break;
-    case ST_MARCH: do_march(l, P); break;
-    case ST_COLLIDE: do_collide<USE_TF>(l, P); break;
-    case ST_NEE: do_nee(l, P); break;
-    case ST_POSTNEE: do_postnee(l, P); break;
-    case ST_ESCAPE: do_escape(l, P); break;
+// sequential driver (host harness / reference order): one state transition of one lane
+template <bool USE_TF, class Cold>
+VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uint32_t& next_item) {
+    switch (h.state) {
+    case ST_NEW:
+        if (next_item >= (uint32_t)wu.n_items) { h.state = ST_DONE; break; }
+        do_new(h, c, P, wu, next_item++);
+        break;
+    case ST_MARCH: do_march(h, P); break;
+    case ST_COLLIDE: do_collide<USE_TF>(h, c, P); break;
+    case ST_NEE: do_nee(h, c, P); break;
+    case ST_POSTNEE: do_postnee(h, c, P, wu); break;
+    case ST_ESCAPE: do_escape(h, c, P, wu); break;
     default: break;
     }
 }

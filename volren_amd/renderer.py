@@ -208,3 +208,20 @@ def math_probe(fn, a, b=None):
     out = np.empty_like(a)
     _lib.check(_lib.load().vr_math_probe(int(fn), a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size))
     return out
+
+
+STATE_NAMES = ("new", "begin", "march", "collide", "nee", "postnee", "escape")
+
+
+def sched_stats(enable=True, read=False):
+    """Scheduler diagnostics of the path-tracing kernel. Returns {state: (executions, active_lanes)} when read."""
+    out = np.zeros(26, np.uint64) if read else None
+    _lib.check(_lib.load().vr_sched_stats(1 if enable else 0, out.ctypes.data if read else None))
+    if not read:
+        return None
+    d = {n: (int(out[2 * i]), int(out[2 * i + 1])) for i, n in enumerate(STATE_NAMES)}
+    d["iterations"] = int(out[16])
+    d["waves"] = int(out[17])
+    d["cycles"] = {n: int(out[18 + i]) for i, n in enumerate(STATE_NAMES)}     # s_memtime ticks inside each state's block
+    d["wave_cycles"] = int(out[25])                                             # summed lifetime of all wavefronts
+    return d
