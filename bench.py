@@ -28,16 +28,6 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def tile_owner_lists(w, h, n_ranks):
-    """Diagonal interleave of 16x16 tiles: owner(tx, ty) = (tx + ty) mod N.  Returns one raster-id list per rank."""
-    tiles_x, tiles_y = (w + 15) // 16, (h + 15) // 16
-    lists = [[] for _ in range(n_ranks)]
-    for ty in range(tiles_y):
-        for tx in range(tiles_x):
-            lists[(tx + ty) % n_ranks].append(ty * tiles_x + tx)
-    return lists
-
-
 def algorithmic_bytes_per_sample(counters, spp, use_tf, has_emission):
     """B = 4*N_dda + b_tap*T*N_coll + b_em*N_coll_sv + 200*N_nee + 48*N_esc + 16/spp."""
     n = float(counters["samples"])
@@ -110,17 +100,16 @@ def main():
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
 
-    tile_lists = tile_owner_lists(w, h, world)
-    mine = tile_lists[rank]
+    from volren_amd.shard import TileShard
+    shard = TileShard(w, h, world, rank)
+    mine = shard.mine
     packed = gathered = tiles_dev = all_tiles_dev = None
     if world > 1:
         r.set_tiles(mine)
-        n_max = max(len(t) for t in tile_lists)
-        pad = [t + [-1] * (n_max - len(t)) for t in tile_lists]           # -1 = padding entry (skipped by unpack)
-        tiles_dev = torch.tensor(mine + [mine[-1]] * (n_max - len(mine)), dtype=torch.int32, device="cuda")
-        all_tiles_dev = torch.tensor(sum(pad, []), dtype=torch.int32, device="cuda")
-        packed = torch.empty(n_max * 256 * 4, dtype=torch.float32, device="cuda")
-        gathered = torch.empty(world * n_max * 256 * 4, dtype=torch.float32, device="cuda")
+        tiles_dev = torch.from_numpy(shard.pack_ids).cuda()
+        all_tiles_dev = torch.from_numpy(shard.unpack_ids).cuda()
+        packed = torch.empty(shard.packed_floats, dtype=torch.float32, device="cuda")
+        gathered = torch.empty(shard.gathered_floats, dtype=torch.float32, device="cuda")
 
     kernel_ms = []
 
@@ -128,10 +117,9 @@ def main():
         r.reset()
         r.render(spp, sync=False)                                           # ONE fused launch: all spp of all owned tiles
         if world > 1:
-            n_max = packed.numel() // 1024
-            r.pack_tiles(tiles_dev.data_ptr(), n_max, packed.data_ptr())
-            dist.all_gather_into_tensor(gathered, packed)                   # RCCL over xGMI, once per frame
-            r.unpack_tiles(all_tiles_dev.data_ptr(), world * n_max, gathered.data_ptr())
+            r.pack_tiles(tiles_dev.data_ptr(), shard.n_max, packed.data_ptr())
+            shard.all_gather(dist, gathered, packed)                        # RCCL over xGMI, once per frame
+            r.unpack_tiles(all_tiles_dev.data_ptr(), world * shard.n_max, gathered.data_ptr())
 
     def barrier():
         if world > 1:

@@ -94,6 +94,23 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
     for (size_t i = 0; i < (size_t)env_w * env_h; ++i) { env[4 * i] = env_rgb[3 * i]; env[4 * i + 1] = env_rgb[3 * i + 1]; env[4 * i + 2] = env_rgb[3 * i + 2]; env[4 * i + 3] = 1.f; }
     P.envmap = env.data(); P.env_w = env_w; P.env_h = env_h;
     P.impmap = impmap; P.imp_dim = imp_dim;
+    std::vector<float> cdf(((size_t)imp_dim * imp_dim - 1) / 3 * 4);
+    {   // == env_cdf_kernel of vr_kernels.hip
+        int base = 0; while ((1 << base) < imp_dim) ++base;
+        for (int mip = base - 1; mip >= 0; --mip) {
+            const int d = imp_dim >> mip, hd = d >> 1;
+            const float* level = impmap + imp_level_offset(imp_dim, mip);
+            float* dst = cdf.data() + 4 * (size_t)env_cdf_offset(base - 1 - mip);
+            for (int y = 0; y < hd; ++y) for (int x = 0; x < hd; ++x) {
+                const float w0 = level[(size_t)(2 * y) * d + 2 * x], w1 = level[(size_t)(2 * y) * d + 2 * x + 1];
+                const float w2 = level[(size_t)(2 * y + 1) * d + 2 * x], w3 = level[(size_t)(2 * y + 1) * d + 2 * x + 1];
+                const float q0 = w0 + w2, q1 = w1 + w3;
+                float* o = dst + 4 * ((size_t)y * hd + x);
+                o[0] = q0 / max_(1e-8f, q0 + q1); o[1] = w0 / q0; o[2] = w1 / q1; o[3] = 0.f;
+            }
+        }
+    }
+    P.env_cdf = cdf.data();
     P.cam_z = -0.5f / tan_(0.5f * kPi * u.cam_fov / 180.f);
     long long steps = 0;
     const int W = u.resolution[0], H = u.resolution[1];

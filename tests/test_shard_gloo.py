@@ -1,0 +1,79 @@
+"""CPU, world_size 2 over gloo: the multi-GPU path of bench.py (tile ownership -> render own tiles -> pack -> ONE
+all_gather -> unpack) with the oracle standing in for the HIP renderer and numpy for the pack/unpack kernels.
+The sharded frame must be bit-identical to the single-process frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import scenes
+from volren_amd.shard import TileShard, tile_owner_lists, pack_tiles_numpy, unpack_tiles_numpy
+
+W, H, SPP = 70, 52, 3
+
+
+def test_tile_ownership_is_a_partition():
+    for w, h in ((1024, 1024), (1920, 1080), (70, 52), (16, 16)):
+        tx, ty = (w + 15) // 16, (h + 15) // 16
+        for n in (1, 2, 4, 8):
+            lists = tile_owner_lists(w, h, n)
+            flat = sorted(sum(lists, []))
+            assert flat == list(range(tx * ty))
+            if tx * ty >= 8 * n:
+                sizes = [len(t) for t in lists]
+                assert max(sizes) - min(sizes) <= max(tx, ty)          # diagonal interleave balances the counts
+            s = TileShard(w, h, n, n - 1)
+            assert len(s.pack_ids) == s.n_max and len(s.unpack_ids) == n * s.n_max
+            assert sorted(t for t in s.unpack_ids if t >= 0) == flat
+
+
+def test_pack_unpack_roundtrip():
+    rs = np.random.RandomState(0)
+    fb = rs.rand(H, W, 4).astype(np.float32)
+    ids = list(range(((W + 15) // 16) * ((H + 15) // 16)))
+    out = unpack_tiles_numpy(pack_tiles_numpy(fb, ids), ids, np.zeros_like(fb))
+    assert np.array_equal(out, fb)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = TileShard(W, H, world, rank)
+        r = scenes.oracle_scene("c1", W, H)
+        tiles_x = (W + 15) // 16
+        for t in shard.mine:                      # render only the owned tiles
+            tx, ty = t % tiles_x, t // tiles_x
+            r.render(SPP, rect=(tx * 16, ty * 16, min(W, tx * 16 + 16), min(H, ty * 16 + 16)), threads=1)
+            r.sample = 0
+        packed = torch.from_numpy(pack_tiles_numpy(r.fb, shard.pack_ids))
+        gathered = torch.empty(shard.gathered_floats, dtype=torch.float32)
+        shard.all_gather(dist, gathered, packed)
+        frame = unpack_tiles_numpy(gathered.numpy(), shard.unpack_ids, np.zeros((H, W, 4), np.float32))
+        q.put((rank, frame))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_render_equals_single_process():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    frames = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = scenes.oracle_scene("c1", W, H).render(SPP)
+    for rk in (0, 1):
+        assert np.array_equal(frames[rk].view(np.uint32), ref.view(np.uint32)), "rank %d frame differs" % rk

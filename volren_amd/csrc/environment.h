@@ -26,6 +26,7 @@ public:
     float strength;
     DeviceBufferPtr envmap;      // RGBA32F texels, row 0 = bottom of the image (GL texture order)
     DeviceBufferPtr impmap;      // R32F pyramid: 512^2, 256^2, ..., 1
+    DeviceBufferPtr cdf;         // per-2x2-block warp thresholds derived from the pyramid (see vr_trace.h sample_environment)
     int width = 0, height = 0;
 
     std::vector<float> download_impmap() const;

@@ -236,6 +236,7 @@ void RendererHIP::fill_params(SceneParams& P) {
     P.env_w = environment->width; P.env_h = environment->height;
     P.impmap = environment->impmap->as<float>();
     P.imp_dim = (int)environment->dimension();
+    P.env_cdf = environment->cdf->as<float>();
     u.resolution[0] = resolution.x; u.resolution[1] = resolution.y;
     u.integrator = integrator;
 }

@@ -20,6 +20,9 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, uint3
 // env_setup.glsl:18-34 + glGenerateMipmap (environment.cpp:27-31): importance pyramid of a dim x dim map
 void launch_build_impmap(const float* envmap_rgba, int32_t env_w, int32_t env_h, int32_t dim, float* pyramid, hipStream_t stream);
 
+// warp table of sample_environment: float4 per 2x2 block of every pyramid level (coarsest first); (dim^2 - 1) / 3 records
+void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipStream_t stream);
+
 // effective majorant of every cell of every range mip:
 //   m = density_scale * float(range.y);  with a LUT: m = vol_majorant * tf_lookup(m * vol_inv_majorant).a
 // (common.glsl:278-281, 425, 472)

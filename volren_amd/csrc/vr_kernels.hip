@@ -174,7 +174,7 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
 }
 
 // thr[]: NEW, (unused), MARCH (= flush level of the hot pair), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE
-static SchedParams g_sched = { { 16, 4, 24, 2, 12, 12, 16, 0 }, 0u };
+static SchedParams g_sched = { { 24, 4, 24, 2, 20, 20, 24, 0 }, 0u };
 static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
 static int32_t g_samples_per_unit = 4;
 static int32_t g_blocks_per_cu = 0;                 // 0 = from the occupancy query
@@ -267,6 +267,29 @@ impmap_mip_kernel(const float* __restrict__ src, int32_t d, float* __restrict__ 
     const float c = src[(size_t)(2 * y + 1) * d + 2 * x], e = src[(size_t)(2 * y + 1) * d + 2 * x + 1];
     dst[i] = ((a + b) + (c + e)) * 0.25f;
 }
+// warp table of sample_environment (see vr_trace.h): one thread per 2x2 block of pyramid level `mip`
+__global__ void __launch_bounds__(256)
+env_cdf_kernel(const float* __restrict__ level, int32_t d, float* __restrict__ out) {
+    const int32_t hd = d >> 1;
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hd * hd) return;
+    const int32_t x = i % hd, y = i / hd;
+    const float w0 = level[(size_t)(2 * y) * d + 2 * x], w1 = level[(size_t)(2 * y) * d + 2 * x + 1];
+    const float w2 = level[(size_t)(2 * y + 1) * d + 2 * x], w3 = level[(size_t)(2 * y + 1) * d + 2 * x + 1];
+    const float q0 = w0 + w2, q1 = w1 + w3;
+    reinterpret_cast<float4*>(out)[i] = make_float4(q0 / max_(1e-8f, q0 + q1), w0 / q0, w1 / q1, 0.0f);
+}
+void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipStream_t stream) {
+    // levels base-1 .. 0; level m lives at pyramid offset imp_level_offset(dim, m) and has (dim >> m)^2 texels
+    int32_t base = 0;
+    while ((1 << base) < dim) ++base;
+    for (int32_t mip = base - 1; mip >= 0; --mip) {
+        const int32_t d = dim >> mip, n = (d >> 1) * (d >> 1);
+        float* dst = table + 4 * (size_t)env_cdf_offset(base - 1 - mip);
+        hipLaunchKernelGGL(env_cdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pyramid + imp_level_offset(dim, mip), d, dst);
+    }
+}
+
 void launch_build_impmap(const float* envmap_rgba, int32_t env_w, int32_t env_h, int32_t dim, float* pyramid, hipStream_t stream) {
     const dim3 grid((dim + 15) / 16, (dim + 15) / 16), block(256);
     hipLaunchKernelGGL(impmap_base_kernel, grid, block, 0, stream, envmap_rgba, env_w, env_h, dim, pyramid);

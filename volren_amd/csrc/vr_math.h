@@ -98,8 +98,56 @@ VR_HD float log_(float x) {
     return r;
 }
 
-// -log(1 - xi) for xi in [0,1): the free-flight optical depth draw (common.glsl:421,451,468,497)
-VR_HD float neg_log_1m(float xi) { return -log_(1.0f - xi); }
+// log_(x) restricted to normal, finite x in (0, 1]: same arithmetic, none of the special-case tests
+VR_HD float log_unit_(float x) {
+    const uint32_t u = f2u(x);
+    int e = (int)((u >> 23) & 0xFFu) - 126;
+    float m = u2f((u & 0x007FFFFFu) | 0x3F000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; }
+    else { m = m - 1.0f; }
+    const float z = m * m;
+    float y = 7.0376836292E-2f;
+    y = fma_(y, m, -1.1514610310E-1f);
+    y = fma_(y, m, 1.1676998740E-1f);
+    y = fma_(y, m, -1.2420140846E-1f);
+    y = fma_(y, m, 1.4249322787E-1f);
+    y = fma_(y, m, -1.6668057665E-1f);
+    y = fma_(y, m, 2.0000714765E-1f);
+    y = fma_(y, m, -2.4999993993E-1f);
+    y = fma_(y, m, 3.3333331174E-1f);
+    y = y * m * z;
+    const float fe = (float)e;
+    y = fma_(-2.12194440e-4f, fe, y);
+    y = fma_(-0.5f, z, y);
+    float r = m + y;
+    r = fma_(0.693359375f, fe, r);
+    return r;
+}
+// -log(1 - xi) for xi = k * 2^-24 in [0,1): the free-flight optical depth draw (common.glsl:421,451,468,497).
+// 1 - xi is exact and lies in [2^-24, 1], so the restricted log applies.
+VR_HD float neg_log_1m(float xi) { return -log_unit_(1.0f - xi); }
+
+// r < w / s decided without the full IEEE division whenever the answer is not within rounding distance:
+// q = w * rcp(s) is within 2.5 ulp of w/s, so outside a +-8 ulp band the comparison with q equals the comparison with
+// the correctly rounded quotient; inside the band (probability ~1e-6) the exact division decides.  Host: always exact.
+VR_HD bool lt_quot(float r, float w, float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float q = w * __builtin_amdgcn_rcpf(s);
+    const float m = abs_(q) * 9.5367431640625e-07f;      // 2^-20
+    if (r < q - m) return true;
+    if (r > q + m) return false;
+#endif
+    return r < w / s;
+}
+
+// float(b) / 255.f for b in 0..255 (GL unorm8), correctly rounded in 3 operations instead of a division
+// (y = RN(1/255), q = b*y, q + fma(-q,255,b)*y; verified exhaustively against b / 255.f on host and device)
+VR_HD float unorm8(uint32_t b) {
+    const float a = (float)b;
+    const float y = 1.0f / 255.0f;
+    const float q = a * y;
+    return fma_(fma_(-q, 255.0f, a), y, q);
+}
 
 struct SinCosArg { float r; int j; };
 VR_HD SinCosArg sincos_reduce(float ax) {

@@ -48,6 +48,7 @@ struct SceneParams {
     int32_t env_w, env_h;
     const float* impmap;               // importance pyramid, level 0 (dim^2) first, 2x2 box mips after it
     int32_t imp_dim;
+    const float* env_cdf;              // warp table: float4 (d, e0, e1, 0) per 2x2 block of every pyramid level, coarsest first
     float cam_z;                       // -.5f / tan(.5f * M_PI * cam_fov / 180.f), common.glsl:78 (uniform per frame)
 };
 

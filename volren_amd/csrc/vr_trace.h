@@ -98,18 +98,18 @@ VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
     if (bx >= (uint32_t)g.nb[0] || by >= (uint32_t)g.nb[1] || bz >= (uint32_t)g.nb[2]) return 0.0f;
     const BrickRec rec = g.bricks[(bz * (uint32_t)g.nb[1] + by) * (uint32_t)g.nb[0] + bx];
     const uint32_t b = g.atlas[(size_t)rec.slot * 512u + ((((uint32_t)z & 7u) << 6) | (((uint32_t)y & 7u) << 3) | ((uint32_t)x & 7u))];
-    const float unorm = (float)b / 255.0f;
-    return rec.rmin + unorm * rec.rdiff;
+    return rec.rmin + unorm8(b) * rec.rdiff;
 }
 VR_HD float majorant_at(const GridView& g, v3 ipos, int32_t mip) {
-    const int32_t x = floor2i(ipos.x), y = floor2i(ipos.y), z = floor2i(ipos.z);
-    if ((x | y | z) < 0) return 0.0f;
-    const uint32_t sh = 3u + (uint32_t)mip;
-    const uint32_t bx = (uint32_t)x >> sh, by = (uint32_t)y >> sh, bz = (uint32_t)z >> sh;
+    // cell = floor(ipos) >> (3 + mip); outside [0, cells) (or NaN) reads 0.  The range test is done on the floats
+    // (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails both), after which truncation equals floor.
     if (mip > g.n_mips) return 0.0f;
+    const uint32_t sh = 3u + (uint32_t)mip;
     const uint32_t rnd = (1u << mip) - 1u;
     const uint32_t dx = ((uint32_t)g.nb[0] + rnd) >> mip, dy = ((uint32_t)g.nb[1] + rnd) >> mip, dz = ((uint32_t)g.nb[2] + rnd) >> mip;
-    if (bx >= dx || by >= dy || bz >= dz) return 0.0f;
+    const float lx = (float)(dx << sh), ly = (float)(dy << sh), lz = (float)(dz << sh);
+    if (!(ipos.x >= 0.0f && ipos.x < lx && ipos.y >= 0.0f && ipos.y < ly && ipos.z >= 0.0f && ipos.z < lz)) return 0.0f;
+    const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
     // lane-varying mip: select the level offset instead of indexing the kernel-argument array
     const int32_t off = mip == 0 ? g.mip_off[0] : (mip == 1 ? g.mip_off[1] : (mip == 2 ? g.mip_off[2] : g.mip_off[3]));
     return g.majorant[(uint32_t)off + (bz * dy + by) * dx + bx];
@@ -128,39 +128,40 @@ VR_HD float density_trilinear_raw(const GridView& g, v3 ipos) {
     return mix_(mix_(lx0, lx1, fy), mix_(hx0, hx1, fy), fz);
 }
 
-// stochastic tricubic tap (common.glsl:221-244): 9 draws in the order tap2.xyz, tap3.xyz, tap4.xyz
-VR_HD int32_t tricubic_axis_weights(float q, float& w1, float& c2, float& c3, float& c4) {
-    // returns floor(q); thresholds c_k = w_k / max(1e-3, w_1 + ... + w_k)
+// stochastic tricubic tap (common.glsl:221-244): 9 draws in the order tap2.xyz, tap3.xyz, tap4.xyz;
+// tap k replaces the choice when draw < w_k / max(1e-3, w_1 + ... + w_k)
+struct AxisWeights { float w2, s2, w3, s3, w4, s4; int32_t base; };
+VR_HD AxisWeights tricubic_axis_weights(float q) {
+    AxisWeights a;
     const float fl = floor_(q);
     const float t = q - fl, t2 = t * t;
     const float k = 1.0f / 6.0f;
-    w1 = k * (-t * t2 + 3.0f * t2 - 3.0f * t + 1.0f);
-    float sum = w1;
-    float w = k * (3.0f * t * t2 - 6.0f * t2 + 4.0f);
-    sum = w + sum; c2 = w / max_(1e-3f, sum);
-    w = k * (-3.0f * t * t2 + 3.0f * t2 + 3.0f * t + 1.0f);
-    sum = w + sum; c3 = w / max_(1e-3f, sum);
-    w = k * t * t2;
-    sum = w + sum; c4 = w / max_(1e-3f, sum);
-    return floor2i(q);
+    float sum = k * (-t * t2 + 3.0f * t2 - 3.0f * t + 1.0f);
+    a.w2 = k * (3.0f * t * t2 - 6.0f * t2 + 4.0f);
+    sum = a.w2 + sum; a.s2 = max_(1e-3f, sum);
+    a.w3 = k * (-3.0f * t * t2 + 3.0f * t2 + 3.0f * t + 1.0f);
+    sum = a.w3 + sum; a.s3 = max_(1e-3f, sum);
+    a.w4 = k * t * t2;
+    sum = a.w4 + sum; a.s4 = max_(1e-3f, sum);
+    a.base = floor2i(q);
+    return a;
 }
 VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) {
-    float w1, ax2, ax3, ax4, ay2, ay3, ay4, az2, az3, az4;
-    const int32_t ix = tricubic_axis_weights(ipos.x - 0.5f, w1, ax2, ax3, ax4);
-    const int32_t iy = tricubic_axis_weights(ipos.y - 0.5f, w1, ay2, ay3, ay4);
-    const int32_t iz = tricubic_axis_weights(ipos.z - 0.5f, w1, az2, az3, az4);
+    const AxisWeights ax = tricubic_axis_weights(ipos.x - 0.5f);
+    const AxisWeights ay = tricubic_axis_weights(ipos.y - 0.5f);
+    const AxisWeights az = tricubic_axis_weights(ipos.z - 0.5f);
     int32_t jx = 0, jy = 0, jz = 0;
     float r;
-    r = rng(seed); if (r < ax2) jx = 1;
-    r = rng(seed); if (r < ay2) jy = 1;
-    r = rng(seed); if (r < az2) jz = 1;
-    r = rng(seed); if (r < ax3) jx = 2;
-    r = rng(seed); if (r < ay3) jy = 2;
-    r = rng(seed); if (r < az3) jz = 2;
-    r = rng(seed); if (r < ax4) jx = 3;
-    r = rng(seed); if (r < ay4) jy = 3;
-    r = rng(seed); if (r < az4) jz = 3;
-    tx = offs_i(ix, jx - 1); ty = offs_i(iy, jy - 1); tz = offs_i(iz, jz - 1);
+    r = rng(seed); if (lt_quot(r, ax.w2, ax.s2)) jx = 1;
+    r = rng(seed); if (lt_quot(r, ay.w2, ay.s2)) jy = 1;
+    r = rng(seed); if (lt_quot(r, az.w2, az.s2)) jz = 1;
+    r = rng(seed); if (lt_quot(r, ax.w3, ax.s3)) jx = 2;
+    r = rng(seed); if (lt_quot(r, ay.w3, ay.s3)) jy = 2;
+    r = rng(seed); if (lt_quot(r, az.w3, az.s3)) jz = 2;
+    r = rng(seed); if (lt_quot(r, ax.w4, ax.s4)) jx = 3;
+    r = rng(seed); if (lt_quot(r, ay.w4, ay.s4)) jy = 3;
+    r = rng(seed); if (lt_quot(r, az.w4, az.s4)) jz = 3;
+    tx = offs_i(ax.base, jx - 1); ty = offs_i(ay.base, jy - 1); tz = offs_i(az.base, jz - 1);
 }
 
 // transfer function (common.glsl:203-212)
@@ -217,18 +218,28 @@ VR_HD v3 lookup_environment(const SceneParams& P, v3 dir) {
     const v3 c = env_texture(P, u, v);
     return v3{ P.u.env_strength * c.x, P.u.env_strength * c.y, P.u.env_strength * c.z };
 }
+// The 2x2 warp of level `mip` only needs three numbers per parent cell: d = q0 / max(1e-8, q0 + q1), e0 = w0 / q0,
+// e1 = w1 / q1 (common.glsl:116,126).  They depend on the importance pyramid alone, so they are tabulated once per
+// environment (cdf_kernel, same operations) as one 16-byte record per cell: 1 load and 2 divisions per level instead
+// of 4 loads and 4 divisions.  Cells of level base-1 (1 cell) come first, level 0 ((dim/2)^2 cells) last.
+VR_HD int32_t env_cdf_offset(int32_t levels_above) { return ((1 << (2 * levels_above)) - 1) / 3; }   // sum_{i<k} 4^i
 VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i, v3& Le, float& pdf_out) {
     int32_t posx = 0, posy = 0;
     float px = r0, py = r1;
-    for (int32_t mip = P.u.env_imp_base_mip - 1; mip >= 0; mip--) {
+    const int32_t top = P.u.env_imp_base_mip - 1;
+    for (int32_t mip = top; mip >= 0; mip--) {
+        const int32_t k = top - mip;                           // cells per axis at this level = 2^k
+        const float* rec = P.env_cdf + 4 * (env_cdf_offset(k) + (posy << k) + posx);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float4 t = *reinterpret_cast<const float4*>(rec);
+        const float d = t.x, e0 = t.y, e1 = t.z;
+#else
+        const float d = rec[0], e0 = rec[1], e1 = rec[2];
+#endif
         posx *= 2; posy *= 2;
-        const float w0 = imp_fetch(P, posx, posy, mip), w1 = imp_fetch(P, posx + 1, posy, mip);
-        const float w2 = imp_fetch(P, posx, posy + 1, mip), w3 = imp_fetch(P, posx + 1, posy + 1, mip);
-        const float q0 = w0 + w2, q1 = w1 + w3;
-        const float d = q0 / max_(1e-8f, q0 + q1);
         float e;
-        if (px < d) { px = px / d; e = w0 / q0; }
-        else { posx += 1; px = (px - d) / (1.0f - d); e = w1 / q1; }
+        if (px < d) { px = px / d; e = e0; }
+        else { posx += 1; px = (px - d) / (1.0f - d); e = e1; }
         if (py < e) { py = py / e; }
         else { posy += 1; py = (py - e) / (1.0f - e); }
     }
