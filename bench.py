@@ -29,7 +29,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROA
 
 
 def algorithmic_bytes_per_sample(counters, spp, use_tf, has_emission):
-    """B = 4*N_dda + b_tap*T*N_coll + b_em*N_coll_sv + 200*N_nee + 48*N_esc + 16/spp."""
+    """B = 4*N_dda + b_tap*T*N_coll + b_em*N_coll_sv + 200*N_nee + 48*N_esc + B_fb, with
+    B_fb = 32 B: 16 B written to the per-sample radiance pool + 16 B read back by the ordered accumulate pass
+    (the same 32 B the reference's per-dispatch image read-modify-write costs)."""
     n = float(counters["samples"])
     n_dda = (counters["n_dda_sv"] + counters["n_dda_tr"]) / n
     n_coll = (counters["n_coll_sv"] + counters["n_coll_tr"]) / n
@@ -37,7 +39,7 @@ def algorithmic_bytes_per_sample(counters, spp, use_tf, has_emission):
     n_nee = counters["n_nee"] / n
     n_esc = counters["n_esc"] / n
     taps = 8 if use_tf else 1
-    b = 4.0 * n_dda + 9.0 * taps * n_coll + (9.0 if has_emission else 0.0) * n_coll_sv + 200.0 * n_nee + 48.0 * n_esc + 16.0 / spp
+    b = 4.0 * n_dda + 9.0 * taps * n_coll + (9.0 if has_emission else 0.0) * n_coll_sv + 200.0 * n_nee + 48.0 * n_esc + 32.0
     return b, dict(N_dda=n_dda, N_coll=n_coll, N_coll_sv=n_coll_sv, N_nee=n_nee, N_esc=n_esc,
                    primary_miss=counters["n_primary_miss"] / n)
 
@@ -157,7 +159,15 @@ def main():
             _, counters = cpu_baseline_and_counters(args.config, w, h, 0.5)
         b_sample, events = algorithmic_bytes_per_sample(counters, spp, use_tf, False)
         my_samples = len(mine) * 256.0 * spp if world > 1 else samples_per_step
-        achieved = b_sample * my_samples / (last_ms * 1e-3) / 1e9
+        launches = max(1, r.last_launches)                       # a frame is split so that a sub-launch fits the sample pool
+        launch_ms = last_ms / launches                           # HIP events on the renderer's stream around the frame's launches
+        achieved = b_sample * (my_samples / launches) / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass (FETCH_SIZE/WRITE_SIZE), collected separately
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("config") == args.config and tj.get("width") == w and tj.get("height") == h:
+                traffic = tj["hbm_bytes_per_sample"] * (my_samples / launches)
         out = {
             "metric": "Msamples/s (pixels x spp / s), volume path tracing",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,8 +177,10 @@ def main():
                 {"c1": 0, "c2": 1, "c3": 2}.get(args.config, -1), args.config, " + lut.txt" if use_tf else ", no transfer function", w, h, spp),
                 "parallelism": "tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame" % world if world > 1 else "1 GPU, 1 fused launch/frame"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "pathtrace_kernel<%s>" % ("true" if use_tf else "false"), "kernel_ms": last_ms,
-                         "bytes_per_sample": b_sample, "events_per_sample": events},
+                         "traffic": traffic, "kernel": "pathtrace_kernel<%s,false>" % ("true" if use_tf else "false"),
+                         "kernel_ms": launch_ms, "launches_per_step": launches, "samples_per_launch": my_samples / launches,
+                         "bytes_per_sample": b_sample, "events_per_sample": events,
+                         "note": "bytes = algorithmic (SURVEY 8d); the scene is cache resident and the kernel is VALU-issue/latency bound, see DESIGN.md 5/7"},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu

@@ -222,6 +222,7 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "integrator") *v = R.integrator;
         else if (n == "grid_frame_counter") *v = R.volume ? (int)R.volume->grid_frame_counter : 0;
         else if (n == "n_grid_frames") *v = R.volume ? (int)R.volume->n_grid_frames() : 0;
+        else if (n == "last_launches") *v = R.last_launches;
         else if (n == "width") *v = R.resolution.x;
         else if (n == "height") *v = R.resolution.y;
         else throw std::runtime_error("unknown int parameter: " + n);

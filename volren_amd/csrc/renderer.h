@@ -98,6 +98,7 @@ struct RendererHIP {
     ivec2 resolution{ 0, 0 };
     hipStream_t stream = nullptr;
     int integrator = 0;                               // 0: DDA tracking (both reference kernels)
+    int last_launches = 0;                            // path-tracing sub-launches of the last trace()/render()
     size_t sample_pool_bytes = (size_t)2 << 30;       // HBM budget of the per-sample radiance pool (16 B per pixel-sample)
 
     void set_tiles(const std::vector<int32_t>& tile_ids);     // empty = whole frame
