@@ -286,12 +286,13 @@ void RendererHIP::launch(int n) {
     per_launch = std::min(per_launch, n);
     const size_t need = pathtrace_pool_floats(n_tiles, per_launch) * sizeof(float);
     if (!pool_ || pool_->size_bytes() < need) { pool_.reset(); pool_ = make_device_buffer(need); }
+    if (!workspace_) workspace_ = make_device_buffer(pathtrace_workspace_floats() * sizeof(float));
     VR_HIP(hipEventRecord(ev0_, stream));
     last_launches = 0;
     for (int done = 0; done < n; done += per_launch) {
         ++last_launches;
         const int m = std::min(per_launch, n - done);
-        launch_pathtrace(P, color->as<float>(), pool_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, sample + 1 + done, m, status_->as<uint32_t>(), stream);
+        launch_pathtrace(P, color->as<float>(), pool_->as<float>(), workspace_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, sample + 1 + done, m, status_->as<uint32_t>(), stream);
         VR_HIP(hipGetLastError());
     }
     VR_HIP(hipEventRecord(ev1_, stream));

@@ -117,6 +117,7 @@ private:
     DeviceBufferPtr tiles_dev_;
     DeviceBufferPtr status_;
     DeviceBufferPtr pool_;
+    DeviceBufferPtr workspace_;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     double last_ms_ = 0.0;
     bool timing_pending_ = false;

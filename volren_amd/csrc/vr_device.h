@@ -14,7 +14,8 @@ namespace vr {
 // tiles == nullptr: all tiles of the frame (n_tiles = their count).  sample_pool must hold
 // pathtrace_pool_floats(n_tiles, n_samples) floats; unit_counter is one device word (the work queue head).  status[0] is set non-zero if a wavefront trips the watchdog.
 size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples);
-void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
+size_t pathtrace_workspace_floats();      // cold path state of all resident wavefronts
+void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream);
 
 // env_setup.glsl:18-34 + glGenerateMipmap (environment.cpp:27-31): importance pyramid of a dim x dim map

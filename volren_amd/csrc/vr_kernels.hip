@@ -52,89 +52,246 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #ifndef VR_WAVES_PER_SIMD
 #define VR_WAVES_PER_SIMD 4
 #endif
+
+// ---------------------------------------------------------------------------------------------------
+// Wave-private path pool.
+//
+// A wavefront owns NSLOT path slots, more than it has lanes.  The 64 lanes hold, in registers, the hot state of the
+// paths that are currently marching; every other path of the pool is parked: its hot state (NHOT dwords) sits in LDS
+// and its slot id in one of the wave's LDS stacks -- READY (may march), NEE / POSTNEE / ESCAPE (wait for that event),
+// FREE.  Cold path state lives in global memory ([wave][field][slot], L2 resident), it is only touched by the events.
+//   * a lane whose path reaches an event parks it (16 ds_write + a stack push) and immediately resumes a READY path,
+//     so the march/collide code runs with (nearly) all 64 lanes;
+//   * an event's code runs when a full-width batch of parked paths has piled up (or when the wave runs dry): lane i
+//     loads parked path i of the batch, runs the unchanged per-path code of vr_trace.h, stores it and routes the slot to
+//     the stack of its new state.  The marching lanes' registers are saved/restored around a batch phase (the lanes
+//     double as batch workers), which costs 32 LDS instructions per phase -- about 2 per sample.
+// Everything is wave-synchronous (ballots, mbcnt ranks, scalar counters): no atomics, no barriers, no spinning; the only
+// global atomic is the work-queue head.  Which lane runs which path never changes a result.
+#ifndef VR_NSLOT
+#define VR_NSLOT 160
+#endif
+constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
+
+constexpr int32_t NHOT = 12;
+enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
+
+struct HotStore {                      // [field][slot] dwords in LDS; lanes address different slots
+    uint32_t* base;
+    // 12 dwords per parked path: ri = 1/idir is recomputed on load (same IEEE divisions), mip (a multiple of 1/4 in
+    // [0,3]) rides in the flag word
+    __device__ __forceinline__ void save(const Hot& h, int32_t slot) const {
+        uint32_t* p = base + slot;
+        p[0 * NSLOT] = h.seed;
+        p[1 * NSLOT] = f2u(h.ipos.x); p[2 * NSLOT] = f2u(h.ipos.y); p[3 * NSLOT] = f2u(h.ipos.z);
+        p[4 * NSLOT] = f2u(h.idir.x); p[5 * NSLOT] = f2u(h.idir.y); p[6 * NSLOT] = f2u(h.idir.z);
+        p[7 * NSLOT] = f2u(h.t); p[8 * NSLOT] = f2u(h.far); p[9 * NSLOT] = f2u(h.tau);
+        p[10 * NSLOT] = f2u(h.Tr);
+        p[11 * NSLOT] = (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)(int32_t)(h.mip * 4.0f) << 16);
+    }
+    __device__ __forceinline__ void load(Hot& h, int32_t slot) const {
+        const uint32_t* p = base + slot;
+        h.seed = p[0 * NSLOT];
+        h.ipos = v3{ u2f(p[1 * NSLOT]), u2f(p[2 * NSLOT]), u2f(p[3 * NSLOT]) };
+        h.idir = v3{ u2f(p[4 * NSLOT]), u2f(p[5 * NSLOT]), u2f(p[6 * NSLOT]) };
+        h.ri = v3{ 1.0f / h.idir.x, 1.0f / h.idir.y, 1.0f / h.idir.z };
+        h.t = u2f(p[7 * NSLOT]); h.far = u2f(p[8 * NSLOT]); h.tau = u2f(p[9 * NSLOT]);
+        h.Tr = u2f(p[10 * NSLOT]);
+        const uint32_t f = p[11 * NSLOT];
+        h.state = (int32_t)(f & 0xFFu); h.shadow = (int32_t)((f >> 8) & 0xFFu);
+        h.mip = (float)(f >> 16) * 0.25f;
+        h.majorant = 0.0f;
+    }
+};
+struct ColdGlobal {                    // [field][slot] floats of this wavefront's slice of the workspace
+    float* base;
+    __device__ __forceinline__ float ld(int32_t f) const { return base[f * NSLOT]; }
+    __device__ __forceinline__ void st(int32_t f, float v) { base[f * NSLOT] = v; }
+};
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 template <bool USE_TF, bool STATS>
 __global__ void __launch_bounds__(256, VR_WAVES_PER_SIMD)
-pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, const LaunchDesc D, const SchedParams S,
+pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restrict__ cold_ws, const LaunchDesc D, const SchedParams S,
                  uint32_t* __restrict__ status, unsigned long long* __restrict__ stats) {
     const int32_t W = P.u.resolution[0];
     const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+
+    __shared__ uint8_t lds_q[4 * Q_COUNT * NSLOT];
+    uint8_t* const q = lds_q + wave * (Q_COUNT * NSLOT);
+    // per-wavefront slice of the workspace: the cold fields of its NSLOT paths
+    float* const cold_base = cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)(C_COUNT * NSLOT);
+    __shared__ uint32_t lds_hot[4 * NHOT * NSLOT];
+    const HotStore hs{ lds_hot + wave * (NHOT * NSLOT) };
+
+    int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = NSLOT;     // stack heights (wave-uniform)
+    for (int32_t i = lane; i < NSLOT; i += 64) q[Q_FREE * NSLOT + i] = (uint8_t)i;
+    __builtin_amdgcn_wave_barrier();
 
     WorkUnit wu;
     wu.px0 = wu.py0 = 0; wu.first_sample = 1; wu.n_items = 0; wu.base = 0u; wu.out = sbuf;
     uint32_t cursor = 0u;             // next item of the current unit (wave-uniform)
     bool exhausted = false;           // the global queue has no more units
 
-    // cold path state of the workgroup's 4 wavefronts: [wave][field][lane] dwords, lanes on consecutive banks
-    __shared__ float cold_mem[4 * C_COUNT * 64];
-    struct ColdLDS {
-        float* base;
-        __device__ __forceinline__ float ld(int32_t f) const { return base[f * 64]; }
-        __device__ __forceinline__ void st(int32_t f, float v) { base[f * 64] = v; }
-    } c{ cold_mem + wave * (C_COUNT * 64) + lane };
-
     Hot l;
     hot_init(l);
+    int32_t slot = -1;                // path held in this lane's registers (-1: none)
 
     uint32_t iters = 0u;
-    // optional scheduler statistics (wave-uniform counters in scalar registers): executions and active lanes per state
     uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
 #define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
 #define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
-    // Scheduler.  The hot pair MARCH/COLLIDE runs as ONE block per iteration (up to S.thr[ST_COLLIDE] march steps, then
-    // the collision code for every lane that reached one).  The rarer states are gated: a state's code runs when at least
-    // thr[state] lanes wait in it, or when the hot pair is running low on lanes (fewer than thr[ST_MARCH]) -- then every
-    // non-empty state is flushed.  Gates use fresh ballots in flow order (ESCAPE -> POSTNEE -> NEW -> NEE -> hot pair), so
-    // a lane can pass through several states in one iteration.
+// push the slots of all lanes where COND holds onto stack QI (wave-synchronous)
+#define VR_PUSH(QI, CNT, COND, SLOTV) do { \
+        const uint64_t m_ = __ballot(COND); \
+        if (m_) { if (COND) q[(QI) * NSLOT + (CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(SLOTV); (CNT) += __popcll(m_); } \
+    } while (0)
+
     for (;;) {
-        const int32_t n_hot = __popcll(__ballot(l.state == ST_MARCH || l.state == ST_COLLIDE));
-        if (__ballot(l.state != ST_DONE) == 0ull) break;
         if (++iters > S.max_iters) {
             if (lane == 0) atomicOr(status, 1u);
             break;
         }
-        const bool flush = n_hot < S.thr[ST_MARCH];
+        // (1) idle lanes resume READY paths
+        {
+            const uint64_t idle = __ballot(slot < 0);
+            const int32_t take = min(__popcll(idle), cnt_ready);
+            if (take > 0) {
+                if (slot < 0) {
+                    const int32_t r = (int32_t)lane_rank(idle);
+                    if (r < take) { slot = q[Q_READY * NSLOT + cnt_ready - 1 - r]; hs.load(l, slot); }
+                }
+                cnt_ready -= take;
+            }
+        }
+        // (2) the hot pair: up to thr[COLLIDE] march steps, then the collision code
         int32_t n;
-        n = __popcll(__ballot(l.state == ST_ESCAPE));
-        if (n > 0 && (flush || n >= S.thr[ST_ESCAPE])) { VR_STAT(ST_ESCAPE, n); if (l.state == ST_ESCAPE) do_escape(l, c, P, wu); VR_STAT_END(ST_ESCAPE); }
-        n = __popcll(__ballot(l.state == ST_POSTNEE));
-        if (n > 0 && (flush || n >= S.thr[ST_POSTNEE])) { VR_STAT(ST_POSTNEE, n); if (l.state == ST_POSTNEE) do_postnee(l, c, P, wu); VR_STAT_END(ST_POSTNEE); }
-        {   // lanes without work take the next items of the current unit; an empty unit is replaced from the global queue
-            const uint64_t want = __ballot(l.state == ST_NEW);
-            n = __popcll(want);
-            if (n > 0 && (flush || n >= S.thr[ST_NEW])) {
-                if (cursor == (uint32_t)wu.n_items && !exhausted) {
+        for (int32_t k = 0; k < S.thr[ST_COLLIDE]; ++k) {
+            n = __popcll(__ballot(slot >= 0 && l.state == ST_MARCH));
+            if (n == 0) break;
+            VR_STAT(ST_MARCH, n);
+            if (slot >= 0 && l.state == ST_MARCH) do_march(l, P);
+            VR_STAT_END(ST_MARCH);
+        }
+        n = __popcll(__ballot(slot >= 0 && l.state == ST_COLLIDE));
+        if (n > 0) {
+            VR_STAT(ST_COLLIDE, n);
+            if (slot >= 0 && l.state == ST_COLLIDE) { ColdGlobal c{ cold_base + slot }; do_collide<USE_TF>(l, c, P); }
+            VR_STAT_END(ST_COLLIDE);
+        }
+        // (3) park paths that reached an event
+        {
+            const bool parked = slot >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE;
+            if (__ballot(parked)) {
+                if (parked) hs.save(l, slot);
+                VR_PUSH(Q_NEE, cnt_nee, parked && l.state == ST_NEE, slot);
+                VR_PUSH(Q_POST, cnt_post, parked && l.state == ST_POSTNEE, slot);
+                VR_PUSH(Q_ESC, cnt_esc, parked && l.state == ST_ESCAPE, slot);
+                if (parked) slot = -1;
+            }
+        }
+        // (4) event batches
+        const int32_t n_live = __popcll(__ballot(slot >= 0)) + cnt_ready;
+        const bool hungry = n_live < S.thr[ST_MARCH];                    // the hot pair is about to run under-filled
+        // a batch runs when it is full enough; a hungry wave additionally runs its LARGEST batch (only that one, so that the
+        // others keep filling up)
+        const int32_t c_new = exhausted ? 0 : cnt_free;
+        int32_t big = c_new;
+        if (cnt_nee > big) big = cnt_nee;
+        if (cnt_post > big) big = cnt_post;
+        if (cnt_esc > big) big = cnt_esc;
+        const bool want_new = c_new > 0 && (c_new >= S.thr[ST_NEW] || (hungry && c_new == big));
+        const bool want_nee = cnt_nee > 0 && (cnt_nee >= S.thr[ST_NEE] || (hungry && cnt_nee == big));
+        const bool want_post = cnt_post > 0 && (cnt_post >= S.thr[ST_POSTNEE] || (hungry && cnt_post == big));
+        const bool want_esc = cnt_esc > 0 && (cnt_esc >= S.thr[ST_ESCAPE] || (hungry && cnt_esc == big));
+        if (want_new || want_nee || want_post || want_esc) {
+            // the lanes double as batch workers: save the marching paths' registers
+            const int32_t my_slot = slot;
+            if (my_slot >= 0) hs.save(l, my_slot);
+            __builtin_amdgcn_wave_barrier();
+            if (want_esc) {
+                n = min(64, cnt_esc);
+                VR_STAT(ST_ESCAPE, n);
+                int32_t bs = -1;
+                if (lane < n) {
+                    bs = q[Q_ESC * NSLOT + cnt_esc - 1 - lane];
+                    hs.load(l, bs);
+                    ColdGlobal c{ cold_base + bs };
+                    do_escape(l, c, P, wu);                              // writes the sample; the slot becomes free
+                }
+                cnt_esc -= n;
+                VR_PUSH(Q_FREE, cnt_free, bs >= 0, bs);
+                VR_STAT_END(ST_ESCAPE);
+            }
+            if (want_post) {
+                n = min(64, cnt_post);
+                VR_STAT(ST_POSTNEE, n);
+                int32_t bs = -1;
+                if (lane < n) {
+                    bs = q[Q_POST * NSLOT + cnt_post - 1 - lane];
+                    hs.load(l, bs);
+                    ColdGlobal c{ cold_base + bs };
+                    do_postnee(l, c, P, wu);
+                    hs.save(l, bs);
+                }
+                cnt_post -= n;
+                VR_PUSH(Q_READY, cnt_ready, bs >= 0 && l.state == ST_MARCH, bs);
+                VR_PUSH(Q_ESC, cnt_esc, bs >= 0 && l.state == ST_ESCAPE, bs);
+                VR_PUSH(Q_FREE, cnt_free, bs >= 0 && l.state == ST_NEW, bs);       // path ended (bounce cap / roulette)
+                VR_STAT_END(ST_POSTNEE);
+            }
+            if (want_new) {
+                if (cursor == (uint32_t)wu.n_items) {
                     uint32_t u = 0u;
                     if (lane == 0) u = atomicAdd(D.unit_counter, 1u);
                     u = __builtin_amdgcn_readfirstlane(u);
                     if (u >= D.n_units) exhausted = true;
                     else { wu = make_unit(D, W, u, sbuf); cursor = 0u; }
                 }
-                const uint32_t left = (uint32_t)wu.n_items - cursor;
-                if (left == 0u) {           // queue exhausted: these lanes are finished
-                    if (l.state == ST_NEW) l.state = ST_DONE;
-                } else {
+                n = min(min(64, cnt_free), (int32_t)((uint32_t)wu.n_items - cursor));
+                if (n > 0) {
                     VR_STAT(ST_NEW, n);
-                    if (l.state == ST_NEW) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-                        if (rank < left) do_new(l, c, P, wu, cursor + rank);      // the others stay in ST_NEW for the next unit
+                    int32_t bs = -1;
+                    if (lane < n) {
+                        bs = q[Q_FREE * NSLOT + cnt_free - 1 - lane];
+                        hot_init(l);
+                        ColdGlobal c{ cold_base + bs };
+                        do_new(l, c, P, wu, cursor + (uint32_t)lane);
+                        hs.save(l, bs);
                     }
+                    cnt_free -= n;
+                    cursor += (uint32_t)n;
+                    VR_PUSH(Q_READY, cnt_ready, bs >= 0 && l.state == ST_MARCH, bs);
+                    VR_PUSH(Q_ESC, cnt_esc, bs >= 0 && l.state == ST_ESCAPE, bs);
+                    VR_PUSH(Q_FREE, cnt_free, bs >= 0 && l.state == ST_NEW, bs);   // pixel outside a ragged frame: nothing to trace
                     VR_STAT_END(ST_NEW);
-                    cursor += min((uint32_t)n, left);
                 }
             }
+            if (want_nee) {
+                n = min(64, cnt_nee);
+                VR_STAT(ST_NEE, n);
+                int32_t bs = -1;
+                if (lane < n) {
+                    bs = q[Q_NEE * NSLOT + cnt_nee - 1 - lane];
+                    hs.load(l, bs);
+                    ColdGlobal c{ cold_base + bs };
+                    do_nee(l, c, P);
+                    hs.save(l, bs);
+                }
+                cnt_nee -= n;
+                VR_PUSH(Q_READY, cnt_ready, bs >= 0 && l.state == ST_MARCH, bs);
+                VR_PUSH(Q_POST, cnt_post, bs >= 0 && l.state == ST_POSTNEE, bs);
+                VR_STAT_END(ST_NEE);
+            }
+            __builtin_amdgcn_wave_barrier();
+            slot = my_slot;
+            if (my_slot >= 0) hs.load(l, my_slot);
         }
-        n = __popcll(__ballot(l.state == ST_NEE));
-        if (n > 0 && (flush || n >= S.thr[ST_NEE])) { VR_STAT(ST_NEE, n); if (l.state == ST_NEE) do_nee(l, c, P); VR_STAT_END(ST_NEE); }
-        for (int32_t k = 0; k < S.thr[ST_COLLIDE]; ++k) {
-            n = __popcll(__ballot(l.state == ST_MARCH));
-            if (n == 0) break;
-            VR_STAT(ST_MARCH, n);
-            if (l.state == ST_MARCH) do_march(l, P);
-            VR_STAT_END(ST_MARCH);
-        }
-        n = __popcll(__ballot(l.state == ST_COLLIDE));
-        if (n > 0) { VR_STAT(ST_COLLIDE, n); if (l.state == ST_COLLIDE) do_collide<USE_TF>(l, c, P); VR_STAT_END(ST_COLLIDE); }
+        if (exhausted && cnt_free == NSLOT) break;                        // every path of the pool has finished
     }
     if (STATS && stats && lane == 0) {
 #pragma unroll
@@ -147,6 +304,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, const LaunchDesc
     }
 #undef VR_STAT
 #undef VR_STAT_END
+#undef VR_PUSH
 }
 
 // Running mean over the samples of one launch, in sample order (pathtracer_brick.glsl:36): one thread per pixel.
@@ -174,7 +332,9 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
 }
 
 // thr[]: NEW, (unused), MARCH (= flush level of the hot pair), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE
-static SchedParams g_sched = { { 24, 4, 24, 2, 20, 20, 24, 0 }, 0u };
+// thr[]: NEW (free slots that trigger a NEW batch), unused, MARCH (= low-water mark of live paths: below it every
+// non-empty batch runs), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
+static SchedParams g_sched = { { 64, 0, 32, 2, 48, 48, 64, 0 }, 0u };
 static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
 static int32_t g_samples_per_unit = 4;
 static int32_t g_blocks_per_cu = 0;                 // 0 = from the occupancy query
@@ -211,7 +371,9 @@ static int resident_blocks(K kernel) {
     return cus * per_cu;
 }
 
-void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
+size_t pathtrace_workspace_floats() { return (size_t)8192 * C_COUNT * NSLOT; }      // cold state of up to 8192 resident wavefronts
+
+void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream) {
     if (n_tiles <= 0 || n_samples <= 0) return;
     tuning_from_env();
@@ -227,11 +389,11 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, uint3
                              : (g_stats ? pathtrace_kernel<false, true> : pathtrace_kernel<false, false>);
     static int blocks_cache[4] = { 0, 0, 0, 0 };
     int& blocks = blocks_cache[(P.u.use_tf ? 2 : 0) + (g_stats ? 1 : 0)];
-    if (blocks == 0 || g_blocks_per_cu > 0) blocks = resident_blocks(kernel);
+    if (blocks == 0 || g_blocks_per_cu > 0) blocks = std::min(resident_blocks(kernel), 2048);      // workspace holds 2048 workgroups
     const uint32_t waves_needed = (D.n_units + 3u) / 4u;
     const dim3 grid((unsigned)std::min<uint32_t>((uint32_t)blocks, waves_needed > 0 ? waves_needed : 1u)), block(256);
     (void)hipMemsetAsync(unit_counter, 0, sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(kernel, grid, block, 0, stream, P, sample_pool, D, S, status, g_stats);
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, P, sample_pool, workspace, D, S, status, g_stats);
     hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)n_tiles), block, 0, stream, sample_pool, fb, tiles, n_tiles,
                        P.u.resolution[0], P.u.resolution[1], first_sample, n_samples, D.spu);
 }
