@@ -85,6 +85,16 @@ def test_render_matches_oracle(name, w, h, spp):
     _assert_same(r.framebuffer(), o.render(spp), "%s %dx%d %dspp" % (name, w, h, spp))
 
 
+@pytest.mark.parametrize("name", ["c1", "c3"])
+def test_global_majorant_tracking_variant(name):
+    o = scenes.oracle_scene(name, 64, 64)
+    o.integrator = 1
+    r = scenes.hip_scene(name, 64, 64)
+    r.integrator = 1
+    r.render(8)
+    _assert_same(r.framebuffer(), o.render(8), "global-majorant tracking " + name)
+
+
 def test_trace_protocol_equals_fused_render():
     """trace() x N (the reference protocol) == render(N) == render(a) + render(b)."""
     a = scenes.hip_scene("c1", 48, 48)
@@ -166,3 +176,37 @@ def test_determinism_full_size_property():
     assert np.isfinite(fa).all() and (fa[..., 3] >= 0).all() and (fa[..., 3] <= 1).all()
     # 31 % of camera rays miss the box at fov 40: alpha==0 pixels exist, and they carry pure env radiance
     assert 0.3 < (fa[..., 3] == 0).mean() < 0.95
+
+
+def test_cli_offline_render_matches_oracle(tmp_path):
+    """`volren ... --render` (parse_cmd order semantics, offline loop, tonemap.glsl, PNG naming) against the
+    oracle's tonemapped frame: identical 8-bit pixels."""
+    import subprocess
+    from PIL import Image
+    exe = scenes.ROOT + "/volren_amd/volren"
+    cmd = [exe, scenes.SMOKE, scenes.HDR, "-w", "96", "-h", "80", "--render", "--spp", "12", "--bounces", "128", "--albedo", "0.8",
+           "--phase", "0.3", "--density", "100", "--env_strength", "3", "--env_rot", "270", "--exposure", "3", "--gamma", "2.0",
+           "--cam_fov", "40", "--output", "some/dir/shot.png"]
+    out = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    png = tmp_path / "shot_000000.png"            # directory of --output is dropped, "_%06d" appended (main.cpp:552-554)
+    assert png.exists(), out.stdout
+    img = np.asarray(Image.open(png))
+    assert img.shape == (80, 96, 4)
+    o = scenes.oracle_scene("readme", 96, 80)
+    o.render(12)
+    tm = o.tonemapped()[::-1]
+    want = np.floor(np.clip(tm, 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(img, want)
+
+
+def test_tonemap_and_display_buffer():
+    o = scenes.oracle_scene("c1", 48, 32)
+    o.tonemap_exposure, o.tonemap_gamma = 2.5, 2.2
+    o.render(4)
+    r = scenes.hip_scene("c1", 48, 32)
+    r.tonemap_exposure, r.tonemap_gamma = 2.5, 2.2
+    r.render(4)
+    r.draw()
+    assert np.array_equal(_bits(r.display()), _bits(o.tonemapped()))
+    assert np.array_equal(_bits(r.framebuffer()), _bits(o.fb))          # draw() leaves the accumulation buffer untouched

@@ -23,6 +23,19 @@ def test_state_machine_matches_oracle(name, w, h, spp):
     assert _same(got, want), "relative L2 %.3e" % scenes.rel_l2(got[..., :3], want[..., :3])
 
 
+@pytest.mark.parametrize("name", ["c1", "c3"])
+def test_global_majorant_tracking_variant(name):
+    """common.glsl:333-394 (delta / ratio tracking against the global majorant; the reference compiles it out with USE_DDA):
+    selectable as integrator = 1, and an unbiased cross-check of the DDA trackers."""
+    r = scenes.oracle_scene(name, 40, 40)
+    r.integrator = 1
+    want = r.render(8).copy()
+    got, _ = hk.render(r, 8)
+    assert _same(got, want)
+    dda = scenes.oracle_scene(name, 40, 40).render(8)
+    assert abs(float(want[..., :3].mean()) - float(dda[..., :3].mean())) < 0.1 * float(dda[..., :3].mean()) + 1e-4
+
+
 def test_sample_chunks_and_progressive_accumulation():
     """40 spp spans two 32-sample chunks of a wave's item pool; rendering 3 + 5 more samples continues the running mean."""
     r = scenes.oracle_scene("c1", 24, 24)

@@ -141,6 +141,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     int32_t slot = -1;                // path held in this lane's registers (-1: none)
 
     uint32_t iters = 0u;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
     uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
 #define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
@@ -151,8 +152,22 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
         if (m_) { if (COND) q[(QI) * NSLOT + (CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(SLOTV); (CNT) += __popcll(m_); } \
     } while (0)
 
+// route the batch paths to the stack of their new state; an impossible state is reported and the slot recycled
+#define VR_ROUTE(BS) do { \
+        const bool v_ = (BS) >= 0; \
+        VR_PUSH(Q_READY, cnt_ready, v_ && (l.state == ST_MARCH || l.state == ST_COLLIDE), BS); \
+        VR_PUSH(Q_NEE, cnt_nee, v_ && l.state == ST_NEE, BS); \
+        VR_PUSH(Q_POST, cnt_post, v_ && l.state == ST_POSTNEE, BS); \
+        VR_PUSH(Q_ESC, cnt_esc, v_ && l.state == ST_ESCAPE, BS); \
+        const bool lost_ = v_ && (l.state < ST_NEW || l.state > ST_ESCAPE || l.state == ST_BEGIN); \
+        if (__ballot(lost_)) { if (lost_) atomicOr(status, 2u); } \
+        VR_PUSH(Q_FREE, cnt_free, v_ && (l.state == ST_NEW || lost_), BS); \
+    } while (0)
+
     for (;;) {
-        if (++iters > S.max_iters) {
+        // watchdog: a wavefront's share of a launch is tens of milliseconds; give up (and report) after S.max_iters
+        // scheduler iterations or ~8 s of shader clock, whichever comes first -- a kernel must never hang the GPU
+        if (++iters > S.max_iters || ((iters & 1023u) == 0u && __builtin_readcyclecounter() - t_begin > 20000000000ull)) {
             if (lane == 0) atomicOr(status, 1u);
             break;
         }
@@ -180,7 +195,10 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
         n = __popcll(__ballot(slot >= 0 && l.state == ST_COLLIDE));
         if (n > 0) {
             VR_STAT(ST_COLLIDE, n);
-            if (slot >= 0 && l.state == ST_COLLIDE) { ColdGlobal c{ cold_base + slot }; do_collide<USE_TF>(l, c, P); }
+            if (slot >= 0 && l.state == ST_COLLIDE) {
+                ColdGlobal c{ cold_base + slot };
+                if (P.u.integrator != 0) do_collide_global<USE_TF>(l, c, P); else do_collide<USE_TF>(l, c, P);
+            }
             VR_STAT_END(ST_COLLIDE);
         }
         // (3) park paths that reached an event
@@ -188,9 +206,8 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
             const bool parked = slot >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE;
             if (__ballot(parked)) {
                 if (parked) hs.save(l, slot);
-                VR_PUSH(Q_NEE, cnt_nee, parked && l.state == ST_NEE, slot);
-                VR_PUSH(Q_POST, cnt_post, parked && l.state == ST_POSTNEE, slot);
-                VR_PUSH(Q_ESC, cnt_esc, parked && l.state == ST_ESCAPE, slot);
+                const int32_t ps = parked ? slot : -1;
+                VR_ROUTE(ps);
                 if (parked) slot = -1;
             }
         }
@@ -224,7 +241,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                     do_escape(l, c, P, wu);                              // writes the sample; the slot becomes free
                 }
                 cnt_esc -= n;
-                VR_PUSH(Q_FREE, cnt_free, bs >= 0, bs);
+                VR_ROUTE(bs);                                            // ST_NEW: the slot is free again
                 VR_STAT_END(ST_ESCAPE);
             }
             if (want_post) {
@@ -239,9 +256,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                     hs.save(l, bs);
                 }
                 cnt_post -= n;
-                VR_PUSH(Q_READY, cnt_ready, bs >= 0 && l.state == ST_MARCH, bs);
-                VR_PUSH(Q_ESC, cnt_esc, bs >= 0 && l.state == ST_ESCAPE, bs);
-                VR_PUSH(Q_FREE, cnt_free, bs >= 0 && l.state == ST_NEW, bs);       // path ended (bounce cap / roulette)
+                VR_ROUTE(bs);                                            // ST_NEW = path ended (bounce cap / roulette)
                 VR_STAT_END(ST_POSTNEE);
             }
             if (want_new) {
@@ -265,9 +280,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                     }
                     cnt_free -= n;
                     cursor += (uint32_t)n;
-                    VR_PUSH(Q_READY, cnt_ready, bs >= 0 && l.state == ST_MARCH, bs);
-                    VR_PUSH(Q_ESC, cnt_esc, bs >= 0 && l.state == ST_ESCAPE, bs);
-                    VR_PUSH(Q_FREE, cnt_free, bs >= 0 && l.state == ST_NEW, bs);   // pixel outside a ragged frame: nothing to trace
+                    VR_ROUTE(bs);                                        // ST_NEW = pixel outside a ragged frame
                     VR_STAT_END(ST_NEW);
                 }
             }
@@ -283,8 +296,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                     hs.save(l, bs);
                 }
                 cnt_nee -= n;
-                VR_PUSH(Q_READY, cnt_ready, bs >= 0 && l.state == ST_MARCH, bs);
-                VR_PUSH(Q_POST, cnt_post, bs >= 0 && l.state == ST_POSTNEE, bs);
+                VR_ROUTE(bs);
                 VR_STAT_END(ST_NEE);
             }
             __builtin_amdgcn_wave_barrier();
@@ -305,6 +317,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
 #undef VR_STAT
 #undef VR_STAT_END
 #undef VR_PUSH
+#undef VR_ROUTE
 }
 
 // Running mean over the samples of one launch, in sample order (pathtracer_brick.glsl:36): one thread per pixel.
@@ -384,7 +397,7 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     const int32_t chunks = (n_samples + D.spu - 1) / D.spu;
     D.n_units = (uint32_t)chunks * (uint32_t)n_tiles * 4u;
     D.unit_counter = unit_counter;
-    S.max_iters = 0xFFFFFFF0u;       // watchdog: every path is bounded by `bounces` and the grid extent; cap the loop anyway
+    S.max_iters = 1u << 27;          // watchdog (see the kernel): ~100x the iterations of the heaviest wavefront seen
     auto kernel = P.u.use_tf ? (g_stats ? pathtrace_kernel<true, true> : pathtrace_kernel<true, false>)
                              : (g_stats ? pathtrace_kernel<false, true> : pathtrace_kernel<false, false>);
     static int blocks_cache[4] = { 0, 0, 0, 0 };

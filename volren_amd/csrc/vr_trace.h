@@ -350,9 +350,19 @@ VR_HD void begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
     }
     h.ipos = mat4_point(P.u.vol_density_inv_transform, pos);
     h.idir = mat4_dir(P.u.vol_density_inv_transform, d);
+    h.far = tfar;
+    if (P.u.integrator != 0) {
+        // global-majorant delta / ratio tracking (common.glsl:333-394; compiled out in the reference by USE_DDA):
+        // t = near - log(1 - xi) * vol_inv_majorant, then straight to the first tentative collision
+        h.ri = v3{ 0, 0, 0 };
+        h.tau = 0.0f;
+        h.t = tnear + neg_log_1m(rng(h.seed)) * P.u.vol_inv_majorant;
+        if (h.t < h.far) { h.majorant = P.u.vol_majorant; h.state = ST_COLLIDE; }
+        else h.state = shadow ? ST_POSTNEE : ST_ESCAPE;
+        return;
+    }
     h.ri = v3{ 1.0f / h.idir.x, 1.0f / h.idir.y, 1.0f / h.idir.z };
     h.t = tnear + 1e-6f;
-    h.far = tfar;
     h.tau = neg_log_1m(rng(h.seed));
     h.state = ST_MARCH;
 }
@@ -444,6 +454,56 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
     h.state = ST_MARCH;
 }
 
+// tentative collision of the global-majorant trackers (common.glsl:342-359, 372-392): stays in ST_COLLIDE while the
+// ray is inside the box
+template <bool USE_TF, class Cold>
+VR_HD void do_collide_global(Hot& h, Cold& c, const SceneParams& P) {
+    const Uniforms& u = P.u;
+    const v3 ip = axpy(h.ipos, h.t, h.idir);
+    float d;
+    float rgba[4] = { 0, 0, 0, 0 };
+    if (USE_TF) {
+        tf_lookup(P, (u.vol_density_scale * density_trilinear_raw(P.density, ip)) * u.vol_inv_majorant, rgba);
+        d = u.vol_majorant * rgba[3];
+    } else {
+        int32_t tx, ty, tz;
+        tricubic_tap(ip, h.seed, tx, ty, tz);
+        d = u.vol_density_scale * brick_value(P.density, tx, ty, tz);
+    }
+    if (!h.shadow) {
+        const float P_real = d * u.vol_inv_majorant;
+        if (u.has_emission) {
+            const v3 ie = mat4_point(P.emission_from_density, ip);
+            int32_t ex, ey, ez;
+            tricubic_tap(ie, h.seed, ex, ey, ez);
+            const float tt = brick_value(P.emission, ex, ey, ez) * u.vol_emission_norm;
+            const v3 e3 = v3{ tt, sqr(tt), sqr(sqr(tt)) };
+            const v3 em = v3{ u.vol_emission_scale * sqr(e3.x), u.vol_emission_scale * sqr(e3.y), u.vol_emission_scale * sqr(e3.z) };
+            const v3 oma = v3{ 1.0f - u.vol_albedo[0], 1.0f - u.vol_albedo[1], 1.0f - u.vol_albedo[2] };
+            st3(c, C_L, ld3(c, C_L) + ((ld3(c, C_THR) * oma) * em) * P_real);
+        } else {
+            rng_skip9(h.seed);
+        }
+        if (rng(h.seed) < P_real) {
+            v3 thr = ld3(c, C_THR);
+            if (USE_TF) thr = thr * v3{ rgba[0] * u.vol_albedo[0], rgba[1] * u.vol_albedo[1], rgba[2] * u.vol_albedo[2] };
+            else thr = thr * v3{ u.vol_albedo[0], u.vol_albedo[1], u.vol_albedo[2] };
+            st3(c, C_THR, thr);
+            h.state = ST_NEE;
+            return;
+        }
+    } else {
+        h.Tr *= 1.0f - d * u.vol_inv_majorant;
+        if (h.Tr < 0.1f) {
+            const float prob = 1.0f - h.Tr;
+            if (rng(h.seed) < prob) { h.Tr = 0.0f; h.state = ST_POSTNEE; return; }
+            h.Tr /= 1.0f - prob;
+        }
+    }
+    h.t = h.t + neg_log_1m(rng(h.seed)) * u.vol_inv_majorant;
+    if (!(h.t < h.far)) h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE;
+}
+
 // real collision: common.glsl:611-626 up to (and including the set-up of) the transmittance call
 template <class Cold>
 VR_HD void do_nee(Hot& h, Cold& c, const SceneParams& P) {
@@ -525,7 +585,7 @@ VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, 
         do_new(h, c, P, wu, next_item++);
         break;
     case ST_MARCH: do_march(h, P); break;
-    case ST_COLLIDE: do_collide<USE_TF>(h, c, P); break;
+    case ST_COLLIDE: if (P.u.integrator != 0) do_collide_global<USE_TF>(h, c, P); else do_collide<USE_TF>(h, c, P); break;
     case ST_NEE: do_nee(h, c, P); break;
     case ST_POSTNEE: do_postnee(h, c, P, wu); break;
     case ST_ESCAPE: do_escape(h, c, P, wu); break;
