@@ -120,6 +120,9 @@ int vr_set_sched(const int32_t thresholds[8]);
 int vr_sched_stats(int enable, unsigned long long* out);
 /* unit-test probe of the device math (volren_amd/csrc/vr_math.h): host arrays in/out */
 int vr_math_probe(int fn, const float* a, const float* b, float* out, int n);
+/* voldata::Volume::to_brick_grid + BrickGrid serialisation: encode a dense float grid (x fastest) and write it as a .brick
+ * container (SURVEY.md 2.3 layout); transform may be NULL (identity).  Host only, needs no device. */
+int vr_write_brick_from_dense(const float* voxels, int nx, int ny, int nz, const float* transform, const char* path);
 /* host-side helpers exposed for tests: dense->brick encoder statistics */
 int vr_encode_dense_stats(const float* voxels, int nx, int ny, int nz, uint32_t n_bricks_out[3], uint64_t* brick_counter, float min_maj_out[2]);
 

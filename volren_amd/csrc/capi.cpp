@@ -418,6 +418,15 @@ int vr_math_probe(int fn, const float* a, const float* b, float* out, int n) {
     });
 }
 
+int vr_write_brick_from_dense(const float* voxels, int nx, int ny, int nz, const float* transform, const char* path) {
+    if (!voxels || !path || nx <= 0 || ny <= 0 || nz <= 0) return fail(VR_ERR_ARG, "bad arguments");
+    return guard([&] {
+        auto d = std::make_shared<vr::DenseGrid>((uint32_t)nx, (uint32_t)ny, (uint32_t)nz, voxels);
+        if (transform) memcpy(d->transform.m, transform, 64);
+        vr::Volume::to_brick_grid(d)->write(path);
+    });
+}
+
 int vr_encode_dense_stats(const float* voxels, int nx, int ny, int nz, uint32_t nb[3], uint64_t* counter, float mm[2]) {
     if (!voxels || !nb || !counter || !mm) return fail(VR_ERR_ARG, "null argument");
     return guard([&] {

@@ -153,16 +153,19 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     } while (0)
 
 // route the batch paths to the stack of their new state; an impossible state is reported and the slot recycled
-#define VR_ROUTE(BS) do { \
+#define VR_ROUTE_ST(BS, STV) do { \
         const bool v_ = (BS) >= 0; \
-        VR_PUSH(Q_READY, cnt_ready, v_ && (l.state == ST_MARCH || l.state == ST_COLLIDE), BS); \
-        VR_PUSH(Q_NEE, cnt_nee, v_ && l.state == ST_NEE, BS); \
-        VR_PUSH(Q_POST, cnt_post, v_ && l.state == ST_POSTNEE, BS); \
-        VR_PUSH(Q_ESC, cnt_esc, v_ && l.state == ST_ESCAPE, BS); \
-        const bool lost_ = v_ && (l.state < ST_NEW || l.state > ST_ESCAPE || l.state == ST_BEGIN); \
+        const int32_t s_ = (STV); \
+        VR_PUSH(Q_READY, cnt_ready, v_ && (s_ == ST_MARCH || s_ == ST_COLLIDE), BS); \
+        VR_PUSH(Q_NEE, cnt_nee, v_ && s_ == ST_NEE, BS); \
+        VR_PUSH(Q_POST, cnt_post, v_ && s_ == ST_POSTNEE, BS); \
+        VR_PUSH(Q_ESC, cnt_esc, v_ && s_ == ST_ESCAPE, BS); \
+        const bool lost_ = v_ && (s_ < ST_NEW || s_ > ST_ESCAPE || s_ == ST_BEGIN); \
         if (__ballot(lost_)) { if (lost_) atomicOr(status, 2u); } \
-        VR_PUSH(Q_FREE, cnt_free, v_ && (l.state == ST_NEW || lost_), BS); \
+        VR_PUSH(Q_FREE, cnt_free, v_ && (s_ == ST_NEW || lost_), BS); \
     } while (0)
+#define VR_ROUTE(BS) VR_ROUTE_ST(BS, l.state)
+#define VR_ROUTE_B(BS) VR_ROUTE_ST(BS, b.state)
 
     for (;;) {
         // watchdog: a wavefront's share of a launch is tens of milliseconds; give up (and report) after S.max_iters
@@ -226,22 +229,20 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
         const bool want_post = cnt_post > 0 && (cnt_post >= S.thr[ST_POSTNEE] || (hungry && cnt_post == big));
         const bool want_esc = cnt_esc > 0 && (cnt_esc >= S.thr[ST_ESCAPE] || (hungry && cnt_esc == big));
         if (want_new || want_nee || want_post || want_esc) {
-            // the lanes double as batch workers: save the marching paths' registers
-            const int32_t my_slot = slot;
-            if (my_slot >= 0) hs.save(l, my_slot);
-            __builtin_amdgcn_wave_barrier();
+            // the lanes double as batch workers; the batch path lives in its own register set `b`, the marching path `l` stays put
+            Hot b;
             if (want_esc) {
                 n = min(64, cnt_esc);
                 VR_STAT(ST_ESCAPE, n);
                 int32_t bs = -1;
                 if (lane < n) {
                     bs = q[Q_ESC * NSLOT + cnt_esc - 1 - lane];
-                    hs.load(l, bs);
+                    hs.load(b, bs);
                     ColdGlobal c{ cold_base + bs };
-                    do_escape(l, c, P, wu);                              // writes the sample; the slot becomes free
+                    do_escape(b, c, P, wu);                              // writes the sample; the slot becomes free
                 }
                 cnt_esc -= n;
-                VR_ROUTE(bs);                                            // ST_NEW: the slot is free again
+                VR_ROUTE_B(bs);                                            // ST_NEW: the slot is free again
                 VR_STAT_END(ST_ESCAPE);
             }
             if (want_post) {
@@ -250,13 +251,13 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                 int32_t bs = -1;
                 if (lane < n) {
                     bs = q[Q_POST * NSLOT + cnt_post - 1 - lane];
-                    hs.load(l, bs);
+                    hs.load(b, bs);
                     ColdGlobal c{ cold_base + bs };
-                    do_postnee(l, c, P, wu);
-                    hs.save(l, bs);
+                    do_postnee(b, c, P, wu);
+                    hs.save(b, bs);
                 }
                 cnt_post -= n;
-                VR_ROUTE(bs);                                            // ST_NEW = path ended (bounce cap / roulette)
+                VR_ROUTE_B(bs);                                            // ST_NEW = path ended (bounce cap / roulette)
                 VR_STAT_END(ST_POSTNEE);
             }
             if (want_new) {
@@ -273,14 +274,14 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                     int32_t bs = -1;
                     if (lane < n) {
                         bs = q[Q_FREE * NSLOT + cnt_free - 1 - lane];
-                        hot_init(l);
+                        hot_init(b);
                         ColdGlobal c{ cold_base + bs };
-                        do_new(l, c, P, wu, cursor + (uint32_t)lane);
-                        hs.save(l, bs);
+                        do_new(b, c, P, wu, cursor + (uint32_t)lane);
+                        hs.save(b, bs);
                     }
                     cnt_free -= n;
                     cursor += (uint32_t)n;
-                    VR_ROUTE(bs);                                        // ST_NEW = pixel outside a ragged frame
+                    VR_ROUTE_B(bs);                                        // ST_NEW = pixel outside a ragged frame
                     VR_STAT_END(ST_NEW);
                 }
             }
@@ -290,18 +291,15 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                 int32_t bs = -1;
                 if (lane < n) {
                     bs = q[Q_NEE * NSLOT + cnt_nee - 1 - lane];
-                    hs.load(l, bs);
+                    hs.load(b, bs);
                     ColdGlobal c{ cold_base + bs };
-                    do_nee(l, c, P);
-                    hs.save(l, bs);
+                    do_nee(b, c, P);
+                    hs.save(b, bs);
                 }
                 cnt_nee -= n;
-                VR_ROUTE(bs);
+                VR_ROUTE_B(bs);
                 VR_STAT_END(ST_NEE);
             }
-            __builtin_amdgcn_wave_barrier();
-            slot = my_slot;
-            if (my_slot >= 0) hs.load(l, my_slot);
         }
         if (exhausted && cnt_free == NSLOT) break;                        // every path of the pool has finished
     }
@@ -318,6 +316,8 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
 #undef VR_STAT_END
 #undef VR_PUSH
 #undef VR_ROUTE
+#undef VR_ROUTE_B
+#undef VR_ROUTE_ST
 }
 
 // Running mean over the samples of one launch, in sample order (pathtracer_brick.glsl:36): one thread per pixel.
