@@ -56,6 +56,9 @@ int vr_load_transferfunc(vr_renderer* r, const char* path);        /* "%f, %f, %
  *     transform: grid index->model, 16 floats column-major (NULL = identity).  name: "density" | "temperature" | "flame" | "flames".
  *     unit_cube != 0 applies load_volume's density_scale=1 + scale_and_move_to_unit_cube().  Follow with vr_commit(). */
 int vr_set_volume_dense(vr_renderer* r, const char* name, const float* voxels, int nx, int ny, int nz, const float* transform, int unit_cube);
+/* dense fp16 grid that STAYS dense on the device (no brick conversion; north_star "dense fp16 grid"): voxels are IEEE
+ * binary16, x fastest.  No reference counterpart (the reference bricks every grid in commit(), src/renderer.cpp:63). */
+int vr_set_volume_dense_f16(vr_renderer* r, const char* name, const uint16_t* voxels, int nx, int ny, int nz, const float* transform, int unit_cube);
 /* voldata::BrickGrid fields as stored in a .brick file; mips may be NULL/0 */
 int vr_set_volume_brick(vr_renderer* r, const char* name, const float* transform, const uint32_t n_bricks[3], const float min_maj[2],
                         const uint32_t* indirection, const uint32_t* range, const uint32_t atlas_dim[3], const uint8_t* atlas,

@@ -29,7 +29,8 @@ class BrickGrid(C.Structure):
     _fields_ = [("transform", c_f * 16), ("n_bricks", c_u * 3), ("min_maj", c_f * 2),
                 ("brick_counter", C.c_uint64), ("indirection", P_u32), ("range", P_u32),
                 ("atlas_dim", c_u * 3), ("atlas", P_u8), ("n_mips", c_u),
-                ("mip_dim", (c_u * 3) * 8), ("mips", P_u32 * 8)]
+                ("mip_dim", (c_u * 3) * 8), ("mips", P_u32 * 8),
+                ("extent", c_u * 3), ("dense", C.POINTER(C.c_uint16))]
 
 
 class Params(C.Structure):
@@ -164,8 +165,12 @@ class Grid:
         lib().orc_free_brick(C.byref(raw))
         return g
 
-    def set(self, transform, n_bricks, min_maj, brick_counter, indirection, rng, atlas_dim, atlas, mips):
+    def set(self, transform, n_bricks, min_maj, brick_counter, indirection, rng, atlas_dim, atlas, mips, extent=None, dense=None):
         c = self.c
+        self.extent = tuple(int(v) for v in extent) if extent is not None else None
+        self.dense = np.ascontiguousarray(dense, np.float16) if dense is not None else None
+        c.extent[:] = self.extent if self.extent is not None else (0, 0, 0)
+        c.dense = self.dense.view(np.uint16).ctypes.data_as(C.POINTER(C.c_uint16)) if self.dense is not None else None
         self.transform = _f32(transform).reshape(16)
         self.n_bricks = tuple(int(v) for v in n_bricks)
         self.min_maj = (float(min_maj[0]), float(min_maj[1]))
@@ -190,7 +195,7 @@ class Grid:
 
     @property
     def index_extent(self):
-        return tuple(8 * v for v in self.n_bricks)
+        return self.extent if getattr(self, "extent", None) else tuple(8 * v for v in self.n_bricks)
 
     def decode_dense(self):
         """Dense float grid [z][y][x] of the decoded voxels (common.glsl:268-275), numpy."""

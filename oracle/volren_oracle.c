@@ -285,8 +285,16 @@ static void stochastic_tricubic_filter(v3 ipos, uint32_t* seed, int out[3]) {
 
 /* ------------------------------------------------------------------ */
 /* brick grid lookups  ref: common.glsl:268-281; out-of-range texelFetch (GL: undefined) reads 0 */
+static inline void grid_extent(const orc_brickgrid* g, uint32_t e[3]) {
+    for (int k = 0; k < 3; ++k) e[k] = g->extent[k] ? g->extent[k] : g->n_bricks[k] * 8u;
+}
+
 float orc_lookup_density_brick(const orc_brickgrid* g, int32_t x, int32_t y, int32_t z) {
     if (x < 0 || y < 0 || z < 0) return 0.0f;
+    if (g->dense) {             /* dense fp16 grid: the voxel itself, 0 outside */
+        if ((uint32_t)x >= g->extent[0] || (uint32_t)y >= g->extent[1] || (uint32_t)z >= g->extent[2]) return 0.0f;
+        return om_half2float(g->dense[((size_t)z * g->extent[1] + (size_t)y) * g->extent[0] + (size_t)x]);
+    }
     const uint32_t bx = (uint32_t)x >> 3, by = (uint32_t)y >> 3, bz = (uint32_t)z >> 3;
     if (bx >= g->n_bricks[0] || by >= g->n_bricks[1] || bz >= g->n_bricks[2]) return 0.0f;
     const size_t bi = ((size_t)bz * g->n_bricks[1] + by) * g->n_bricks[0] + bx;
@@ -796,7 +804,8 @@ void orc_mat4_inverse(const float m[16], float out[16]) {
 /* ref: renderer.cpp:227-242; index_extent = n_bricks * 8 for a loaded BrickGrid */
 void orc_unit_cube(const orc_brickgrid* g, float vt[16], float* density_scale) {
     const float* T = g->transform;
-    const v3 ext_i = V3((float)(g->n_bricks[0] * 8), (float)(g->n_bricks[1] * 8), (float)(g->n_bricks[2] * 8));
+    uint32_t ge[3]; grid_extent(g, ge);
+    const v3 ext_i = V3((float)ge[0], (float)ge[1], (float)ge[2]);
     const v3 c0 = mat4point(T, V3(0, 0, 0)), c1 = mat4point(T, ext_i);
     /* bb_min = min(FLT_MAX, c0); bb_max = max(FLT_MIN, c1) (reference quirk: FLT_MIN is the smallest positive float) */
     const v3 bb_min = V3(om_min(3.402823466e+38f, c0.x), om_min(3.402823466e+38f, c0.y), om_min(3.402823466e+38f, c0.z));
@@ -842,7 +851,8 @@ void orc_volume_uniforms(orc_params* p, const orc_brickgrid* density, const orc_
     /* volume->AABB(): world-space box of the grid (voldata, unvendored): corners of [0, index_extent] through volume.transform * grid.transform */
     float M[16];
     orc_mat4_mul(vt, density->transform, M);
-    const v3 ext_i = V3((float)(density->n_bricks[0] * 8), (float)(density->n_bricks[1] * 8), (float)(density->n_bricks[2] * 8));
+    uint32_t ge[3]; grid_extent(density, ge);
+    const v3 ext_i = V3((float)ge[0], (float)ge[1], (float)ge[2]);
     v3 lo = V3(INFINITY, INFINITY, INFINITY), hi = V3(-INFINITY, -INFINITY, -INFINITY);
     for (int k = 0; k < 8; ++k) {
         const v3 cn = mat4point(M, V3((k & 1) ? ext_i.x : 0.0f, (k & 2) ? ext_i.y : 0.0f, (k & 4) ? ext_i.z : 0.0f));

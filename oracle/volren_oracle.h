@@ -41,6 +41,10 @@ typedef struct {
     uint32_t n_mips;
     uint32_t mip_dim[8][3];
     uint32_t* mips[8];          /* range mip levels 1..n_mips */
+    /* build-only extension (no reference counterpart): dense fp16 voxels [z][y][x] instead of indirection+atlas
+     * (north_star "dense fp16 grid"); extent = voxel dimensions (0 -> n_bricks*8 as for a loaded BrickGrid) */
+    uint32_t extent[3];
+    const uint16_t* dense;
 } orc_brickgrid;
 
 /* the uniform block RendererOpenGL::trace uploads (src/renderer.cpp:88-138) */

@@ -77,3 +77,50 @@ def encode(dense_zyx, transform=None):
     g.set(a["transform"], a["n_bricks"], a["min_maj"], a["brick_counter"], a["indirection"], a["rng"],
           a["atlas_dim"], a["atlas"], a["mips"])
     return g
+
+
+def dense_fp16_arrays(dense_zyx, transform=None):
+    """Dense fp16 grid + macro-cell ranges (8^3 cells dilated by 2 voxels, 3 min/max mips) -- same rules as
+    vr::DenseGridF16 in volren_amd/csrc/grids.cpp.  Cells: ceil(dim / 8) per axis (no rounding up to 8 cells)."""
+    h = np.ascontiguousarray(dense_zyx, np.float16)
+    d = h.astype(np.float32)
+    nz, ny, nx = d.shape
+    nbx, nby, nbz = (nx + 7) // 8, (ny + 7) // 8, (nz + 7) // 8
+    pad = np.zeros((nbz * 8 + 4, nby * 8 + 4, nbx * 8 + 4), np.float32)
+    pad[2:2 + nz, 2:2 + ny, 2:2 + nx] = d
+    lo = np.zeros((nbz, nby, nbx), np.float32)
+    hi = np.zeros((nbz, nby, nbx), np.float32)
+    for bz in range(nbz):
+        for by in range(nby):
+            blk = pad[bz * 8:bz * 8 + 12, by * 8:by * 8 + 12]
+            for bx in range(nbx):
+                b = blk[:, :, bx * 8:bx * 8 + 12]
+                lo[bz, by, bx], hi[bz, by, bx] = b.min(), b.max()
+    word = lambda l, u: l.astype(np.float16).view(np.uint16).astype(np.uint32) | (u.astype(np.float16).view(np.uint16).astype(np.uint32) << 16)
+    rng = word(lo, hi)
+    mips = []
+    cur_lo, cur_hi = lo, hi
+    for _ in range(3):
+        z, y, x = cur_lo.shape
+        z2, y2, x2 = (z + 1) // 2, (y + 1) // 2, (x + 1) // 2
+        plo = np.full((z2 * 2, y2 * 2, x2 * 2), np.inf, np.float32)
+        phi = np.full((z2 * 2, y2 * 2, x2 * 2), -np.inf, np.float32)
+        plo[:z, :y, :x] = cur_lo
+        phi[:z, :y, :x] = cur_hi
+        cur_lo = plo.reshape(z2, 2, y2, 2, x2, 2).min((1, 3, 5))
+        cur_hi = phi.reshape(z2, 2, y2, 2, x2, 2).max((1, 3, 5))
+        mips.append(((x2, y2, z2), word(cur_lo, cur_hi).reshape(-1)))
+    t = np.eye(4, dtype=np.float32).reshape(16) if transform is None else np.asarray(transform, np.float32).reshape(16)
+    return dict(transform=t, n_bricks=(nbx, nby, nbz), min_maj=(float(d.min()), float(d.max())), rng=rng.reshape(-1), mips=mips,
+                extent=(nx, ny, nz), dense=h)
+
+
+def encode_dense_fp16(dense_zyx, transform=None):
+    """-> oracle.binding.Grid holding the dense fp16 voxels."""
+    from oracle import binding as ob
+    a = dense_fp16_arrays(dense_zyx, transform)
+    g = ob.Grid()
+    n = int(np.prod(a["n_bricks"]))
+    g.set(a["transform"], a["n_bricks"], a["min_maj"], 0, np.zeros(n, np.uint32), a["rng"], (8, 8, 8), np.zeros(512, np.uint8),
+          a["mips"], extent=a["extent"], dense=a["dense"])
+    return g

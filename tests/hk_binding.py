@@ -27,7 +27,8 @@ def build(sanitize=False):
 
 class GridDesc(C.Structure):
     _fields_ = [("nb", C.c_uint32 * 3), ("atlas_dim", C.c_uint32 * 3), ("n_mips", C.c_int32),
-                ("indirection", C.c_void_p), ("range", C.c_void_p), ("atlas", C.c_void_p), ("mips", C.c_void_p * 3)]
+                ("indirection", C.c_void_p), ("range", C.c_void_p), ("atlas", C.c_void_p), ("mips", C.c_void_p * 3),
+                ("dense", C.c_void_p), ("dim", C.c_uint32 * 3)]
 
 
 def grid_desc(g):
@@ -40,6 +41,9 @@ def grid_desc(g):
     d.atlas = g.atlas.ctypes.data
     for i, (_, a) in enumerate(g.mips):
         d.mips[i] = a.ctypes.data
+    if getattr(g, "dense", None) is not None:
+        d.dense = g.dense.ctypes.data
+        d.dim[:] = g.extent
     return d
 
 

@@ -67,6 +67,7 @@ extern "C" {
 struct hk_grid_desc {
     uint32_t nb[3]; uint32_t atlas_dim[3]; int32_t n_mips;
     const uint32_t* indirection; const uint32_t* range; const uint8_t* atlas; const uint32_t* mips[3];
+    const uint16_t* dense; uint32_t dim[3];
 };
 
 int hk_uniforms_size() { return (int)sizeof(Uniforms); }
@@ -81,6 +82,8 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
     HostGrid dg, eg;
     build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true);
     P.density = dg.view;
+    P.density.dense = density->dense;
+    for (int i = 0; i < 3; ++i) P.density.dim[i] = (int32_t)density->dim[i];
     if (emission && u.has_emission) {
         build_grid(eg, u, lut, emission->nb, emission->indirection, emission->range, emission->atlas_dim, emission->atlas, emission->n_mips, emission->mips, false);
         P.emission = eg.view;

@@ -75,6 +75,21 @@ def test_emission_grid():
     assert _same(got, want)
 
 
+def test_dense_fp16_grid():
+    """Dense fp16 voxels + macro-cell majorants (no brick indirection): product device code vs oracle."""
+    import encoder_ref
+    dens = scenes.synthetic_density(44)[:40, :36, :44].copy()
+    o = ob.OracleRenderer(32, 32)
+    o.load_envmap(scenes.HDR)
+    o.set_volume(encoder_ref.encode_dense_fp16(dens))
+    o.cam_fov = 40.0
+    o.bounces = 8
+    want = o.render(8).copy()
+    got, _ = hk.render(o, 8)
+    assert want[..., 3].max() > 0
+    assert _same(got, want)
+
+
 def test_degenerate_inputs_do_not_diverge():
     """Zero-majorant volume (all-empty grid) and a camera inside the volume: both sides must agree, no hangs."""
     import encoder_ref

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvolren_amd.so")
 # every symbol include/volren_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "vr_last_error", "vr_version", "vr_device_count", "vr_create", "vr_destroy", "vr_resize",
-    "vr_load_volume", "vr_load_envmap", "vr_load_transferfunc", "vr_set_volume_dense", "vr_set_volume_brick",
+    "vr_load_volume", "vr_load_envmap", "vr_load_transferfunc", "vr_set_volume_dense", "vr_set_volume_dense_f16", "vr_set_volume_brick",
     "vr_set_envmap", "vr_set_transferfunc", "vr_set_int", "vr_get_int", "vr_set_float", "vr_get_float",
     "vr_commit", "vr_reset", "vr_scale_and_move_to_unit_cube", "vr_trace", "vr_render", "vr_synchronize",
     "vr_last_kernel_ms", "vr_framebuffer", "vr_framebuffer_device", "vr_draw", "vr_display", "vr_save_png",
@@ -52,6 +52,7 @@ def load():
     for n in ("vr_load_volume", "vr_load_envmap", "vr_load_transferfunc", "vr_save_png"):
         getattr(L, n).argtypes = [vp, C.c_char_p]
     L.vr_set_volume_dense.argtypes = [vp, C.c_char_p, vp, ci, ci, ci, vp, ci]
+    L.vr_set_volume_dense_f16.argtypes = [vp, C.c_char_p, vp, ci, ci, ci, vp, ci]
     L.vr_set_volume_brick.argtypes = [vp, C.c_char_p, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci]
     L.vr_set_envmap.argtypes = [vp, vp, ci, ci]
     L.vr_set_transferfunc.argtypes = [vp, vp, ci]

@@ -138,6 +138,17 @@ int vr_set_volume_dense(vr_renderer* r, const char* name, const float* voxels, i
     });
 }
 
+int vr_set_volume_dense_f16(vr_renderer* r, const char* name, const uint16_t* voxels, int nx, int ny, int nz, const float* transform, int unit_cube) {
+    NEED(r);
+    if (!voxels || nx <= 0 || ny <= 0 || nz <= 0) return fail(VR_ERR_ARG, "bad dense grid arguments");
+    return guard([&] {
+        use_device(r);
+        auto g = std::make_shared<vr::DenseGridF16>((uint32_t)nx, (uint32_t)ny, (uint32_t)nz, voxels);
+        if (transform) memcpy(g->transform.m, transform, 64);
+        install_grid(r, name, g, unit_cube);
+    });
+}
+
 int vr_set_volume_brick(vr_renderer* r, const char* name, const float* transform, const uint32_t nb[3], const float min_maj[2],
                         const uint32_t* indirection, const uint32_t* range, const uint32_t atlas_dim[3], const uint8_t* atlas,
                         int n_mips, const uint32_t* const* mips, const uint32_t (*mip_dims)[3], int unit_cube) {

@@ -58,6 +58,62 @@ DenseGrid::DenseGrid(uint32_t w, uint32_t h, uint32_t d, const float* data) : di
     min_maj = { lo, hi };
 }
 
+// (min of mins, max of maxes) over 2x2x2 children, halves kept as the children's own fp16 words
+static void build_range_mips(const Buf3D<uint32_t>& base, std::vector<Buf3D<uint32_t>>& mips) {
+    mips.clear();
+    mips.reserve(3);
+    const Buf3D<uint32_t>* src = &base;
+    for (int m = 0; m < 3; ++m) {
+        const uvec3 s = src->stride;
+        Buf3D<uint32_t> dst((s.x + 1) / 2, (s.y + 1) / 2, (s.z + 1) / 2);
+        for (uint32_t z = 0; z < dst.stride.z; ++z)
+            for (uint32_t y = 0; y < dst.stride.y; ++y)
+                for (uint32_t x = 0; x < dst.stride.x; ++x) {
+                    float lo = INFINITY, hi = -INFINITY; uint16_t hlo = 0, hhi = 0;
+                    for (uint32_t c = 0; c < 8; ++c) {
+                        const uint32_t cx = 2 * x + (c & 1), cy = 2 * y + ((c >> 1) & 1), cz = 2 * z + (c >> 2);
+                        if (cx >= s.x || cy >= s.y || cz >= s.z) continue;
+                        const uint32_t rg = (*src)(cx, cy, cz);
+                        const float l = half2float(rg & 0xFFFFu), h = half2float(rg >> 16);
+                        if (l < lo) { lo = l; hlo = (uint16_t)(rg & 0xFFFFu); }
+                        if (h > hi) { hi = h; hhi = (uint16_t)(rg >> 16); }
+                    }
+                    dst(x, y, z) = (uint32_t)hlo | ((uint32_t)hhi << 16);
+                }
+        mips.push_back(std::move(dst));
+        src = &mips.back();
+    }
+}
+
+DenseGridF16::DenseGridF16(uint32_t w, uint32_t h, uint32_t d, const uint16_t* data) : dim{ w, h, d }, voxels(data, data + (size_t)w * h * d) {
+    if (voxels.empty()) throw std::runtime_error("DenseGridF16: empty grid");
+    const uint32_t nbx = (w + 7) / 8, nby = (h + 7) / 8, nbz = (d + 7) / 8;
+    range = Buf3D<uint32_t>(nbx, nby, nbz);
+    // separable dilated min/max would be faster; the direct form is the specification
+    std::vector<float> f(voxels.size());
+    float gmin = INFINITY, gmax = -INFINITY;
+    for (size_t i = 0; i < voxels.size(); ++i) { f[i] = half2float(voxels[i]); gmin = std::min(gmin, f[i]); gmax = std::max(gmax, f[i]); }
+    min_maj = { gmin, gmax };
+    auto at = [&](int64_t x, int64_t y, int64_t z) -> float {
+        if (x < 0 || y < 0 || z < 0 || x >= w || y >= h || z >= d) return 0.f;
+        return f[((size_t)z * h + y) * w + x];
+    };
+    for (uint32_t bz = 0; bz < nbz; ++bz)
+        for (uint32_t by = 0; by < nby; ++by)
+            for (uint32_t bx = 0; bx < nbx; ++bx) {
+                float lo = INFINITY, hi = -INFINITY;
+                const int64_t x0 = (int64_t)bx * 8 - 2, y0 = (int64_t)by * 8 - 2, z0 = (int64_t)bz * 8 - 2;
+                for (int64_t z = z0; z < z0 + 12; ++z)
+                    for (int64_t y = y0; y < y0 + 12; ++y)
+                        for (int64_t x = x0; x < x0 + 12; ++x) {
+                            const float v = at(x, y, z);
+                            lo = std::min(lo, v); hi = std::max(hi, v);
+                        }
+                range(bx, by, bz) = (uint32_t)float_to_half_round_down(lo) | ((uint32_t)float_to_half_round_up(hi) << 16);
+            }
+    build_range_mips(range, range_mipmaps);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // .brick container (little endian, leading endianness byte): SURVEY.md 2.3
 namespace {
@@ -201,8 +257,15 @@ std::string Volume::to_string(const std::string& indent) const {
 //   * mips = (min of mins, max of maxes) over 2x2x2 children, min_maj = (min of mins, max of maxes).
 std::shared_ptr<BrickGrid> Volume::to_brick_grid(const GridPtr& grid) {
     if (auto b = std::dynamic_pointer_cast<BrickGrid>(grid)) return b;
-    const auto dense = std::dynamic_pointer_cast<DenseGrid>(grid);
-    if (!dense) throw std::runtime_error("to_brick_grid: unsupported grid type");
+    auto dense = std::dynamic_pointer_cast<DenseGrid>(grid);
+    if (!dense) {
+        const auto f16 = std::dynamic_pointer_cast<DenseGridF16>(grid);
+        if (!f16) throw std::runtime_error("to_brick_grid: unsupported grid type");
+        std::vector<float> f(f16->voxels.size());
+        for (size_t i = 0; i < f.size(); ++i) f[i] = half2float(f16->voxels[i]);
+        dense = std::make_shared<DenseGrid>(f16->dim.x, f16->dim.y, f16->dim.z, f.data());
+        dense->transform = f16->transform;
+    }
     const uvec3 dim = dense->dim;
     auto up8 = [](uint32_t v) { return ((v + 7u) / 8u + 7u) / 8u * 8u; };
     auto out = std::make_shared<BrickGrid>();

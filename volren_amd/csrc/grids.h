@@ -44,6 +44,21 @@ struct DenseGrid : Grid {
     float lookup(uint32_t x, uint32_t y, uint32_t z) const override { return voxels[((size_t)z * dim.y + y) * dim.x + x]; }
 };
 
+// Dense fp16 grid (north_star: "dense fp16 grid ... lives in HBM3E"): voxels stay dense, x fastest; the DDA still needs
+// local majorants, so 8^3 macro cells (dilated by 2 voxels for the tricubic taps) and their 3 min/max mips are derived
+// on construction.  No reference counterpart: the reference turns every grid into a BrickGrid at commit().
+struct DenseGridF16 : Grid {
+    uvec3 dim;
+    std::vector<uint16_t> voxels;                // IEEE binary16
+    std::pair<float, float> min_maj{ 0.f, 0.f };
+    Buf3D<uint32_t> range;                       // per 8^3 cell: 2 x fp16 (min, max), ceil(dim / 8) cells per axis
+    std::vector<Buf3D<uint32_t>> range_mipmaps;
+    DenseGridF16(uint32_t w, uint32_t h, uint32_t d, const uint16_t* data);
+    uvec3 index_extent() const override { return dim; }
+    std::pair<float, float> minorant_majorant() const override { return min_maj; }
+    float lookup(uint32_t x, uint32_t y, uint32_t z) const override { return half2float(voxels[((size_t)z * dim.y + y) * dim.x + x]); }
+};
+
 // voldata::BrickGrid, fields as in the .brick file
 struct BrickGrid : Grid {
     uvec3 n_bricks;

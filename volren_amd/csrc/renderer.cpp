@@ -66,17 +66,53 @@ void RendererHIP::commit() {
     std::cout << "Preparing brick grids for HIP..." << std::endl;
     for (const auto& frame : volume->grids) {
         Volume::GridPtr density_grid = frame.at("density");       // throws std::out_of_range like the reference
-        density_grids.push_back(brick_grid_to_device(Volume::to_brick_grid(density_grid)));
+        density_grids.push_back(grid_to_device(density_grid));
         Volume::GridPtr emission_grid;
         for (const char* name : { "flame", "flames", "temperature" }) {
             auto it = frame.find(name);
             if (it != frame.end()) { emission_grid = it->second; break; }
         }
         if (emission_grid) {
-            emission_grids.push_back(brick_grid_to_device(Volume::to_brick_grid(emission_grid)));
+            emission_grids.push_back(grid_to_device(emission_grid));
             majorant_emission = std::max(majorant_emission, emission_grid->minorant_majorant().second);
         }
     }
+}
+
+BrickGridHIP RendererHIP::grid_to_device(const Volume::GridPtr& grid) {
+    if (auto f16 = std::dynamic_pointer_cast<DenseGridF16>(grid)) return dense_grid_to_device(f16);
+    return brick_grid_to_device(Volume::to_brick_grid(grid));
+}
+
+static void upload_range_words(BrickGridHIP& out, const uvec3 nb, const Buf3D<uint32_t>& range, const std::vector<Buf3D<uint32_t>>& mips) {
+    if (mips.size() > 3) throw std::runtime_error("grid upload: at most 3 range mips are supported");
+    std::vector<uint32_t> words(range.data);
+    out.n_mips = (int)mips.size();
+    for (int m = 0; m <= 3; ++m) out.mip_off[m] = 0;
+    for (int m = 1; m <= out.n_mips; ++m) {
+        const auto& mm = mips[m - 1];
+        const uint32_t rnd = (1u << m) - 1u;
+        if (mm.stride.x != ((nb.x + rnd) >> m) || mm.stride.y != ((nb.y + rnd) >> m) || mm.stride.z != ((nb.z + rnd) >> m))
+            throw std::runtime_error("grid upload: range mip dimensions are not ceil(n_bricks / 2^m)");
+        out.mip_off[m] = (int32_t)words.size();
+        words.insert(words.end(), mm.data.begin(), mm.data.end());
+    }
+    out.n_cells = (int32_t)words.size();
+    out.range_words = make_device_buffer(words.size() * sizeof(uint32_t));
+    out.range_words->upload(words.data(), words.size() * sizeof(uint32_t));
+    out.majorant = make_device_buffer(words.size() * sizeof(float));
+}
+
+BrickGridHIP RendererHIP::dense_grid_to_device(const std::shared_ptr<DenseGridF16>& g) {
+    BrickGridHIP out;
+    const uvec3 nb = g->range.stride;
+    out.nb[0] = (int)nb.x; out.nb[1] = (int)nb.y; out.nb[2] = (int)nb.z;
+    out.dim[0] = (int)g->dim.x; out.dim[1] = (int)g->dim.y; out.dim[2] = (int)g->dim.z;
+    out.transform = g->transform;
+    out.dense = make_device_buffer(g->voxels.size() * sizeof(uint16_t));
+    out.dense->upload(g->voxels.data(), g->voxels.size() * sizeof(uint16_t));
+    upload_range_words(out, nb, g->range, g->range_mipmaps);
+    return out;
 }
 
 BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>& g) {
@@ -84,7 +120,6 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
     const uvec3 nb = g->n_bricks;
     const size_t n_bricks = (size_t)nb.x * nb.y * nb.z;
     if (n_bricks == 0) throw std::runtime_error("brick_grid_to_device: empty grid");
-    if (g->range_mipmaps.size() > 3) throw std::runtime_error("brick_grid_to_device: at most 3 range mips are supported");
     out.nb[0] = (int)nb.x; out.nb[1] = (int)nb.y; out.nb[2] = (int)nb.z;
     out.transform = g->transform;
     // atlas: 3D texture of 8^3 blocks -> brick-major slots of 512 contiguous bytes, plus one all-zero slot that
@@ -114,27 +149,11 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
         r.range = rg;
         recs[i] = r;
     }
-    // range words of all mips, mip m has ceil(nb / 2^m) cells per axis
-    std::vector<uint32_t> words(g->range.data);
-    out.n_mips = (int)g->range_mipmaps.size();
-    out.mip_off[0] = 0;
-    for (int m = 1; m <= 3; ++m) out.mip_off[m] = 0;
-    for (int m = 1; m <= out.n_mips; ++m) {
-        const auto& mm = g->range_mipmaps[m - 1];
-        const uint32_t rnd = (1u << m) - 1u;
-        if (mm.stride.x != ((nb.x + rnd) >> m) || mm.stride.y != ((nb.y + rnd) >> m) || mm.stride.z != ((nb.z + rnd) >> m))
-            throw std::runtime_error("brick_grid_to_device: range mip dimensions are not ceil(n_bricks / 2^m)");
-        out.mip_off[m] = (int32_t)words.size();
-        words.insert(words.end(), mm.data.begin(), mm.data.end());
-    }
-    out.n_cells = (int32_t)words.size();
+    upload_range_words(out, nb, g->range, g->range_mipmaps);
     out.bricks = make_device_buffer(recs.size() * sizeof(BrickRec));
     out.bricks->upload(recs.data(), recs.size() * sizeof(BrickRec));
     out.atlas = make_device_buffer(atlas.size());
     out.atlas->upload(atlas.data(), atlas.size());
-    out.range_words = make_device_buffer(words.size() * sizeof(uint32_t));
-    out.range_words->upload(words.data(), words.size() * sizeof(uint32_t));
-    out.majorant = make_device_buffer(words.size() * sizeof(float));
     return out;
 }
 
@@ -160,8 +179,10 @@ static void copy3(float* dst, vec3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z
 
 static GridView make_view(const BrickGridHIP& g) {
     GridView v;
-    v.bricks = g.bricks->as<BrickRec>();
-    v.atlas = g.atlas->as<uint8_t>();
+    v.bricks = g.bricks ? g.bricks->as<BrickRec>() : nullptr;
+    v.atlas = g.atlas ? g.atlas->as<uint8_t>() : nullptr;
+    v.dense = g.dense ? g.dense->as<uint16_t>() : nullptr;
+    for (int i = 0; i < 3; ++i) v.dim[i] = g.dim[i];
     v.majorant = g.majorant->as<float>();
     for (int i = 0; i < 3; ++i) v.nb[i] = g.nb[i];
     for (int i = 0; i < 4; ++i) v.mip_off[i] = g.mip_off[i];

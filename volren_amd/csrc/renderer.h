@@ -35,6 +35,8 @@ struct BrickGridHIP {
     DeviceBufferPtr atlas;         // brick-major u8 voxels, 512 B per slot
     DeviceBufferPtr range_words;   // fp16x2 range of every cell of mips 0..n_mips (input of the majorant kernel)
     DeviceBufferPtr majorant;      // effective majorants (float), same indexing as range_words
+    DeviceBufferPtr dense;         // dense fp16 voxels (DenseGridF16), then bricks/atlas are empty
+    int32_t dim[3] = { 0, 0, 0 };
     int32_t nb[3] = { 0, 0, 0 };
     int32_t mip_off[4] = { 0, 0, 0, 0 };
     int32_t n_mips = 0;
@@ -56,6 +58,8 @@ struct RendererHIP {
 
     // helper to convert brick grid to device arrays
     BrickGridHIP brick_grid_to_device(const std::shared_ptr<BrickGrid>& grid);
+    BrickGridHIP dense_grid_to_device(const std::shared_ptr<DenseGridF16>& grid);
+    BrickGridHIP grid_to_device(const Volume::GridPtr& grid);      // dense fp16 stays dense, everything else becomes bricks
     // scale and move volume to fit into [-0.5, 0.5] unit cube
     void scale_and_move_to_unit_cube();
 

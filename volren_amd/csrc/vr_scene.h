@@ -21,6 +21,8 @@ struct GridView {
     int32_t nb[3];               // bricks per axis (mip 0); mip m has ceil(nb / 2^m) cells per axis
     int32_t mip_off[4];          // float offset of each mip level inside `majorant`
     int32_t n_mips;              // range mips available above level 0 (reference: 3)
+    const uint16_t* dense;       // dense fp16 voxels [z][y][x] (then bricks/atlas are unused), or nullptr
+    int32_t dim[3];              // voxel extent of the dense grid
 };
 
 struct Uniforms {                // names follow the GLSL uniforms

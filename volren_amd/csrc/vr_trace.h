@@ -94,6 +94,10 @@ VR_HD void rng_skip9(uint32_t& s) {
 // grids  (common.glsl:268-297); out-of-range fetches read 0 (GL: undefined)
 VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
     if ((x | y | z) < 0) return 0.0f;
+    if (g.dense) {          // dense fp16 grid: one 2-byte load, no indirection
+        if ((uint32_t)x >= (uint32_t)g.dim[0] || (uint32_t)y >= (uint32_t)g.dim[1] || (uint32_t)z >= (uint32_t)g.dim[2]) return 0.0f;
+        return half2float(g.dense[((size_t)z * (uint32_t)g.dim[1] + (uint32_t)y) * (uint32_t)g.dim[0] + (uint32_t)x]);
+    }
     const uint32_t bx = (uint32_t)x >> 3, by = (uint32_t)y >> 3, bz = (uint32_t)z >> 3;
     if (bx >= (uint32_t)g.nb[0] || by >= (uint32_t)g.nb[1] || bz >= (uint32_t)g.nb[2]) return 0.0f;
     const BrickRec rec = g.bricks[(bz * (uint32_t)g.nb[1] + by) * (uint32_t)g.nb[0] + bx];

@@ -82,6 +82,16 @@ class Renderer:
         if commit:
             self.commit()
 
+    def set_volume_dense_f16(self, voxels_zyx, transform=None, name="density", unit_cube=True, commit=True):
+        """Dense fp16 grid kept dense on the device (2 B/voxel, no brick indirection)."""
+        v = np.ascontiguousarray(voxels_zyx, dtype=np.float16)
+        nz, ny, nx = v.shape
+        t = _f32(transform).reshape(16) if transform is not None else None
+        _lib.check(self._L.vr_set_volume_dense_f16(self._h, name.encode(), v.ctypes.data, nx, ny, nz,
+                                                   t.ctypes.data if t is not None else None, 1 if unit_cube else 0))
+        if commit:
+            self.commit()
+
     def set_volume_brick(self, transform, n_bricks, min_maj, indirection, rng, atlas_dim, atlas, mips=(), name="density",
                          unit_cube=True, commit=True):
         t = _f32(transform).reshape(16)
