@@ -28,7 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes_per_sample(counters, spp, use_tf, has_emission):
+def algorithmic_bytes_per_sample(counters, spp, use_tf, has_emission, dense=False):
     """B = 4*N_dda + b_tap*T*N_coll + b_em*N_coll_sv + 200*N_nee + 48*N_esc + B_fb, with
     B_fb = 32 B: 16 B written to the per-sample radiance pool + 16 B read back by the ordered accumulate pass
     (the same 32 B the reference's per-dispatch image read-modify-write costs)."""
@@ -39,7 +39,8 @@ def algorithmic_bytes_per_sample(counters, spp, use_tf, has_emission):
     n_nee = counters["n_nee"] / n
     n_esc = counters["n_esc"] / n
     taps = 8 if use_tf else 1
-    b = 4.0 * n_dda + 9.0 * taps * n_coll + (9.0 if has_emission else 0.0) * n_coll_sv + 200.0 * n_nee + 48.0 * n_esc + 32.0
+    b_tap = 2.0 if dense else 9.0          # dense fp16 voxel vs brick tap (4 B indirection + 4 B range + 1 B atlas)
+    b = 4.0 * n_dda + b_tap * taps * n_coll + (9.0 if has_emission else 0.0) * n_coll_sv + 200.0 * n_nee + 48.0 * n_esc + 32.0
     return b, dict(N_dda=n_dda, N_coll=n_coll, N_coll_sv=n_coll_sv, N_nee=n_nee, N_esc=n_esc,
                    primary_miss=counters["n_primary_miss"] / n)
 
@@ -49,12 +50,12 @@ def cpu_baseline_and_counters(config, w, h, budget_s):
     box-missing and cloud pixels), spp chosen to fill ~budget_s seconds."""
     import scenes
     from oracle import binding as ob
-    cw = ch = 256
+    cw = ch = 512
     o = scenes.oracle_scene(config, cw, ch)
     t0 = time.time()
-    o.render(2)
-    rate = cw * ch * 2 / max(time.time() - t0, 1e-6)
-    spp = int(max(2, min(512, budget_s * rate / (cw * ch))))
+    o.render(1)
+    rate = cw * ch / max(time.time() - t0, 1e-6)
+    spp = int(max(1, min(4096, budget_s * rate / (cw * ch))))
     o2 = scenes.oracle_scene(config, cw, ch)
     t0 = time.time()
     o2.render(spp)
@@ -69,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "readme"])
+    ap.add_argument("--config", default="c2", help="c1 | c2 | c3 | readme | c4[:N] (synthetic N^3 dense fp16 grid, default 512)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=1024)
@@ -90,12 +91,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the renderer has no CPU path")
+    n_dev = torch.cuda.device_count()
+    if os.environ.get("VOLREN_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(1, n_dev)                # test mode: ranks may share a device
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL ("nccl") over xGMI is the real path; VOLREN_DIST_BACKEND=gloo exists only so that the multi-rank flow can be
+        # exercised on a box where several ranks have to share one GPU (the collective is then staged through the host)
+        backend = os.environ.get("VOLREN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     w, h, spp = args.width, args.height, args.spp
     r = scenes.hip_scene(args.config, w, h, device=local_rank)
@@ -114,13 +124,19 @@ def main():
         gathered = torch.empty(shard.gathered_floats, dtype=torch.float32, device="cuda")
 
     kernel_ms = []
+    staged = world > 1 and os.environ.get("VOLREN_DIST_BACKEND", "nccl") != "nccl"
 
     def step():
         r.reset()
         r.render(spp, sync=False)                                           # ONE fused launch: all spp of all owned tiles
         if world > 1:
             r.pack_tiles(tiles_dev.data_ptr(), shard.n_max, packed.data_ptr())
-            shard.all_gather(dist, gathered, packed)                        # RCCL over xGMI, once per frame
+            if staged:
+                hg = torch.empty(gathered.shape, dtype=gathered.dtype)
+                shard.all_gather(dist, hg, packed.cpu())
+                gathered.copy_(hg)
+            else:
+                shard.all_gather(dist, gathered, packed)                    # RCCL over xGMI, once per frame
             r.unpack_tiles(all_tiles_dev.data_ptr(), world * shard.n_max, gathered.data_ptr())
 
     def barrier():
@@ -157,7 +173,7 @@ def main():
             cpu, counters = cpu_baseline_and_counters(args.config, w, h, args.cpu_budget)
         else:
             _, counters = cpu_baseline_and_counters(args.config, w, h, 0.5)
-        b_sample, events = algorithmic_bytes_per_sample(counters, spp, use_tf, False)
+        b_sample, events = algorithmic_bytes_per_sample(counters, spp, use_tf, False, dense=args.config.startswith("c4"))
         my_samples = len(mine) * 256.0 * spp if world > 1 else samples_per_step
         launches = max(1, r.last_launches)                       # a frame is split so that a sub-launch fits the sample pool
         launch_ms = last_ms / launches                           # HIP events on the renderer's stream around the frame's launches
@@ -172,9 +188,10 @@ def main():
             "metric": "Msamples/s (pixels x spp / s), volume path tracing",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else ""),
-            "config": {"workload": "BASELINE configs[%d] '%s': smoke.brick%s, %dx%d, %d spp, seed 42, fov 40" % (
-                {"c1": 0, "c2": 1, "c3": 2}.get(args.config, -1), args.config, " + lut.txt" if use_tf else ", no transfer function", w, h, spp),
+            "vs_baseline": None, "dtype": "f32", "data": ("synthetic dense fp16 grid (tests/scenes.py generator) + reference envmap" if args.config.startswith("c4") else
+                                      "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
+            "config": {"workload": "BASELINE configs[%d] '%s': %s%s, %dx%d, %d spp, seed 42, fov 40" % (
+                {"c1": 0, "c2": 1, "c3": 2, "c4": 3}.get(args.config[:2], -1), args.config, "synthetic dense fp16 grid" if args.config.startswith("c4") else "smoke.brick", " + lut.txt" if use_tf else ", no transfer function", w, h, spp),
                 "parallelism": "tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame" % world if world > 1 else "1 GPU, 1 fused launch/frame"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "pathtrace_kernel<%s,false>" % ("true" if use_tf else "false"),

@@ -118,7 +118,7 @@ int vr_impmap_floats(vr_renderer* r);
 int vr_get_impmap(vr_renderer* r, float* out, int count);
 /* scheduler thresholds of the path-tracing kernel (8 ints, see volren_amd/csrc/vr_kernels.hip) */
 int vr_set_sched(const int32_t thresholds[8]);
-/* scheduler statistics (diagnostics): enable != 0 starts counting; out (26 x uint64, may be NULL) receives, per state,
+/* scheduler statistics (diagnostics): enable != 0 starts counting; out (32 x uint64, may be NULL) receives, per state,
  * [block executions, active lanes], then [16] wave iterations, [17] waves, [18..24] cycles per state, [25] summed wave lifetime */
 int vr_sched_stats(int enable, unsigned long long* out);
 /* unit-test probe of the device math (volren_amd/csrc/vr_math.h): host arrays in/out */

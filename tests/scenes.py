@@ -20,7 +20,49 @@ CONFIGS = {
 }
 
 
+def synthetic_dense_fp16(n=512, seed=1234):
+    """BASELINE configs[3] generator: deterministic smoke-like n^3 field (sum of Gaussian blobs on a coarse lattice,
+    tricubically upsampled, ~25 % non-zero, max 5.0) as float16 [z][y][x]."""
+    from scipy import ndimage
+    coarse = max(32, n // 4)
+    f = synthetic_density(coarse, seed=seed, blobs=64).astype(np.float32)
+    if coarse != n:
+        f = ndimage.zoom(f, n / coarse, order=1, mode="nearest", prefilter=False)[:n, :n, :n]
+    f = np.clip(f, 0, None)
+    return np.ascontiguousarray(f * np.float32(5.0 / max(float(f.max()), 1e-6))).astype(np.float16)
+
+
+_DENSE_CACHE = {}
+
+
+def configure_dense(r, is_oracle, n=512):
+    """BASELINE configs[3] ('c4'): synthetic n^3 dense fp16 grid + the README.md:72-73 rendering parameters."""
+    if n not in _DENSE_CACHE:
+        _DENSE_CACHE[n] = synthetic_dense_fp16(n)
+    vox = _DENSE_CACHE[n]
+    if is_oracle:
+        import encoder_ref
+        r.set_volume(encoder_ref.encode_dense_fp16(vox))
+    else:
+        r.set_volume_dense_f16(vox)
+    r.load_envmap(HDR)
+    cfg = CONFIGS["readme"]
+    r.bounces, r.cam_fov = 128, 40.0
+    r.albedo = (cfg["albedo"],) * 3
+    r.phase = cfg["phase"]
+    r.density_scale = cfg["density"]
+    r.env_strength = cfg["env_strength"]
+    if is_oracle:
+        r.set_env_rot(cfg["env_rot"])
+    else:
+        r.env_rot = cfg["env_rot"]
+    r.tonemap_exposure, r.tonemap_gamma = cfg["exposure"], cfg["gamma"]
+    return r
+
+
 def configure(r, name, is_oracle):
+    if name.startswith("c4"):
+        return configure_dense(r, is_oracle, int(name[3:]) if len(name) > 3 else 512)
     """Apply a config in the reference's command-line order (paths first, then overrides: main.cpp:360-435)."""
     cfg = CONFIGS[name]
     r.load_volume(SMOKE)

@@ -136,6 +136,39 @@ def test_ragged_resolution_and_tiles():
         s.set_tiles([10 ** 6])
 
 
+def test_tile_shard_pack_gather_unpack_on_device():
+    """The multi-GPU data path on one GPU: 3 'ranks' render their diagonal-interleaved tiles, pack them with the HIP pack
+    kernel, the packed buffers are concatenated like all_gather does, and every rank's unpack rebuilds the full frame --
+    bit-identical to the unsharded render (torch only carries the device buffers)."""
+    import torch
+    from volren_amd.shard import TileShard
+    w, h, spp, world = 150, 90, 3, 3
+    full = scenes.hip_scene("c1", w, h)
+    full.render(spp)
+    ref = full.framebuffer()
+    packed = []
+    shards = []
+    for rank in range(world):
+        sh = TileShard(w, h, world, rank)
+        r = scenes.hip_scene("c1", w, h)
+        r.set_tiles(sh.mine)
+        r.render(spp)
+        ids = torch.from_numpy(sh.pack_ids).cuda()
+        buf = torch.zeros(sh.packed_floats, dtype=torch.float32, device="cuda")
+        r.pack_tiles(ids.data_ptr(), sh.n_max, buf.data_ptr())
+        r.synchronize()
+        torch.cuda.synchronize()
+        packed.append(buf)
+        shards.append((sh, r))
+    gathered = torch.cat(packed)
+    for sh, r in shards:
+        assert gathered.numel() == sh.gathered_floats
+        ids = torch.from_numpy(sh.unpack_ids).cuda()
+        r.unpack_tiles(ids.data_ptr(), world * sh.n_max, gathered.data_ptr())
+        r.synchronize()
+        assert np.array_equal(_bits(r.framebuffer()), _bits(ref))
+
+
 def test_emission_grid_and_brick_upload():
     """Synthetic density + temperature brick grids (numpy reference encoder) handed to both sides as raw BrickGrid
     arrays: checks vr_set_volume_brick, the emission path (common.glsl:324-328,489) and a second grid layout."""

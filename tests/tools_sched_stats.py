@@ -19,5 +19,6 @@ for k in va.renderer.STATE_NAMES:
     cyc = st["cycles"][k]
     print("  %-8s exec %10d  lanes/exec %5.1f  lane-steps/sample %6.2f  exec/wave-sample %6.2f  cyc/exec %7.0f  share %5.1f%%"%(k,e,l/max(e,1),l/ns,e/(ns/64), cyc/max(e,1), 100.0*cyc/max(st["wave_cycles"],1)))
 print("  wave lifetime cycles/wave-sample %.0f ; unaccounted (scheduler) %.1f%%"%(st["wave_cycles"]/(ns/64), 100.0*(1-sum(st["cycles"].values())/max(st["wave_cycles"],1))))
+print("  pool occupancy per iteration:", {k: round(v,1) for k,v in st.get("occupancy",{}).items()})
 print("  avg resident waves (at 2.4 GHz) %.0f  (waves launched %d)"%(st["wave_cycles"]/(ms*2.4e6), st["waves"]))
 print("  iterations/wave-sample %.1f  blocks/iter %.2f"%(st["iterations"]/(ns/64), tot_exec/st["iterations"]))

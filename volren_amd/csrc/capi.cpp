@@ -406,10 +406,10 @@ int vr_set_sched(const int32_t thr[8]) {
 int vr_sched_stats(int enable, unsigned long long* out) {
     static unsigned long long* dev = nullptr;
     return guard([&] {
-        if (out && dev) { VR_HIP(hipDeviceSynchronize()); VR_HIP(hipMemcpy(out, dev, 26 * 8, hipMemcpyDeviceToHost)); }
+        if (out && dev) { VR_HIP(hipDeviceSynchronize()); VR_HIP(hipMemcpy(out, dev, 32 * 8, hipMemcpyDeviceToHost)); }
         if (enable) {
-            if (!dev) VR_HIP(hipMalloc((void**)&dev, 26 * 8));
-            VR_HIP(hipMemset(dev, 0, 26 * 8));
+            if (!dev) VR_HIP(hipMalloc((void**)&dev, 32 * 8));
+            VR_HIP(hipMemset(dev, 0, 32 * 8));
             vr::set_stats_buffer(dev);
         } else {
             vr::set_stats_buffer(nullptr);

@@ -144,6 +144,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     const unsigned long long t_begin = __builtin_readcyclecounter();
     uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long occ[6] = { 0, 0, 0, 0, 0, 0 };      // summed per iteration: marching lanes, READY, NEE, POSTNEE, ESCAPE, FREE
 #define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
 #define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
 // push the slots of all lanes where COND holds onto stack QI (wave-synchronous)
@@ -186,6 +187,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                 cnt_ready -= take;
             }
         }
+        if (STATS) { occ[0] += (unsigned)__popcll(__ballot(slot >= 0)); occ[1] += (unsigned)cnt_ready; occ[2] += (unsigned)cnt_nee; occ[3] += (unsigned)cnt_post; occ[4] += (unsigned)cnt_esc; occ[5] += (unsigned)cnt_free; }
         // (2) the hot pair: up to thr[COLLIDE] march steps, then the collision code
         int32_t n;
         for (int32_t k = 0; k < S.thr[ST_COLLIDE]; ++k) {
@@ -311,6 +313,8 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
 #pragma unroll
         for (int k = 0; k < ST_DONE; ++k) atomicAdd(&stats[18 + k], st_cyc[k]);
         atomicAdd(&stats[25], __builtin_readcyclecounter() - t_start);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&stats[26 + k], occ[k]);
     }
 #undef VR_STAT
 #undef VR_STAT_END

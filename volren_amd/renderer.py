@@ -225,7 +225,7 @@ STATE_NAMES = ("new", "begin", "march", "collide", "nee", "postnee", "escape")
 
 def sched_stats(enable=True, read=False):
     """Scheduler diagnostics of the path-tracing kernel. Returns {state: (executions, active_lanes)} when read."""
-    out = np.zeros(26, np.uint64) if read else None
+    out = np.zeros(32, np.uint64) if read else None
     _lib.check(_lib.load().vr_sched_stats(1 if enable else 0, out.ctypes.data if read else None))
     if not read:
         return None
@@ -233,5 +233,6 @@ def sched_stats(enable=True, read=False):
     d["iterations"] = int(out[16])
     d["waves"] = int(out[17])
     d["cycles"] = {n: int(out[18 + i]) for i, n in enumerate(STATE_NAMES)}     # s_memtime ticks inside each state's block
-    d["wave_cycles"] = int(out[25])                                             # summed lifetime of all wavefronts
+    d["wave_cycles"] = int(out[25])
+    d["occupancy"] = {n: int(out[26 + i]) / max(1, int(out[16])) for i, n in enumerate(("marching", "ready", "nee", "postnee", "escape", "free"))}                                             # summed lifetime of all wavefronts
     return d
