@@ -52,6 +52,9 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #ifndef VR_WAVES_PER_SIMD
 #define VR_WAVES_PER_SIMD 4
 #endif
+#ifndef VR_BATCH_REGS
+#define VR_BATCH_REGS 1
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Wave-private path pool.
@@ -103,10 +106,10 @@ struct HotStore {                      // [field][slot] dwords in LDS; lanes add
         h.majorant = 0.0f;
     }
 };
-struct ColdGlobal {                    // [field][slot] floats of this wavefront's slice of the workspace
+struct ColdGlobal {                    // one 128-byte line per path slot in this wavefront's slice of the workspace
     float* base;
-    __device__ __forceinline__ float ld(int32_t f) const { return base[f * NSLOT]; }
-    __device__ __forceinline__ void st(int32_t f, float v) { base[f * NSLOT] = v; }
+    __device__ __forceinline__ float ld(int32_t f) const { return static_cast<const float*>(__builtin_assume_aligned(base, 128))[f]; }
+    __device__ __forceinline__ void st(int32_t f, float v) { static_cast<float*>(__builtin_assume_aligned(base, 128))[f] = v; }
 };
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
@@ -123,7 +126,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     __shared__ uint8_t lds_q[4 * Q_COUNT * NSLOT];
     uint8_t* const q = lds_q + wave * (Q_COUNT * NSLOT);
     // per-wavefront slice of the workspace: the cold fields of its NSLOT paths
-    float* const cold_base = cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)(C_COUNT * NSLOT);
+    float* const cold_base = cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)(C_STRIDE * NSLOT);
     __shared__ uint32_t lds_hot[4 * NHOT * NSLOT];
     const HotStore hs{ lds_hot + wave * (NHOT * NSLOT) };
 
@@ -201,7 +204,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
         if (n > 0) {
             VR_STAT(ST_COLLIDE, n);
             if (slot >= 0 && l.state == ST_COLLIDE) {
-                ColdGlobal c{ cold_base + slot };
+                ColdGlobal c{ cold_base + slot * C_STRIDE };
                 if (P.u.integrator != 0) do_collide_global<USE_TF>(l, c, P); else do_collide<USE_TF>(l, c, P);
             }
             VR_STAT_END(ST_COLLIDE);
@@ -231,8 +234,16 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
         const bool want_post = cnt_post > 0 && (cnt_post >= S.thr[ST_POSTNEE] || (hungry && cnt_post == big));
         const bool want_esc = cnt_esc > 0 && (cnt_esc >= S.thr[ST_ESCAPE] || (hungry && cnt_esc == big));
         if (want_new || want_nee || want_post || want_esc) {
-            // the lanes double as batch workers; the batch path lives in its own register set `b`, the marching path `l` stays put
+            // the lanes double as batch workers.  VR_BATCH_REGS=1: the batch path lives in its own register set `b` and the
+            // marching path `l` stays put; =0: the marching path is saved to its LDS slot and `l` is reused (fewer VGPRs)
+#if VR_BATCH_REGS
             Hot b;
+#else
+            const int32_t my_slot = slot;
+            if (my_slot >= 0) hs.save(l, my_slot);
+            __builtin_amdgcn_wave_barrier();
+            Hot& b = l;
+#endif
             if (want_esc) {
                 n = min(64, cnt_esc);
                 VR_STAT(ST_ESCAPE, n);
@@ -240,7 +251,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                 if (lane < n) {
                     bs = q[Q_ESC * NSLOT + cnt_esc - 1 - lane];
                     hs.load(b, bs);
-                    ColdGlobal c{ cold_base + bs };
+                    ColdGlobal c{ cold_base + bs * C_STRIDE };
                     do_escape(b, c, P, wu);                              // writes the sample; the slot becomes free
                 }
                 cnt_esc -= n;
@@ -254,7 +265,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                 if (lane < n) {
                     bs = q[Q_POST * NSLOT + cnt_post - 1 - lane];
                     hs.load(b, bs);
-                    ColdGlobal c{ cold_base + bs };
+                    ColdGlobal c{ cold_base + bs * C_STRIDE };
                     do_postnee(b, c, P, wu);
                     hs.save(b, bs);
                 }
@@ -277,7 +288,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                     if (lane < n) {
                         bs = q[Q_FREE * NSLOT + cnt_free - 1 - lane];
                         hot_init(b);
-                        ColdGlobal c{ cold_base + bs };
+                        ColdGlobal c{ cold_base + bs * C_STRIDE };
                         do_new(b, c, P, wu, cursor + (uint32_t)lane);
                         hs.save(b, bs);
                     }
@@ -294,7 +305,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                 if (lane < n) {
                     bs = q[Q_NEE * NSLOT + cnt_nee - 1 - lane];
                     hs.load(b, bs);
-                    ColdGlobal c{ cold_base + bs };
+                    ColdGlobal c{ cold_base + bs * C_STRIDE };
                     do_nee(b, c, P);
                     hs.save(b, bs);
                 }
@@ -302,6 +313,10 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                 VR_ROUTE_B(bs);
                 VR_STAT_END(ST_NEE);
             }
+#if !VR_BATCH_REGS
+            __builtin_amdgcn_wave_barrier();
+            if (my_slot >= 0) hs.load(l, my_slot);
+#endif
         }
         if (exhausted && cnt_free == NSLOT) break;                        // every path of the pool has finished
     }
@@ -388,7 +403,7 @@ static int resident_blocks(K kernel) {
     return cus * per_cu;
 }
 
-size_t pathtrace_workspace_floats() { return (size_t)8192 * C_COUNT * NSLOT; }      // cold state of up to 8192 resident wavefronts
+size_t pathtrace_workspace_floats() { return (size_t)8192 * C_STRIDE * NSLOT; }      // cold state of up to 8192 resident wavefronts
 
 void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream) {

@@ -57,9 +57,12 @@ struct Hot {
 // Cold: path state that only the rare events (new sample, scatter, escape) read or write.  On the GPU it is parked
 // in LDS ([field][lane] dwords, conflict-free) so that it does not occupy registers while the lane marches; the
 // host harness backs it with a plain array.  `Cold` is any type with float ld(int) / void st(int, float).
+// Field order = six 16-byte groups that the events read and write whole, so that a path's cold state is one
+// 128-byte line of [slot][field] storage and adjacent accesses fuse into dwordx4:
+//   (pos, f_p) (dir, n_paths) (thr, item) (L, -) (sh_a, sh_pdf) (sh_Le, -)
 enum ColdField : int32_t {
-    C_POS = 0, C_DIR = 3, C_THR = 6, C_L = 9, C_SHA = 12, C_SHLE = 15, C_SHPDF = 18, C_FP = 19, C_NPATHS = 20, C_ITEM = 21,
-    C_COUNT = 22
+    C_POS = 0, C_FP = 3, C_DIR = 4, C_NPATHS = 7, C_THR = 8, C_ITEM = 11, C_L = 12, C_SHA = 16, C_SHPDF = 19, C_SHLE = 20,
+    C_COUNT = 24, C_STRIDE = 32
 };
 template <class Cold> VR_HD v3 ld3(const Cold& c, int32_t f) { return v3{ c.ld(f), c.ld(f + 1), c.ld(f + 2) }; }
 template <class Cold> VR_HD void st3(Cold& c, int32_t f, v3 v) { c.st(f, v.x); c.st(f + 1, v.y); c.st(f + 2, v.z); }
