@@ -599,6 +599,37 @@ static void trace_path(ctx_t* c, v3 pos, v3 dir, uint32_t* seed, float out[4]) {
     out[3] = n_paths > 0 ? 1.0f : 0.0f;     /* clamp(n_paths, 0.f, 1.f) */
 }
 
+/* ref: common.glsl:571-591 direct_volume_rendering: 64 jittered steps of emission-absorption compositing through the
+ * transfer function (dead code in the reference: no kernel calls it; selectable here as integrator = 2, needs a LUT).
+ * out[3] (not defined by the reference): opacity 1 - Tr. */
+#define RAYMARCH_STEPS 64
+static void direct_volume_rendering(ctx_t* c, v3 pos, v3 dir, uint32_t* seed, float out[4]) {
+    const orc_params* p = c->p;
+    v3 L = V3(0, 0, 0);
+    float near, far;
+    if (!intersect_box(pos, dir, p->vol_bb_min, p->vol_bb_max, &near, &far)) {
+        const v3 e = lookup_environment(c, dir);
+        out[0] = e.x; out[1] = e.y; out[2] = e.z; out[3] = 0.0f;
+        return;
+    }
+    const v3 ipos = mat4point(p->vol_density_inv_transform, pos);
+    const v3 idir = mat4dir(p->vol_density_inv_transform, dir);
+    const float dt = (far - near) / (float)RAYMARCH_STEPS;
+    near += rng(seed) * dt;
+    float Tr = 1.0f;
+    for (int i = 0; i < RAYMARCH_STEPS; ++i) {
+        float rgba[4];
+        tf_lookup(c, lookup_density_trilinear(c, v3axpy(ipos, om_min(near + (float)i * dt, far), idir)) * p->vol_inv_majorant, rgba);
+        const float dtau = rgba[3] * p->vol_majorant * dt;
+        L = v3add(L, v3scale(v3scale(V3(rgba[0], rgba[1], rgba[2]), dtau), Tr));
+        Tr *= om_exp(-dtau);
+        if (Tr <= 1e-6f) { out[0] = L.x; out[1] = L.y; out[2] = L.z; out[3] = 1.0f - Tr; return; }
+    }
+    const v3 e = lookup_environment(c, dir);
+    L = v3add(L, v3scale(e, Tr));
+    out[0] = L.x; out[1] = L.y; out[2] = L.z; out[3] = 1.0f - Tr;
+}
+
 /* ref: pathtracer_brick.glsl:23-37 / pathtracer_brick_tf.glsl:24-38, one pixel, one sample */
 static void pixel_sample(ctx_t* c, int x, int y, int sample, float out[4]) {
     const orc_params* p = c->p;
@@ -608,7 +639,8 @@ static void pixel_sample(ctx_t* c, int x, int y, int sample, float out[4]) {
     const v3 pos = V3(p->cam_pos[0], p->cam_pos[1], p->cam_pos[2]);
     const float jx = rng(&seed), jy = rng(&seed);
     const v3 dir = view_dir(p, x, y, W, H, jx, jy);
-    trace_path(c, pos, dir, &seed, out);
+    if (p->integrator == 2 && p->use_tf) direct_volume_rendering(c, pos, dir, &seed, out);
+    else trace_path(c, pos, dir, &seed, out);
     c->c.samples++;
 }
 

@@ -63,7 +63,8 @@ typedef struct {
     /* build-only switches */
     int32_t use_tf;          /* pathtracer_brick_tf.glsl vs pathtracer_brick.glsl */
     int32_t has_emission;    /* emission grid bound (renderer.cpp:117-124) */
-    int32_t integrator;      /* 0 = USE_DDA (both reference kernels), 1 = global-majorant delta/ratio tracking (common.glsl:333-394) */
+    int32_t integrator;      /* 0 = USE_DDA (both reference kernels), 1 = global-majorant delta/ratio tracking (common.glsl:333-394),
+                              * 2 = direct volume rendering, 64-step ray marcher (common.glsl:571-591; needs a LUT) */
 } orc_params;
 
 typedef struct {

@@ -36,6 +36,18 @@ def test_global_majorant_tracking_variant(name):
     assert abs(float(want[..., :3].mean()) - float(dda[..., :3].mean())) < 0.1 * float(dda[..., :3].mean()) + 1e-4
 
 
+def test_direct_volume_rendering_integrator():
+    """common.glsl:571-591 (64-step emission-absorption ray marcher through the LUT; dead code in the reference):
+    integrator = 2."""
+    r = scenes.oracle_scene("c3", 40, 40)
+    r.integrator = 2
+    r.show_environment = True
+    want = r.render(4).copy()
+    got, _ = hk.render(r, 4)
+    assert want[..., 3].max() > 0.5 and want[..., 3].min() == 0.0
+    assert _same(got, want)
+
+
 def test_sample_chunks_and_progressive_accumulation():
     """40 spp spans two 32-sample chunks of a wave's item pool; rendering 3 + 5 more samples continues the running mean."""
     r = scenes.oracle_scene("c1", 24, 24)

@@ -339,6 +339,22 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
 #undef VR_ROUTE_ST
 }
 
+// integrator = 2: direct volume rendering, one thread per (pixel, sample) item, same sample-buffer layout
+__global__ void __launch_bounds__(256)
+dvr_kernel(const SceneParams P, float* __restrict__ sbuf, const LaunchDesc D) {
+    const uint32_t per_unit = (uint32_t)(D.spu * 64);
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t u = g / per_unit, item = g - u * per_unit;
+    if (u >= D.n_units) return;
+    const WorkUnit wu = make_unit(D, P.u.resolution[0], u, sbuf);
+    if ((int32_t)item >= wu.n_items) return;
+    const int32_t px = wu.px0 + (int32_t)(item & 7u), py = wu.py0 + (int32_t)((item >> 3) & 7u);
+    if (px >= P.u.resolution[0] || py >= P.u.resolution[1]) return;
+    float L[4];
+    dvr_sample(P, px, py, wu.first_sample + (int32_t)(item >> 6), L);
+    reinterpret_cast<float4*>(sbuf)[g] = make_float4(L[0], L[1], L[2], L[3]);
+}
+
 // Running mean over the samples of one launch, in sample order (pathtracer_brick.glsl:36): one thread per pixel.
 __global__ void __launch_bounds__(256)
 accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const int32_t* __restrict__ tiles, int32_t n_tiles,
@@ -424,8 +440,13 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     if (blocks == 0 || g_blocks_per_cu > 0) blocks = std::min(resident_blocks(kernel), 2048);      // workspace holds 2048 workgroups
     const uint32_t waves_needed = (D.n_units + 3u) / 4u;
     const dim3 grid((unsigned)std::min<uint32_t>((uint32_t)blocks, waves_needed > 0 ? waves_needed : 1u)), block(256);
-    (void)hipMemsetAsync(unit_counter, 0, sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(kernel, grid, block, 0, stream, P, sample_pool, workspace, D, S, status, g_stats);
+    if (P.u.integrator == 2 && P.u.use_tf) {
+        const uint64_t items = (uint64_t)D.n_units * (uint64_t)(D.spu * 64);
+        hipLaunchKernelGGL(dvr_kernel, dim3((unsigned)((items + 255) / 256)), block, 0, stream, P, sample_pool, D);
+    } else {
+        (void)hipMemsetAsync(unit_counter, 0, sizeof(uint32_t), stream);
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, P, sample_pool, workspace, D, S, status, g_stats);
+    }
     hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)n_tiles), block, 0, stream, sample_pool, fb, tiles, n_tiles,
                        P.u.resolution[0], P.u.resolution[1], first_sample, n_samples, D.spu);
 }

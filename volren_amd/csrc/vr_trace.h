@@ -583,6 +583,45 @@ VR_HD void do_escape(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) 
     h.state = ST_NEW;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// direct_volume_rendering (common.glsl:571-591): 64 jittered steps of emission-absorption compositing through the
+// transfer function.  Dead code in the reference (no kernel calls it); offered as integrator = 2 (needs a LUT).  One
+// call per (pixel, sample): no path state, no scheduler.  .w = opacity 1 - Tr (not defined by the reference).
+VR_HD void dvr_sample(const SceneParams& P, int32_t px, int32_t py, int32_t smp, float out[4]) {
+    const Uniforms& u = P.u;
+    const int32_t W = u.resolution[0], H = u.resolution[1];
+    uint32_t seed = tea32((uint32_t)u.seed * (uint32_t)(py * W + px), (uint32_t)smp);
+    const float jx = rng(seed), jy = rng(seed);
+    const float fx = (((float)px + jx) - (float)W * 0.5f) / (float)H;
+    const float fy = (((float)py + jy) - (float)H * 0.5f) / (float)H;
+    const v3 dir = normalize(mat3_mul(u.cam_transform, normalize(v3{ fx, fy, P.cam_z })));
+    const v3 pos = v3{ u.cam_pos[0], u.cam_pos[1], u.cam_pos[2] };
+    v3 L = v3{ 0, 0, 0 };
+    float tnear, tfar;
+    if (!intersect_box(pos, dir, u.vol_bb_min, u.vol_bb_max, tnear, tfar)) {
+        const v3 e = lookup_environment(P, dir);
+        out[0] = e.x; out[1] = e.y; out[2] = e.z; out[3] = 0.0f;
+        return;
+    }
+    const v3 ipos = mat4_point(u.vol_density_inv_transform, pos);
+    const v3 idir = mat4_dir(u.vol_density_inv_transform, dir);
+    const float dt = (tfar - tnear) / 64.0f;
+    tnear += rng(seed) * dt;
+    float Tr = 1.0f;
+    for (int32_t i = 0; i < 64; ++i) {
+        float rgba[4];
+        const v3 ip = axpy(ipos, min_(tnear + (float)i * dt, tfar), idir);
+        tf_lookup(P, (u.vol_density_scale * density_trilinear_raw(P.density, ip)) * u.vol_inv_majorant, rgba);
+        const float dtau = rgba[3] * u.vol_majorant * dt;
+        L = L + (v3{ rgba[0], rgba[1], rgba[2] } * dtau) * Tr;
+        Tr *= exp_(-dtau);
+        if (Tr <= 1e-6f) { out[0] = L.x; out[1] = L.y; out[2] = L.z; out[3] = 1.0f - Tr; return; }
+    }
+    const v3 e = lookup_environment(P, dir);
+    L = L + e * Tr;
+    out[0] = L.x; out[1] = L.y; out[2] = L.z; out[3] = 1.0f - Tr;
+}
+
 // sequential driver (host harness / reference order): one state transition of one lane
 template <bool USE_TF, class Cold>
 VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uint32_t& next_item) {
