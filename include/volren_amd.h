@@ -70,7 +70,8 @@ int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
 
 /* --- public fields of RendererOpenGL / Environment / TransferFunction / camera (src/renderer.h:30-62, environment.h:20-21,
  *     transferfunc.h:39, src/main.cpp:360-435).  Names: "sample" "sppx" "seed" "bounces" "show_environment" "tonemapping"
- *     "integrator" "grid_frame_counter" (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
+ *     "integrator" (0 DDA tracking, 1 global-majorant tracking, 2 direct volume rendering) "grid_frame_counter"
+ *     "sample_pool_mb" (HBM budget of the per-sample radiance pool, default 16384) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
  *     "emission_scale" "vol_clip_min"(3) "vol_clip_max"(3) "env_strength" "env_transform"(9) "env_rot"(1, degrees about +y,
  *     main.cpp:382) "tf_window_left" "tf_window_width" "cam_pos"(3) "cam_dir"(3) "cam_up"(3) "cam_fov" "volume_transform"(16) (float) */
 int vr_set_int(vr_renderer* r, const char* name, int value);

@@ -211,6 +211,7 @@ int vr_set_int(vr_renderer* r, const char* name, int v) {
         else if (n == "show_environment") R.show_environment = v != 0;
         else if (n == "tonemapping") R.tonemapping = v != 0;
         else if (n == "integrator") R.integrator = v;
+        else if (n == "sample_pool_mb") { if (v < 16) throw std::runtime_error("sample_pool_mb must be >= 16"); R.sample_pool_bytes = (size_t)v << 20; }
         else if (n == "grid_frame_counter") {
             if (!R.volume || v < 0 || (size_t)v >= R.volume->n_grid_frames()) throw std::runtime_error("grid_frame_counter out of range");
             R.volume->grid_frame_counter = (size_t)v;
@@ -231,6 +232,7 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "show_environment") *v = R.show_environment ? 1 : 0;
         else if (n == "tonemapping") *v = R.tonemapping ? 1 : 0;
         else if (n == "integrator") *v = R.integrator;
+        else if (n == "sample_pool_mb") *v = (int)(R.sample_pool_bytes >> 20);
         else if (n == "grid_frame_counter") *v = R.volume ? (int)R.volume->grid_frame_counter : 0;
         else if (n == "n_grid_frames") *v = R.volume ? (int)R.volume->n_grid_frames() : 0;
         else if (n == "last_launches") *v = R.last_launches;

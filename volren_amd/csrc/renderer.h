@@ -103,7 +103,7 @@ struct RendererHIP {
     hipStream_t stream = nullptr;
     int integrator = 0;                               // 0: DDA tracking (both reference kernels)
     int last_launches = 0;                            // path-tracing sub-launches of the last trace()/render()
-    size_t sample_pool_bytes = (size_t)2 << 30;       // HBM budget of the per-sample radiance pool (16 B per pixel-sample)
+    size_t sample_pool_bytes = (size_t)16 << 30;      // HBM budget of the per-sample radiance pool (16 B per pixel-sample; sized for 288 GB HBM3E, allocated on demand)
 
     void set_tiles(const std::vector<int32_t>& tile_ids);     // empty = whole frame
     void fill_params(SceneParams& P);                          // renderer.cpp:88-138
