@@ -72,17 +72,16 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 // Everything is wave-synchronous (ballots, mbcnt ranks, scalar counters): no atomics, no barriers, no spinning; the only
 // global atomic is the work-queue head.  Which lane runs which path never changes a result.
 #ifndef VR_NSLOT
-#define VR_NSLOT 160
+#define VR_NSLOT 144
 #endif
 constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
 
-constexpr int32_t NHOT = 12;
+constexpr int32_t NHOT = 15;
 enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
 
 struct HotStore {                      // [field][slot] dwords in LDS; lanes address different slots
     uint32_t* base;
-    // 12 dwords per parked path: ri = 1/idir is recomputed on load (same IEEE divisions), mip (a multiple of 1/4 in
-    // [0,3]) rides in the flag word
+    // 15 dwords per parked path; mip (a multiple of 1/4 in [0,3]) rides in the flag word
     __device__ __forceinline__ void save(const Hot& h, int32_t slot) const {
         uint32_t* p = base + slot;
         p[0 * NSLOT] = h.seed;
@@ -91,13 +90,14 @@ struct HotStore {                      // [field][slot] dwords in LDS; lanes add
         p[7 * NSLOT] = f2u(h.t); p[8 * NSLOT] = f2u(h.far); p[9 * NSLOT] = f2u(h.tau);
         p[10 * NSLOT] = f2u(h.Tr);
         p[11 * NSLOT] = (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)(int32_t)(h.mip * 4.0f) << 16);
+        p[12 * NSLOT] = f2u(h.ri.x); p[13 * NSLOT] = f2u(h.ri.y); p[14 * NSLOT] = f2u(h.ri.z);
     }
     __device__ __forceinline__ void load(Hot& h, int32_t slot) const {
         const uint32_t* p = base + slot;
         h.seed = p[0 * NSLOT];
         h.ipos = v3{ u2f(p[1 * NSLOT]), u2f(p[2 * NSLOT]), u2f(p[3 * NSLOT]) };
         h.idir = v3{ u2f(p[4 * NSLOT]), u2f(p[5 * NSLOT]), u2f(p[6 * NSLOT]) };
-        h.ri = v3{ 1.0f / h.idir.x, 1.0f / h.idir.y, 1.0f / h.idir.z };
+        h.ri = v3{ u2f(p[12 * NSLOT]), u2f(p[13 * NSLOT]), u2f(p[14 * NSLOT]) };
         h.t = u2f(p[7 * NSLOT]); h.far = u2f(p[8 * NSLOT]); h.tau = u2f(p[9 * NSLOT]);
         h.Tr = u2f(p[10 * NSLOT]);
         const uint32_t f = p[11 * NSLOT];
@@ -214,8 +214,10 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
             const bool parked = slot >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE;
             if (__ballot(parked)) {
                 if (parked) hs.save(l, slot);
-                const int32_t ps = parked ? slot : -1;
-                VR_ROUTE(ps);
+                // the hot pair can only leave a path in NEE, POSTNEE or ESCAPE
+                VR_PUSH(Q_NEE, cnt_nee, parked && l.state == ST_NEE, slot);
+                VR_PUSH(Q_POST, cnt_post, parked && l.state == ST_POSTNEE, slot);
+                VR_PUSH(Q_ESC, cnt_esc, parked && l.state == ST_ESCAPE, slot);
                 if (parked) slot = -1;
             }
         }

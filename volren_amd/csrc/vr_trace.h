@@ -153,21 +153,47 @@ VR_HD AxisWeights tricubic_axis_weights(float q) {
     a.base = floor2i(q);
     return a;
 }
+// one LCG step; the draw as the integer-valued float k = state & 0xFFFFFF (rng() would return k * 2^-24)
+VR_HD float rng_k(uint32_t& s) {
+    s = s * 1664525u + 1013904223u;
+    return (float)(s & 0x00FFFFFFu);
+}
 VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) {
     const AxisWeights ax = tricubic_axis_weights(ipos.x - 0.5f);
     const AxisWeights ay = tricubic_axis_weights(ipos.y - 0.5f);
     const AxisWeights az = tricubic_axis_weights(ipos.z - 0.5f);
     int32_t jx = 0, jy = 0, jz = 0;
-    float r;
-    r = rng(seed); if (lt_quot(r, ax.w2, ax.s2)) jx = 1;
-    r = rng(seed); if (lt_quot(r, ay.w2, ay.s2)) jy = 1;
-    r = rng(seed); if (lt_quot(r, az.w2, az.s2)) jz = 1;
-    r = rng(seed); if (lt_quot(r, ax.w3, ax.s3)) jx = 2;
-    r = rng(seed); if (lt_quot(r, ay.w3, ay.s3)) jy = 2;
-    r = rng(seed); if (lt_quot(r, az.w3, az.s3)) jz = 2;
-    r = rng(seed); if (lt_quot(r, ax.w4, ax.s4)) jx = 3;
-    r = rng(seed); if (lt_quot(r, ay.w4, ay.s4)) jy = 3;
-    r = rng(seed); if (lt_quot(r, az.w4, az.s4)) jz = 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Device: every test "k * 2^-24 < w / s" is first tried as "k < (w * 2^24) * rcp(s)" with an 8-ulp guard band
+    // (see lt_quot); the 9 tests share ONE exact fallback, taken when any of them lands inside its band (~1e-5 per call).
+    const uint32_t seed0 = seed;
+    bool unsure = false;
+#define VR_TAP(J, V, W, S) do { \
+        const float k_ = rng_k(seed); \
+        const float q_ = ((W) * 16777216.0f) * __builtin_amdgcn_rcpf(S); \
+        const float m_ = abs_(q_) * 9.5367431640625e-07f; \
+        if (k_ < q_ - m_) J = V; else if (!(k_ > q_ + m_)) unsure = true; \
+    } while (0)
+    VR_TAP(jx, 1, ax.w2, ax.s2); VR_TAP(jy, 1, ay.w2, ay.s2); VR_TAP(jz, 1, az.w2, az.s2);
+    VR_TAP(jx, 2, ax.w3, ax.s3); VR_TAP(jy, 2, ay.w3, ay.s3); VR_TAP(jz, 2, az.w3, az.s3);
+    VR_TAP(jx, 3, ax.w4, ax.s4); VR_TAP(jy, 3, ay.w4, ay.s4); VR_TAP(jz, 3, az.w4, az.s4);
+#undef VR_TAP
+    if (unsure) {
+        seed = seed0; jx = jy = jz = 0;
+#endif
+        float r;
+        r = rng(seed); if (r < ax.w2 / ax.s2) jx = 1;
+        r = rng(seed); if (r < ay.w2 / ay.s2) jy = 1;
+        r = rng(seed); if (r < az.w2 / az.s2) jz = 1;
+        r = rng(seed); if (r < ax.w3 / ax.s3) jx = 2;
+        r = rng(seed); if (r < ay.w3 / ay.s3) jy = 2;
+        r = rng(seed); if (r < az.w3 / az.s3) jz = 2;
+        r = rng(seed); if (r < ax.w4 / ax.s4) jx = 3;
+        r = rng(seed); if (r < ay.w4 / ay.s4) jy = 3;
+        r = rng(seed); if (r < az.w4 / az.s4) jz = 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    }
+#endif
     tx = offs_i(ax.base, jx - 1); ty = offs_i(ay.base, jy - 1); tz = offs_i(az.base, jz - 1);
 }
 
