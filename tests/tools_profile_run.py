@@ -8,6 +8,9 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 r = scenes.hip_scene(cfg, size, size)
+if len(sys.argv) > 4:
+    import volren_amd
+    volren_amd.set_sched([int(x) for x in sys.argv[4].split(",")] + [0])
 r.render(spp)
 r.reset()
 r.render(spp)
