@@ -133,6 +133,51 @@ def test_volume_animation_folder(tmp_path):
         _assert_same(r.framebuffer(), o.render(4), "animation frame %d" % i)
 
 
+FLAG_VARIANTS = {
+    # name: (base config, {field: value}) -- the renderer flags of main.cpp:360-435, one deviation at a time
+    "env_hide": ("c1", dict(show_environment=False)),
+    "albedo_zero": ("c1", dict(albedo=(0.0, 0.0, 0.0))),
+    "albedo_rgb_one_bounce": ("c1", dict(albedo=(1.0, 0.5, 0.25), bounces=1)),
+    "phase_backward": ("c2", dict(phase=-0.7)),
+    "dense_medium": ("c1", dict(density_scale=2000.0, bounces=32)),
+    "thin_medium": ("c1", dict(density_scale=3.0)),
+    "crop": ("c1", dict(vol_clip_min=(0.2, 0.1, 0.0), vol_clip_max=(0.9, 0.6, 1.0))),
+    "camera_inside_wide_fov": ("c1", dict(cam_pos=(0.0, -0.2, 0.05), cam_dir=(0.3, 1.0, 0.1), cam_fov=95.0)),
+    "camera_top_down": ("c1", dict(cam_pos=(0.0, 2.0, 0.0), cam_dir=(0.0, -1.0, 0.001), cam_up=(0.0, 0.0, 1.0))),
+    "env_strong_rotated": ("c1", dict(env_strength=7.5, env_rot=123.0)),
+    "seed": ("c1", dict(seed=-7)),
+    "tf_window": ("c3", dict(tf_window_left=0.05, tf_window_width=0.4)),
+    "tf_with_env": ("c3", dict(show_environment=True, albedo=(0.95, 0.95, 0.95))),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(FLAG_VARIANTS))
+def test_renderer_flags_match_oracle(variant):
+    base, fields = FLAG_VARIANTS[variant]
+    o = scenes.oracle_scene(base, 56, 40)
+    r = scenes.hip_scene(base, 56, 40)
+    for k, v in fields.items():
+        if k == "env_rot":
+            o.set_env_rot(v)
+            r.env_rot = v
+        else:
+            setattr(o, k, v)
+            setattr(r, k, v)
+    r.render(5)
+    _assert_same(r.framebuffer(), o.render(5), variant)
+
+
+def test_zero_samples_and_tiny_frames():
+    r = scenes.hip_scene("c1", 1, 1)
+    r.render(3)
+    o = scenes.oracle_scene("c1", 1, 1)
+    _assert_same(r.framebuffer(), o.render(3), "1x1")
+    z = scenes.hip_scene("c1", 24, 24)
+    z.sppx = 0
+    z.render(0)                     # nothing to do: sample stays 0, framebuffer stays zero
+    assert z.sample == 0 and not z.framebuffer().any()
+
+
 def test_trace_protocol_equals_fused_render():
     """trace() x N (the reference protocol) == render(N) == render(a) + render(b)."""
     a = scenes.hip_scene("c1", 48, 48)

@@ -363,8 +363,14 @@ void RendererHIP::download_display(float* rgba) const {
 }
 
 uint32_t RendererHIP::watchdog_status() {
+    // bit 0: a wavefront gave up (iteration / shader-clock budget), bit 1: a path ended in an impossible state.
+    // Read-and-clear, so that one bad launch does not poison the renderer.
     uint32_t s = 0;
     status_->download(&s, sizeof s, stream);
+    if (s != 0) {
+        VR_HIP(hipMemsetAsync(status_->get(), 0, sizeof(uint32_t), stream));
+        VR_HIP(hipStreamSynchronize(stream));
+    }
     return s;
 }
 
