@@ -355,3 +355,47 @@ def test_tonemap_and_display_buffer():
     r.draw()
     assert np.array_equal(_bits(r.display()), _bits(o.tonemapped()))
     assert np.array_equal(_bits(r.framebuffer()), _bits(o.fb))          # draw() leaves the accumulation buffer untouched
+
+
+def test_volpy_module_drives_the_renderer(tmp_path):
+    """The reference's Python surface (src/bindings.cpp:64-209) as used by scripts/datagen_colmap.py: assign
+    Volume/Environment, set fields, unit cube + commit, render(spp), fbo_data(), draw() + save_with_alpha()."""
+    from PIL import Image
+    import volren_amd.volpy as volpy
+    renderer = volpy.Renderer(64, 48)
+    renderer.init()
+    renderer.volume = volpy.Volume(scenes.SMOKE)
+    renderer.scale_and_move_to_unit_cube()
+    renderer.commit()
+    renderer.environment = volpy.Environment(scenes.HDR)
+    renderer.environment.strength = 3.0
+    renderer.albedo = volpy.vec3(0.8)
+    renderer.bounces, renderer.seed, renderer.phase = 16, 42, 0.3
+    renderer.cam_pos, renderer.cam_fov = volpy.vec3(1, 0, 1), 40.0
+    renderer.cam_dir = -volpy.vec3(1, 0, 1) / np.float32(np.sqrt(2))
+    renderer.render(6)
+    assert renderer.sample == 6 and renderer.resolution() == (64, 48)
+    rgb = np.asarray(renderer.fbo_data())
+    assert rgb.shape == (64, 48, 3) and rgb.dtype == np.float32
+    o = scenes.oracle_scene("c1", 64, 48)
+    o.env_strength, o.albedo, o.bounces, o.phase = 3.0, (0.8, 0.8, 0.8), 16, 0.3
+    o.cam_dir = tuple((-np.array([1, 0, 1], np.float32) / np.float32(np.sqrt(2))).tolist())
+    ref = o.render(6)
+    assert np.array_equal(_bits(rgb.reshape(48, 64, 3)), _bits(ref[..., :3]))
+    renderer.draw()
+    out = tmp_path / "view_0000.jpg"
+    renderer.save_with_alpha(str(out))                       # extension forced to .png (bindings.cpp:163)
+    img = np.asarray(Image.open(tmp_path / "view_0000.png"))
+    want = np.floor(np.clip(o.tonemapped()[::-1], 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(img, want)
+    assert abs(renderer.colmap_focal_length() - 48 / (2 * np.tan(np.radians(20.0)))) < 1e-3
+    q = renderer.colmap_view_rot()
+    assert abs(float(np.linalg.norm(q)) - 1.0) < 1e-5 and renderer.colmap_view_trans().shape == (3,)
+    # a dense in-memory volume + a LUT given as a list of vec4, like datagen_denoise.py builds them
+    renderer.volume = volpy.Volume(40, 40, 40, scenes.synthetic_density(40))
+    renderer.scale_and_move_to_unit_cube()
+    renderer.commit()
+    renderer.transferfunc = volpy.TransferFunction([volpy.vec4(0), volpy.vec4(0.2, 0.4, 0.9, 0.5), volpy.vec4(1, 1, 1, 1)])
+    renderer.transferfunc.window_width = 0.5
+    renderer.render(2)
+    assert np.isfinite(np.asarray(renderer.fbo_data())).all()
