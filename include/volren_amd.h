@@ -70,6 +70,7 @@ int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
 
 /* --- public fields of RendererOpenGL / Environment / TransferFunction / camera (src/renderer.h:30-62, environment.h:20-21,
  *     transferfunc.h:39, src/main.cpp:360-435).  Names: "sample" "sppx" "seed" "bounces" "show_environment" "tonemapping"
+ *     "gpu_encoder" (dense grids are bricked on the device, default 1)
  *     "integrator" (0 DDA tracking, 1 global-majorant tracking, 2 direct volume rendering) "grid_frame_counter"
  *     "sample_pool_mb" (HBM budget of the per-sample radiance pool, default 16384) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
  *     "emission_scale" "vol_clip_min"(3) "vol_clip_max"(3) "env_strength" "env_transform"(9) "env_rot"(1, degrees about +y,
@@ -119,6 +120,9 @@ int vr_impmap_floats(vr_renderer* r);
 int vr_get_impmap(vr_renderer* r, float* out, int count);
 /* scheduler thresholds of the path-tracing kernel (8 ints, see volren_amd/csrc/vr_kernels.hip) */
 int vr_set_sched(const int32_t thresholds[8]);
+/* FNV-1a checksums of the committed density grid's device arrays: [0] brick records, [1] atlas, [2] range words (tests: the
+ * device encoder and the host encoder must agree) */
+int vr_grid_checksums(vr_renderer* r, uint64_t out[3]);
 /* scheduler statistics (diagnostics): enable != 0 starts counting; out (32 x uint64, may be NULL) receives, per state,
  * [block executions, active lanes], then [16] wave iterations, [17] waves, [18..24] cycles per state, [25] summed wave lifetime */
 int vr_sched_stats(int enable, unsigned long long* out);

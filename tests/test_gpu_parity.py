@@ -399,3 +399,39 @@ def test_volpy_module_drives_the_renderer(tmp_path):
     renderer.transferfunc.window_width = 0.5
     renderer.render(2)
     assert np.isfinite(np.asarray(renderer.fbo_data())).all()
+
+
+def test_gpu_dense_to_brick_encoder_equals_host_encoder():
+    """the commit()-time dense -> brick conversion on the device produces the same brick records, atlas and
+    range mips as the host encoder (which is bit-identical to the numpy reference encoder), and renders like the oracle."""
+    import encoder_ref
+    import volren_amd
+    from oracle import binding as ob
+    dens = scenes.synthetic_density(72)[:60, :52, :70].copy()          # ragged 70 x 52 x 60
+    sums = []
+    for gpu in (1, 0):
+        r = volren_amd.Renderer(64, 64)
+        r.gpu_encoder = gpu
+        r.load_envmap(scenes.HDR)
+        r.set_volume_dense(dens)
+        sums.append(r.grid_checksums())
+        if gpu:
+            r.cam_fov, r.bounces = 40.0, 8
+            r.render(6)
+            fb = r.framebuffer()
+    assert sums[0] == sums[1], sums
+    o = ob.OracleRenderer(64, 64)
+    o.load_envmap(scenes.HDR)
+    g = encoder_ref.encode(dens)
+    g.extent = None
+    o.set_volume(g)
+    # the in-memory dense grid keeps its own voxel extent for the unit cube / clip box (renderer.cpp:227-242 on the DenseGrid)
+    ext = np.array([70, 52, 60], np.float32)
+    size = float(ext.max())
+    o.volume_transform = np.array([1 / size, 0, 0, 0, 0, 1 / size, 0, 0, 0, 0, 1 / size, 0,
+                                   *(np.float32(1 / size) * (-ext * np.float32(0.5))).tolist(), 1], np.float32)
+    o.density_scale = size
+    g.extent = (70, 52, 60)
+    g.c.extent[:] = g.extent
+    o.cam_fov, o.bounces = 40.0, 8
+    _assert_same(fb, o.render(6), "gpu-encoded dense grid")

@@ -18,7 +18,7 @@ SYMBOLS = [
     "vr_commit", "vr_reset", "vr_scale_and_move_to_unit_cube", "vr_trace", "vr_render", "vr_synchronize",
     "vr_last_kernel_ms", "vr_framebuffer", "vr_framebuffer_device", "vr_draw", "vr_display", "vr_save_png",
     "vr_set_tiles", "vr_set_stream", "vr_pack_tiles", "vr_unpack_tiles", "vr_get_uniforms", "vr_uniforms_size",
-    "vr_impmap_floats", "vr_get_impmap", "vr_set_sched", "vr_sched_stats", "vr_math_probe", "vr_encode_dense_stats", "vr_write_brick_from_dense",
+    "vr_impmap_floats", "vr_get_impmap", "vr_set_sched", "vr_sched_stats", "vr_grid_checksums", "vr_math_probe", "vr_encode_dense_stats", "vr_write_brick_from_dense",
 ]
 
 _lib = None
@@ -77,6 +77,7 @@ def load():
     L.vr_get_impmap.argtypes = [vp, vp, ci]
     L.vr_set_sched.argtypes = [vp]
     L.vr_sched_stats.argtypes = [ci, vp]
+    L.vr_grid_checksums.argtypes = [vp, vp]
     L.vr_math_probe.argtypes = [ci, vp, vp, vp, ci]
     L.vr_write_brick_from_dense.argtypes = [vp, ci, ci, ci, vp, C.c_char_p]
     L.vr_encode_dense_stats.argtypes = [vp, ci, ci, ci, vp, vp, vp]

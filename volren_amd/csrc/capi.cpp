@@ -211,6 +211,7 @@ int vr_set_int(vr_renderer* r, const char* name, int v) {
         else if (n == "show_environment") R.show_environment = v != 0;
         else if (n == "tonemapping") R.tonemapping = v != 0;
         else if (n == "integrator") R.integrator = v;
+        else if (n == "gpu_encoder") R.gpu_encoder = v != 0;
         else if (n == "sample_pool_mb") { if (v < 16) throw std::runtime_error("sample_pool_mb must be >= 16"); R.sample_pool_bytes = (size_t)v << 20; }
         else if (n == "grid_frame_counter") {
             if (!R.volume || v < 0 || (size_t)v >= R.volume->n_grid_frames()) throw std::runtime_error("grid_frame_counter out of range");
@@ -232,6 +233,7 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "show_environment") *v = R.show_environment ? 1 : 0;
         else if (n == "tonemapping") *v = R.tonemapping ? 1 : 0;
         else if (n == "integrator") *v = R.integrator;
+        else if (n == "gpu_encoder") *v = R.gpu_encoder ? 1 : 0;
         else if (n == "sample_pool_mb") *v = (int)(R.sample_pool_bytes >> 20);
         else if (n == "grid_frame_counter") *v = R.volume ? (int)R.volume->grid_frame_counter : 0;
         else if (n == "n_grid_frames") *v = R.volume ? (int)R.volume->n_grid_frames() : 0;
@@ -377,6 +379,17 @@ int vr_unpack_tiles(vr_renderer* r, const int32_t* ids_dev, int n, const void* p
         if (!R.color) throw std::runtime_error("no framebuffer");
         vr::launch_unpack_tiles((const float*)packed, ids_dev, n, R.color->as<float>(), R.resolution.x, R.resolution.y, R.stream);
         VR_HIP(hipGetLastError());
+    });
+}
+
+int vr_grid_checksums(vr_renderer* r, uint64_t out[3]) {
+    NEED(r);
+    if (!out) return fail(VR_ERR_ARG, "null argument");
+    return guard([&] {
+        use_device(r);
+        auto& R = r->impl;
+        if (!R.volume || R.density_grids.empty()) throw std::runtime_error("no committed volume");
+        R.grid_checksums(R.density_grids.at(R.volume->grid_frame_counter), out);
     });
 }
 

@@ -13,42 +13,8 @@ namespace vr {
 // ---------------------------------------------------------------------------------------------------
 // fp16 helpers (range texture is GL_RG16F)
 
-static uint16_t float_to_half_rne(float f) {
-    const uint32_t x = f2u(f);
-    const uint32_t sign = (x >> 16) & 0x8000u;
-    const uint32_t ax = x & 0x7FFFFFFFu;
-    if (ax >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((ax > 0x7F800000u) ? 0x200u : 0u));
-    if (ax >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);              // overflow -> inf
-    if (ax < 0x33000001u) return (uint16_t)sign;                           // underflow -> 0
-    int e = (int)(ax >> 23) - 127;
-    uint32_t m = (ax & 0x007FFFFFu) | 0x00800000u;
-    int shift;
-    uint32_t h;
-    if (e < -14) { shift = 13 + (-14 - e); h = 0; }                        // subnormal half
-    else { shift = 13; h = (uint32_t)(e + 15) << 10; m &= 0x007FFFFFu; }
-    const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
-    uint32_t r = h + q;
-    if (rem > half || (rem == half && (r & 1u))) r += 1u;
-    return (uint16_t)(sign | r);
-}
-static uint16_t half_next_up(uint16_t h) {       // next representable towards +inf
-    if ((h & 0x7FFFu) == 0) return 0x0001u;
-    return (h & 0x8000u) ? (uint16_t)(h - 1u) : (uint16_t)(h + 1u);
-}
-static uint16_t half_next_down(uint16_t h) {
-    if ((h & 0x7FFFu) == 0) return 0x8001u;
-    return (h & 0x8000u) ? (uint16_t)(h + 1u) : (uint16_t)(h - 1u);
-}
-uint16_t float_to_half_round_down(float f) {
-    uint16_t h = float_to_half_rne(f);
-    if (half2float(h) > f) h = half_next_down(h);
-    return h;
-}
-uint16_t float_to_half_round_up(float f) {
-    uint16_t h = float_to_half_rne(f);
-    if (half2float(h) < f) h = half_next_up(h);
-    return h;
-}
+uint16_t float_to_half_round_down(float f) { return (uint16_t)float_to_half_down(f); }
+uint16_t float_to_half_round_up(float f) { return (uint16_t)float_to_half_up(f); }
 
 // ---------------------------------------------------------------------------------------------------
 DenseGrid::DenseGrid(uint32_t w, uint32_t h, uint32_t d, const float* data) : dim{ w, h, d }, voxels(data, data + (size_t)w * h * d) {

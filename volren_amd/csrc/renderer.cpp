@@ -81,6 +81,8 @@ void RendererHIP::commit() {
 
 BrickGridHIP RendererHIP::grid_to_device(const Volume::GridPtr& grid) {
     if (auto f16 = std::dynamic_pointer_cast<DenseGridF16>(grid)) return dense_grid_to_device(f16);
+    if (gpu_encoder)
+        if (auto dense = std::dynamic_pointer_cast<DenseGrid>(grid)) return dense_to_bricks_on_device(dense);
     return brick_grid_to_device(Volume::to_brick_grid(grid));
 }
 
@@ -101,6 +103,65 @@ static void upload_range_words(BrickGridHIP& out, const uvec3 nb, const Buf3D<ui
     out.range_words = make_device_buffer(words.size() * sizeof(uint32_t));
     out.range_words->upload(words.data(), words.size() * sizeof(uint32_t));
     out.majorant = make_device_buffer(words.size() * sizeof(float));
+}
+
+BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseGrid>& g) {
+    BrickGridHIP out;
+    auto up8 = [](uint32_t v) { return ((v + 7u) / 8u + 7u) / 8u * 8u; };
+    const int32_t dim[3] = { (int32_t)g->dim.x, (int32_t)g->dim.y, (int32_t)g->dim.z };
+    const int32_t nb[3] = { (int32_t)up8(g->dim.x), (int32_t)up8(g->dim.y), (int32_t)up8(g->dim.z) };
+    const size_t n = (size_t)nb[0] * nb[1] * nb[2];
+    if (nb[0] > 1023 || nb[1] > 1023) throw std::runtime_error("dense_to_bricks_on_device: grid too large for 10-bit brick pointers");
+    for (int i = 0; i < 3; ++i) out.nb[i] = nb[i];
+    out.transform = g->transform;
+    DeviceBuffer dense(g->voxels.size() * sizeof(float)), flag(n * sizeof(uint32_t)), slot_of((n + 1) * sizeof(uint32_t));
+    dense.upload(g->voxels.data(), g->voxels.size() * sizeof(float), stream);
+    // range words of all mips in one buffer (mip m has ceil(nb / 2^m) cells per axis)
+    int32_t mdim[4][3];
+    size_t total = 0;
+    out.n_mips = 3;
+    for (int m = 0; m <= 3; ++m) {
+        for (int i = 0; i < 3; ++i) mdim[m][i] = (nb[i] + (1 << m) - 1) >> m;
+        out.mip_off[m] = (int32_t)total;
+        total += (size_t)mdim[m][0] * mdim[m][1] * mdim[m][2];
+    }
+    out.n_cells = (int32_t)total;
+    out.range_words = make_device_buffer(total * sizeof(uint32_t));
+    out.majorant = make_device_buffer(total * sizeof(float));
+    uint32_t* words = out.range_words->as<uint32_t>();
+    launch_encode_ranges(dense.as<float>(), dim, nb, words, flag.as<uint32_t>(), slot_of.as<uint32_t>(), stream);
+    VR_HIP(hipGetLastError());
+    uint32_t count = 0;
+    VR_HIP(hipMemcpyAsync(&count, slot_of.as<uint32_t>() + n, sizeof count, hipMemcpyDeviceToHost, stream));
+    VR_HIP(hipStreamSynchronize(stream));
+    const size_t per_layer = (size_t)nb[0] * nb[1];
+    const size_t layers = std::max<size_t>(1, (count + per_layer - 1) / per_layer);
+    if (layers > 1023) throw std::runtime_error("dense_to_bricks_on_device: grid too large for 10-bit brick pointers");
+    const size_t n_slots = per_layer * layers;                   // same atlas extent as the host encoder, + the zero slot
+    out.atlas = make_device_buffer((n_slots + 1) * 512);
+    VR_HIP(hipMemsetAsync(out.atlas->get(), 0, out.atlas->size_bytes(), stream));
+    out.bricks = make_device_buffer(n * sizeof(BrickRec));
+    launch_encode_bricks(dense.as<float>(), dim, nb, words, flag.as<uint32_t>(), slot_of.as<uint32_t>(), out.bricks->as<BrickRec>(), out.atlas->as<uint8_t>(), stream);
+    for (int m = 1; m <= 3; ++m) launch_range_mip(words + out.mip_off[m - 1], mdim[m - 1], words + out.mip_off[m], mdim[m], stream);
+    VR_HIP(hipGetLastError());
+    VR_HIP(hipStreamSynchronize(stream));
+    return out;
+}
+
+static uint64_t fnv1a(const std::vector<uint8_t>& v) {
+    uint64_t h = 1469598103934665603ull;
+    for (uint8_t b : v) { h ^= b; h *= 1099511628211ull; }
+    return h;
+}
+void RendererHIP::grid_checksums(const BrickGridHIP& g, uint64_t out[3]) const {
+    const DeviceBufferPtr bufs[3] = { g.bricks, g.atlas, g.range_words };
+    for (int i = 0; i < 3; ++i) {
+        out[i] = 0;
+        if (!bufs[i]) continue;
+        std::vector<uint8_t> h(bufs[i]->size_bytes());
+        bufs[i]->download(h.data(), h.size(), stream);
+        out[i] = fnv1a(h);
+    }
 }
 
 BrickGridHIP RendererHIP::dense_grid_to_device(const std::shared_ptr<DenseGridF16>& g) {

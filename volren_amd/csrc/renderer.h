@@ -60,6 +60,9 @@ struct RendererHIP {
     BrickGridHIP brick_grid_to_device(const std::shared_ptr<BrickGrid>& grid);
     BrickGridHIP dense_grid_to_device(const std::shared_ptr<DenseGridF16>& grid);
     BrickGridHIP grid_to_device(const Volume::GridPtr& grid);      // dense fp16 stays dense, everything else becomes bricks
+    BrickGridHIP dense_to_bricks_on_device(const std::shared_ptr<DenseGrid>& grid);   // to_brick_grid + upload, all on the GPU
+    bool gpu_encoder = true;                                       // DenseGrid -> bricks on the device (false: host encoder)
+    void grid_checksums(const BrickGridHIP& g, uint64_t out[3]) const;   // FNV-1a of bricks / atlas / range words (tests)
     // scale and move volume to fit into [-0.5, 0.5] unit cube
     void scale_and_move_to_unit_cube();
 

@@ -29,6 +29,13 @@ void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipSt
 // (common.glsl:278-281, 425, 472)
 void launch_majorants(const SceneParams& P, const uint32_t* range_words_all_mips, int32_t n_cells, float* out, hipStream_t stream);
 
+// Dense -> brick encoder on the device (Volume::to_brick_grid / commit(), src/renderer.cpp:63); see vr_kernels.hip.
+// ranges: range[nb] (fp16x2 words), flag[nb] (needs an atlas block), slot_of[nb + 1] (exclusive scan, [nb] = block count)
+void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_t nb[3], uint32_t* range, uint32_t* flag, uint32_t* slot_of, hipStream_t stream);
+void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const uint32_t* range, const uint32_t* flag, const uint32_t* slot_of,
+                          BrickRec* recs, uint8_t* atlas, hipStream_t stream);
+void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream);
+
 // tonemap.glsl:29-36 in place
 void launch_tonemap(float* fb, int32_t w, int32_t h, float exposure, float gamma, hipStream_t stream);
 

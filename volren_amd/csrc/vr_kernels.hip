@@ -520,6 +520,111 @@ void launch_build_impmap(const float* envmap_rgba, int32_t env_w, int32_t env_h,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Dense -> brick encoder on the device (voldata's Volume::to_brick_grid, commit() step of the reference:
+// src/renderer.cpp:63).  Same rules, same arithmetic and same slot order as the host encoder in grids.cpp, so both
+// produce identical device arrays (tests compare checksums):
+//   1. encode_range_kernel : per brick, (min, max) over the brick dilated by 2 voxels, rounded outwards to fp16;
+//                            flag = the brick needs an atlas block (max != min)
+//   2. exclusive scan of the flags (brick index order = slot order)
+//   3. encode_brick_kernel : per brick, BrickRec + 512 quantised voxels straight into the brick-major atlas
+//   4. range_mip_kernel    : (min of mins, max of maxes) over 2x2x2 children, three levels
+__global__ void __launch_bounds__(256)
+encode_range_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int32_t nz, int32_t nbx, int32_t nby, int32_t nbz,
+                    uint32_t* __restrict__ range, uint32_t* __restrict__ flag) {
+    // one wavefront per brick: 12^3 = 1728 taps, 27 per lane
+    const int32_t brick = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (brick >= nbx * nby * nbz) return;
+    const int32_t bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
+    const int32_t x0 = bx * 8 - 2, y0 = by * 8 - 2, z0 = bz * 8 - 2;
+    float lo = inf_(), hi = -inf_();
+    if (x0 >= nx || y0 >= ny || z0 >= nz) { lo = hi = 0.0f; }
+    else
+        for (int32_t i = lane; i < 1728; i += 64) {
+            const int32_t x = x0 + i % 12, y = y0 + (i / 12) % 12, z = z0 + i / 144;
+            float v = 0.0f;
+            if (x >= 0 && y >= 0 && z >= 0 && x < nx && y < ny && z < nz) v = dense[((size_t)z * ny + y) * nx + x];
+            lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+        }
+    for (int32_t o = 32; o > 0; o >>= 1) {
+        const float l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    if (lane == 0) {
+        const uint32_t hlo = float_to_half_down(lo), hhi = float_to_half_up(hi);
+        range[brick] = hlo | (hhi << 16);
+        flag[brick] = half2float(hhi) != half2float(hlo) ? 1u : 0u;
+    }
+}
+// single-workgroup exclusive scan (brick counts are modest: 2M for a 1024^3 grid); out[n] = total
+__global__ void __launch_bounds__(1024)
+exclusive_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int32_t n) {
+    __shared__ uint32_t part[1024];
+    const int32_t per = (n + 1023) / 1024, b = threadIdx.x * per, e = min(n, b + per);
+    uint32_t sum = 0u;
+    for (int32_t i = b; i < e; ++i) sum += in[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t acc = 0u; for (int32_t i = 0; i < 1024; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; } out[n] = acc; }
+    __syncthreads();
+    uint32_t acc = part[threadIdx.x];
+    for (int32_t i = b; i < e; ++i) { out[i] = acc; acc += in[i]; }
+}
+__global__ void __launch_bounds__(64)
+encode_brick_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int32_t nz, int32_t nbx, int32_t nby,
+                    const uint32_t* __restrict__ range, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ slot_of,
+                    BrickRec* __restrict__ recs, uint8_t* __restrict__ atlas) {
+    const int32_t brick = blockIdx.x, lane = threadIdx.x;
+    const int32_t bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
+    const uint32_t rg = range[brick];
+    const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
+    const bool alloc = flag[brick] != 0u;
+    const uint32_t slot = alloc ? slot_of[brick] : 0u;       // bricks without a block point at slot 0 (indirection word 0)
+    if (lane == 0) { BrickRec r; r.slot = slot; r.rmin = lo; r.rdiff = hi - lo; r.range = rg; recs[brick] = r; }
+    if (!alloc) return;
+    const float inv = 255.0f / (hi - lo);
+    uint8_t* dst = atlas + (size_t)slot * 512u;
+    for (int32_t i = lane; i < 512; i += 64) {
+        const int32_t x = bx * 8 + (i & 7), y = by * 8 + ((i >> 3) & 7), z = bz * 8 + (i >> 6);
+        float v = 0.0f;
+        if (x < nx && y < ny && z < nz) v = dense[((size_t)z * ny + y) * nx + x];
+        float qv = floor_((v - lo) * inv + 0.5f);
+        qv = qv < 0.0f ? 0.0f : (qv > 255.0f ? 255.0f : qv);
+        dst[i] = (uint8_t)qv;
+    }
+}
+__global__ void __launch_bounds__(256)
+range_mip_kernel(const uint32_t* __restrict__ src, int32_t sx, int32_t sy, int32_t sz, uint32_t* __restrict__ dst, int32_t dx, int32_t dy, int32_t dz) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= dx * dy * dz) return;
+    const int32_t x = i % dx, y = (i / dx) % dy, z = i / (dx * dy);
+    float lo = inf_(), hi = -inf_(); uint32_t hlo = 0u, hhi = 0u;
+    for (int32_t c = 0; c < 8; ++c) {
+        const int32_t cx = 2 * x + (c & 1), cy = 2 * y + ((c >> 1) & 1), cz = 2 * z + (c >> 2);
+        if (cx >= sx || cy >= sy || cz >= sz) continue;
+        const uint32_t rg = src[((size_t)cz * sy + cy) * sx + cx];
+        const float l = half2float(rg & 0xFFFFu), h = half2float(rg >> 16);
+        if (l < lo) { lo = l; hlo = rg & 0xFFFFu; }
+        if (h > hi) { hi = h; hhi = rg >> 16; }
+    }
+    dst[i] = hlo | (hhi << 16);
+}
+
+void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_t nb[3], uint32_t* range, uint32_t* flag, uint32_t* slot_of, hipStream_t stream) {
+    const int32_t n = nb[0] * nb[1] * nb[2];
+    hipLaunchKernelGGL(encode_range_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], nb[2], range, flag);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, flag, slot_of, n);
+}
+void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const uint32_t* range, const uint32_t* flag, const uint32_t* slot_of,
+                          BrickRec* recs, uint8_t* atlas, hipStream_t stream) {
+    const int32_t n = nb[0] * nb[1] * nb[2];
+    hipLaunchKernelGGL(encode_brick_kernel, dim3(n), dim3(64), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], range, flag, slot_of, recs, atlas);
+}
+void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream) {
+    const int32_t n = ddim[0] * ddim[1] * ddim[2];
+    hipLaunchKernelGGL(range_mip_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, sdim[0], sdim[1], sdim[2], dst, ddim[0], ddim[1], ddim[2]);
+}
+
+// ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, int32_t n, float* __restrict__ out) {
     const int32_t i = blockIdx.x * 256 + threadIdx.x;

@@ -295,6 +295,44 @@ VR_HD float half2float(uint32_t h) {   // low 16 bits
     return u2f(s | ((e + 112u) << 23) | (m << 13));
 }
 
+// float -> binary16 conversions used by the brick encoders (range texture is RG16F; ranges are rounded outwards)
+VR_HD uint32_t float_to_half_rne(float f) {
+    const uint32_t x = f2u(f);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) return sign | 0x7C00u | ((ax > 0x7F800000u) ? 0x200u : 0u);
+    if (ax >= 0x477FF000u) return sign | 0x7C00u;              // overflow -> inf
+    if (ax < 0x33000001u) return sign;                          // underflow -> 0
+    const int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x007FFFFFu) | 0x00800000u;
+    int shift;
+    uint32_t h;
+    if (e < -14) { shift = 13 + (-14 - e); h = 0u; }            // subnormal half
+    else { shift = 13; h = (uint32_t)(e + 15) << 10; m &= 0x007FFFFFu; }
+    const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    uint32_t r = h + q;
+    if (rem > half || (rem == half && (r & 1u))) r += 1u;
+    return sign | r;
+}
+VR_HD uint32_t half_next_up(uint32_t h) {       // next representable towards +inf
+    if ((h & 0x7FFFu) == 0u) return 0x0001u;
+    return (h & 0x8000u) ? (h - 1u) & 0xFFFFu : (h + 1u) & 0xFFFFu;
+}
+VR_HD uint32_t half_next_down(uint32_t h) {
+    if ((h & 0x7FFFu) == 0u) return 0x8001u;
+    return (h & 0x8000u) ? (h + 1u) & 0xFFFFu : (h - 1u) & 0xFFFFu;
+}
+VR_HD uint32_t float_to_half_down(float f) {     // largest fp16 <= f
+    uint32_t h = float_to_half_rne(f);
+    if (half2float(h) > f) h = half_next_down(h);
+    return h;
+}
+VR_HD uint32_t float_to_half_up(float f) {       // smallest fp16 >= f
+    uint32_t h = float_to_half_rne(f);
+    if (half2float(h) < f) h = half_next_up(h);
+    return h;
+}
+
 // ---- small vectors ----
 struct v3 { float x, y, z; };
 VR_HD v3 V3(float x, float y, float z) { return v3{ x, y, z }; }
