@@ -72,35 +72,36 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 // Everything is wave-synchronous (ballots, mbcnt ranks, scalar counters): no atomics, no barriers, no spinning; the only
 // global atomic is the work-queue head.  Which lane runs which path never changes a result.
 #ifndef VR_NSLOT
-#define VR_NSLOT 144
+#define VR_NSLOT 136
 #endif
 constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
 
 constexpr int32_t NHOT = 15;
 enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
 
-struct HotStore {                      // [field][slot] dwords in LDS; lanes address different slots
+constexpr int32_t HOT_STRIDE = 17;     // dwords per slot in LDS: odd, so that lanes with different slots spread over the banks
+struct HotStore {                      // [slot][field]: a path's 15 parked dwords are adjacent (ds_read2/ds_write2 pairs)
     uint32_t* base;
-    // 15 dwords per parked path; mip (a multiple of 1/4 in [0,3]) rides in the flag word
+    // mip (a multiple of 1/4 in [0,3]) rides in the flag word
     __device__ __forceinline__ void save(const Hot& h, int32_t slot) const {
-        uint32_t* p = base + slot;
-        p[0 * NSLOT] = h.seed;
-        p[1 * NSLOT] = f2u(h.ipos.x); p[2 * NSLOT] = f2u(h.ipos.y); p[3 * NSLOT] = f2u(h.ipos.z);
-        p[4 * NSLOT] = f2u(h.idir.x); p[5 * NSLOT] = f2u(h.idir.y); p[6 * NSLOT] = f2u(h.idir.z);
-        p[7 * NSLOT] = f2u(h.t); p[8 * NSLOT] = f2u(h.far); p[9 * NSLOT] = f2u(h.tau);
-        p[10 * NSLOT] = f2u(h.Tr);
-        p[11 * NSLOT] = (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)(int32_t)(h.mip * 4.0f) << 16);
-        p[12 * NSLOT] = f2u(h.ri.x); p[13 * NSLOT] = f2u(h.ri.y); p[14 * NSLOT] = f2u(h.ri.z);
+        uint32_t* p = base + slot * HOT_STRIDE;
+        p[0] = h.seed;
+        p[1] = f2u(h.ipos.x); p[2] = f2u(h.ipos.y); p[3] = f2u(h.ipos.z);
+        p[4] = f2u(h.idir.x); p[5] = f2u(h.idir.y); p[6] = f2u(h.idir.z);
+        p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
+        p[10] = f2u(h.Tr);
+        p[11] = (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)(int32_t)(h.mip * 4.0f) << 16);
+        p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z);
     }
     __device__ __forceinline__ void load(Hot& h, int32_t slot) const {
-        const uint32_t* p = base + slot;
-        h.seed = p[0 * NSLOT];
-        h.ipos = v3{ u2f(p[1 * NSLOT]), u2f(p[2 * NSLOT]), u2f(p[3 * NSLOT]) };
-        h.idir = v3{ u2f(p[4 * NSLOT]), u2f(p[5 * NSLOT]), u2f(p[6 * NSLOT]) };
-        h.ri = v3{ u2f(p[12 * NSLOT]), u2f(p[13 * NSLOT]), u2f(p[14 * NSLOT]) };
-        h.t = u2f(p[7 * NSLOT]); h.far = u2f(p[8 * NSLOT]); h.tau = u2f(p[9 * NSLOT]);
-        h.Tr = u2f(p[10 * NSLOT]);
-        const uint32_t f = p[11 * NSLOT];
+        const uint32_t* p = base + slot * HOT_STRIDE;
+        h.seed = p[0];
+        h.ipos = v3{ u2f(p[1]), u2f(p[2]), u2f(p[3]) };
+        h.idir = v3{ u2f(p[4]), u2f(p[5]), u2f(p[6]) };
+        h.ri = v3{ u2f(p[12]), u2f(p[13]), u2f(p[14]) };
+        h.t = u2f(p[7]); h.far = u2f(p[8]); h.tau = u2f(p[9]);
+        h.Tr = u2f(p[10]);
+        const uint32_t f = p[11];
         h.state = (int32_t)(f & 0xFFu); h.shadow = (int32_t)((f >> 8) & 0xFFu);
         h.mip = (float)(f >> 16) * 0.25f;
         h.majorant = 0.0f;
@@ -127,8 +128,8 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     uint8_t* const q = lds_q + wave * (Q_COUNT * NSLOT);
     // per-wavefront slice of the workspace: the cold fields of its NSLOT paths
     float* const cold_base = cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)(C_STRIDE * NSLOT);
-    __shared__ uint32_t lds_hot[4 * NHOT * NSLOT];
-    const HotStore hs{ lds_hot + wave * (NHOT * NSLOT) };
+    __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NSLOT];
+    const HotStore hs{ lds_hot + wave * (HOT_STRIDE * NSLOT) };
 
     int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = NSLOT;     // stack heights (wave-uniform)
     for (int32_t i = lane; i < NSLOT; i += 64) q[Q_FREE * NSLOT + i] = (uint8_t)i;
