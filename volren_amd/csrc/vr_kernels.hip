@@ -1,11 +1,17 @@
 // vr_kernels.hip -- gfx950 kernels of the volume path tracer.
 //
-// pathtrace_kernel: one wavefront = one 8x8 pixel tile, one workgroup = 4 wavefronts = the reference's 16x16
-// work group (pathtracer_brick.glsl:3).  Each lane owns one pixel for the whole launch and runs ALL requested
-// samples for it (the reference issues one dispatch per sample, renderer.cpp:138-140).  The wavefront is driven
-// by a small scheduler: every iteration it counts lanes per state with ballots (scalar registers), then
-// executes the code of those states that enough lanes are waiting in -- see vr_trace.h for the state bodies.
-// No LDS, no cross-lane data exchange: lanes only vote.  MFMA is not used (there is no dense contraction).
+// pathtrace_kernel (the hot path): persistent wavefronts pull (8x8 pixel tile x 4 samples) work units from one global
+// counter; each wavefront keeps a private pool of more path slots than it has lanes, so that the frequent march/collide
+// code always finds lanes to fill and the rare, expensive events (new sample with the 32-round TEA hash, next-event
+// estimation, scatter, escape) run as near-full-width batches of parked paths.  The per-path code -- the reference's
+// trace_path and everything it calls, restated as a state machine -- is in vr_trace.h; this file is scheduling and launch.
+// Radiance per (pixel, sample) goes to a sample pool; accumulate_kernel folds it into the RGBA32F running mean in sample
+// order, which makes the result bit-identical to the reference's one-dispatch-per-sample loop (renderer.cpp:138-140,
+// pathtracer_brick.glsl:36).  MFMA is not used: there is no dense contraction on this path.
+//
+// Also here: the environment importance pyramid + warp table (env_setup.glsl, environment.cpp), the dense->brick encoder
+// (voldata to_brick_grid at commit()), majorant remap, tonemap.glsl, direct volume rendering (common.glsl:571-591),
+// tile pack/unpack for the multi-GPU gather, and a math probe for the tests.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -62,13 +68,14 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 // A wavefront owns NSLOT path slots, more than it has lanes.  The 64 lanes hold, in registers, the hot state of the
 // paths that are currently marching; every other path of the pool is parked: its hot state (NHOT dwords) sits in LDS
 // and its slot id in one of the wave's LDS stacks -- READY (may march), NEE / POSTNEE / ESCAPE (wait for that event),
-// FREE.  Cold path state lives in global memory ([wave][field][slot], L2 resident), it is only touched by the events.
-//   * a lane whose path reaches an event parks it (16 ds_write + a stack push) and immediately resumes a READY path,
-//     so the march/collide code runs with (nearly) all 64 lanes;
-//   * an event's code runs when a full-width batch of parked paths has piled up (or when the wave runs dry): lane i
-//     loads parked path i of the batch, runs the unchanged per-path code of vr_trace.h, stores it and routes the slot to
-//     the stack of its new state.  The marching lanes' registers are saved/restored around a batch phase (the lanes
-//     double as batch workers), which costs 32 LDS instructions per phase -- about 2 per sample.
+// FREE.  Cold path state lives in global memory (one 128-byte line per slot, L2 / Infinity Cache resident); only the
+// events touch it.
+//   * a lane whose path reaches an event parks it (ds_write2 pairs + a stack push) and immediately resumes a READY path,
+//     so the march/collide code runs with most lanes holding a path;
+//   * an event's code runs when a (nearly) full-width batch of parked paths has piled up, or -- when the wave runs dry --
+//     for its largest batch: lane i loads parked path i, runs the unchanged per-path code of vr_trace.h, stores it and
+//     routes the slot to the stack of its new state.  The lanes double as batch workers; the batch path lives in its own
+//     register set so the marching path stays put (VR_BATCH_REGS=0 swaps it through its LDS slot instead).
 // Everything is wave-synchronous (ballots, mbcnt ranks, scalar counters): no atomics, no barriers, no spinning; the only
 // global atomic is the work-queue head.  Which lane runs which path never changes a result.
 #ifndef VR_NSLOT
