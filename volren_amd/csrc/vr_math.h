@@ -61,6 +61,13 @@ VR_HD int32_t round_half_even(float x) {
     return (int32_t)r;
 }
 
+// round_half_even for the DDA mip, which is always a multiple of 1/4 in [0, 3]: 2-bit table lookup on q = 4*mip
+// (q: 0 1 2 3 4 5 6 7 8 9 10 11 12 -> 0 0 0 1 1 1 2 2 2 2 2 3 3; 0.5 and 2.5 round to the even neighbour)
+VR_HD int32_t round_mip(float mip) {
+    const uint32_t q = (uint32_t)(int32_t)(mip * 4.0f);
+    return (int32_t)((0x3EAA540u >> (2u * q)) & 3u);
+}
+
 VR_HD float scale2(float z, int n) {
     if (n > 254) n = 254;
     if (n < -252) n = -252;

@@ -172,7 +172,9 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
         const float k_ = rng_k(seed); \
         const float q_ = ((W) * 16777216.0f) * __builtin_amdgcn_rcpf(S); \
         const float m_ = abs_(q_) * 9.5367431640625e-07f; \
-        if (k_ < q_ - m_) J = V; else if (!(k_ > q_ + m_)) unsure = true; \
+        const bool yes_ = k_ < q_ - m_, no_ = k_ > q_ + m_; \
+        J = yes_ ? V : J; \
+        unsure = unsure | !(yes_ | no_); \
     } while (0)
     VR_TAP(jx, 1, ax.w2, ax.s2); VR_TAP(jy, 1, ay.w2, ay.s2); VR_TAP(jz, 1, az.w2, az.s2);
     VR_TAP(jx, 2, ax.w3, ax.s3); VR_TAP(jy, 2, ay.w3, ay.s3); VR_TAP(jz, 2, az.w3, az.s3);
@@ -331,7 +333,7 @@ VR_HD bool intersect_box(v3 pos, v3 dir, const float* bmin, const float* bmax, f
 // one DDA step on mip (common.glsl:404-409)
 VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
     const float dim = (float)(8 << mip);
-    const float idim = 1.0f / dim;
+    const float idim = u2f((uint32_t)(124 - mip) << 23);       // 1 / dim exactly (dim = 2^(3+mip)): no division
     const float ox = ri.x >= 0.0f ? dim + 0.5f : -0.5f;
     const float oy = ri.y >= 0.0f ? dim + 0.5f : -0.5f;
     const float oz = ri.z >= 0.0f ? dim + 0.5f : -0.5f;
@@ -423,7 +425,7 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
 VR_HD void do_march(Hot& h, const SceneParams& P) {
     if (!(h.t < h.far)) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
     const v3 curr = axpy(h.ipos, h.t, h.idir);
-    const int32_t m = round_half_even(h.mip);
+    const int32_t m = round_mip(h.mip);
     const float majorant = majorant_at(P.density, curr, m);
     const float dt = step_dda(curr, h.ri, m);
     h.t += dt;
