@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", help="c1 | c2 | c3 | readme | c4[:N] (synthetic N^3 dense fp16 grid, default 512)")
+    ap.add_argument("--config", default="c2", help="c1 | c2 | c3 | readme | c4[:N] (synthetic N^3 dense fp16 grid, default 512) | c5[:N] (synthetic sparse brick grid + emission)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=1024)
@@ -173,7 +173,7 @@ def main():
             cpu, counters = cpu_baseline_and_counters(args.config, w, h, args.cpu_budget)
         else:
             _, counters = cpu_baseline_and_counters(args.config, w, h, 0.5)
-        b_sample, events = algorithmic_bytes_per_sample(counters, spp, use_tf, False, dense=args.config.startswith("c4"))
+        b_sample, events = algorithmic_bytes_per_sample(counters, spp, use_tf, args.config.startswith("c5"), dense=args.config.startswith("c4"))
         my_samples = len(mine) * 256.0 * spp if world > 1 else samples_per_step
         launches = max(1, r.last_launches)                       # a frame is split so that a sub-launch fits the sample pool
         launch_ms = last_ms / launches                           # HIP events on the renderer's stream around the frame's launches
@@ -188,10 +188,10 @@ def main():
             "metric": "Msamples/s (pixels x spp / s), volume path tracing",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": ("synthetic dense fp16 grid (tests/scenes.py generator) + reference envmap" if args.config.startswith("c4") else
+            "vs_baseline": None, "dtype": "f32", "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else
                                       "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
             "config": {"workload": "BASELINE configs[%d] '%s': %s%s, %dx%d, %d spp, seed 42, fov 40" % (
-                {"c1": 0, "c2": 1, "c3": 2, "c4": 3}.get(args.config[:2], -1), args.config, "synthetic dense fp16 grid" if args.config.startswith("c4") else "smoke.brick", " + lut.txt" if use_tf else ", no transfer function", w, h, spp),
+                {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}.get(args.config[:2], -1), args.config, "synthetic dense fp16 grid" if args.config.startswith("c4") else ("synthetic sparse brick grid + temperature grid (emission)" if args.config.startswith("c5") else "smoke.brick"), " + lut.txt" if use_tf else ", no transfer function", w, h, spp),
                 "parallelism": "tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame" % world if world > 1 else "1 GPU, 1 fused launch/frame"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "pathtrace_kernel<%s,false>" % ("true" if use_tf else "false"),

@@ -60,7 +60,52 @@ def configure_dense(r, is_oracle, n=512):
     return r
 
 
+def synthetic_sparse_pair(n=512, seed=4321):
+    """BASELINE configs[4] generator: cloud-like sparse density (~15 % of the voxels non-zero, max 5.0) and a temperature
+    grid correlated with it, float32 [z][y][x]."""
+    from scipy import ndimage
+    coarse = max(32, n // 4)
+    base = synthetic_density(coarse, seed=seed, blobs=48).astype(np.float32)
+    det = synthetic_density(coarse, seed=seed + 1, blobs=96).astype(np.float32)
+    dens = np.maximum(base - np.quantile(base, 0.85 - 0.25) * 0 - 0.35 * base.max(), 0)     # keep the cores of the blobs
+    temp = np.maximum(dens * 0.6 + 0.2 * det * (dens > 0), 0)
+    if coarse != n:
+        z = n / coarse
+        dens = ndimage.zoom(dens, z, order=1, mode="nearest", prefilter=False)[:n, :n, :n]
+        temp = ndimage.zoom(temp, z, order=1, mode="nearest", prefilter=False)[:n, :n, :n]
+    dens = np.ascontiguousarray(np.clip(dens, 0, None) * np.float32(5.0 / max(float(dens.max()), 1e-6)), np.float32)
+    temp = np.ascontiguousarray(np.clip(temp, 0, None) * np.float32(1.0 / max(float(temp.max()), 1e-6)), np.float32)
+    return dens, temp
+
+
+def configure_sparse(r, is_oracle, n=512):
+    """BASELINE configs[4] ('c5'): synthetic sparse brick grid + temperature grid, emission on (common.glsl:324-328,489)."""
+    key = ("c5", n)
+    if key not in _DENSE_CACHE:
+        _DENSE_CACHE[key] = synthetic_sparse_pair(n)
+    dens, temp = _DENSE_CACHE[key]
+    if is_oracle:
+        import encoder_ref
+        gd, gt = encoder_ref.encode(dens), encoder_ref.encode(temp)
+        for g in (gd, gt):                          # an in-memory dense grid keeps its voxel extent (see grid_to_device)
+            g.extent = (n, n, n)
+            g.c.extent[:] = g.extent
+        r.set_volume(gd, emission=gt, majorant_emission=float(temp.max()))
+    else:
+        r.set_volume_dense(dens, commit=False)
+        r.set_volume_dense(temp, name="temperature", commit=True)
+    r.load_envmap(HDR)
+    r.bounces, r.cam_fov = 128, 40.0
+    r.albedo = (0.9, 0.9, 0.9)
+    r.phase = 0.3
+    r.density_scale = 100.0
+    r.emission_scale = 100.0
+    return r
+
+
 def configure(r, name, is_oracle):
+    if name.startswith("c5"):
+        return configure_sparse(r, is_oracle, int(name[3:]) if len(name) > 3 else 512)
     if name.startswith("c4"):
         return configure_dense(r, is_oracle, int(name[3:]) if len(name) > 3 else 512)
     """Apply a config in the reference's command-line order (paths first, then overrides: main.cpp:360-435)."""

@@ -435,3 +435,15 @@ def test_gpu_dense_to_brick_encoder_equals_host_encoder():
     g.c.extent[:] = g.extent
     o.cam_fov, o.bounces = 40.0, 8
     _assert_same(fb, o.render(6), "gpu-encoded dense grid")
+
+
+@pytest.mark.parametrize("name", ["c4:64", "c5:64"])
+def test_synthetic_baseline_configs_small(name):
+    """BASELINE configs[3] / [4] at a size the oracle finishes in seconds: dense fp16 grid (c4) and sparse brick grid +
+    temperature grid with emission through the device encoder (c5)."""
+    o = scenes.oracle_scene(name, 72, 56)
+    r = scenes.hip_scene(name, 72, 56)
+    r.render(4)
+    fb = r.framebuffer()
+    assert fb[..., :3].max() > 0
+    _assert_same(fb, o.render(4), name)
