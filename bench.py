@@ -52,9 +52,16 @@ def cpu_baseline_and_counters(config, w, h, budget_s):
     from oracle import binding as ob
     cw = ch = 512
     o = scenes.oracle_scene(config, cw, ch)
-    t0 = time.time()
-    o.render(1)
-    rate = cw * ch / max(time.time() - t0, 1e-6)
+    o.render(1)                                          # library load, thread pool start
+    probe = 1
+    while True:                                          # probe long enough (>= 1 s) that burst clocks / quotas do not skew the estimate
+        t0 = time.time()
+        o.render(probe)
+        dt = time.time() - t0
+        if dt >= min(1.0, budget_s) or probe >= 1024:
+            break
+        probe *= 2
+    rate = cw * ch * probe / max(dt, 1e-6)
     spp = int(max(1, min(4096, budget_s * rate / (cw * ch))))
     o2 = scenes.oracle_scene(config, cw, ch)
     t0 = time.time()
