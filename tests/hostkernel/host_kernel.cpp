@@ -30,30 +30,39 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
         for (uint32_t z = 0; z < 8; ++z) for (uint32_t y = 0; y < 8; ++y)
             memcpy(&g.atlas[(((size_t)pz * sy + py) * sx + px) * 512 + z * 64 + y * 8],
                    atlas + (((size_t)(pz * 8 + z) * ad[1] + (py * 8 + y)) * ad[0] + px * 8), 8);
-    g.recs.resize(n);
+    for (int i = 0; i < 2; ++i) g.view.bshift[i] = ceil_log2(nb[i]);
+    for (int i = 0; i < 3; ++i) g.view.mshift[i] = ceil_log2(nb[i]) < 3 ? 3 : ceil_log2(nb[i]);
+    g.recs.assign((size_t)nb[2] << (g.view.bshift[0] + g.view.bshift[1]), BrickRec{ 0u, 0.f, 0.f, 0u });
     for (size_t i = 0; i < n; ++i) {
         const uint32_t ind = indirection[i], rg = range[i];
         const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
         const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
-        g.recs[i].slot = (px < sx && py < sy && pz < sz) ? (uint32_t)(((size_t)pz * sy + py) * sx + px) : (uint32_t)slots;
-        g.recs[i].rmin = lo; g.recs[i].rdiff = hi - lo; g.recs[i].range = rg;
+        const size_t bx = i % nb[0], by = (i / nb[0]) % nb[1], bz = i / ((size_t)nb[0] * nb[1]);
+        BrickRec& r = g.recs[(((bz << g.view.bshift[1]) + by) << g.view.bshift[0]) + bx];      // == brick_grid_to_device
+        r.slot = (px < sx && py < sy && pz < sz) ? (uint32_t)(((size_t)pz * sy + py) * sx + px) : (uint32_t)slots;
+        r.rmin = lo; r.rdiff = hi - lo; r.range = rg;
     }
     std::vector<uint32_t> words(range, range + n);
-    g.view.mip_off[0] = 0;
-    for (int m = 1; m <= 3; ++m) g.view.mip_off[m] = 0;
+    uint32_t mip_off[4] = { 0u, 0u, 0u, 0u };
     for (int m = 1; m <= n_mips; ++m) {
         const uint32_t rnd = (1u << m) - 1u;
         const size_t cnt = (size_t)((nb[0] + rnd) >> m) * ((nb[1] + rnd) >> m) * ((nb[2] + rnd) >> m);
-        g.view.mip_off[m] = (int32_t)words.size();
+        mip_off[m] = (uint32_t)words.size();
         words.insert(words.end(), mips[m - 1], mips[m - 1] + cnt);
     }
-    g.majorant.resize(words.size());
+    const uint32_t k = (uint32_t)(g.view.mshift[0] + g.view.mshift[1] + g.view.mshift[2]);
+    g.majorant.assign(majorant_padded_cells(k), 0.0f);
     if (density) {
         SceneParams P{}; P.u = u; P.tf_lut = lut;
-        for (size_t i = 0; i < words.size(); ++i) {          // == majorant_kernel of vr_kernels.hip
-            float m = u.vol_density_scale * half2float(words[i] >> 16);
-            if (u.use_tf) { float rgba[4]; tf_lookup(P, m * u.vol_inv_majorant, rgba); m = u.vol_majorant * rgba[3]; }
-            g.majorant[i] = m;
+        for (int mip = 0; mip <= n_mips; ++mip) {            // == majorant_kernel of vr_kernels.hip
+            const uint32_t rnd = (1u << mip) - 1u;
+            const uint32_t dx = (nb[0] + rnd) >> mip, dy = (nb[1] + rnd) >> mip, dz = (nb[2] + rnd) >> mip;
+            const uint32_t sxm = (uint32_t)g.view.mshift[0] - mip, sym = (uint32_t)g.view.mshift[1] - mip;
+            for (uint32_t cz = 0; cz < dz; ++cz) for (uint32_t cy = 0; cy < dy; ++cy) for (uint32_t cx = 0; cx < dx; ++cx) {
+                float m = u.vol_density_scale * half2float(words[mip_off[mip] + ((size_t)cz * dy + cy) * dx + cx] >> 16);
+                if (u.use_tf) { float rgba[4]; tf_lookup(P, m * u.vol_inv_majorant, rgba); m = u.vol_majorant * rgba[3]; }
+                g.majorant[majorant_level_offset(k, mip) + (((cz << sym) + cy) << sxm) + cx] = m;
+            }
         }
     }
     g.view.bricks = g.recs.data(); g.view.atlas = g.atlas.data(); g.view.majorant = g.majorant.data();

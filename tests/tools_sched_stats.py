@@ -6,7 +6,7 @@ w=h=int(sys.argv[2]) if len(sys.argv)>2 else 512
 spp=int(sys.argv[3]) if len(sys.argv)>3 else 64
 thr = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv)>4 else None
 r = scenes.hip_scene(cfg,w,h)
-if thr: va.set_sched(thr+[0])
+if thr: va.set_sched(thr+[0]*(8-len(thr)))
 r.render(spp); r.reset()
 va.sched_stats(True)
 r.render(spp); ms=r.last_kernel_ms()

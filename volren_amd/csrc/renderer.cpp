@@ -86,6 +86,17 @@ BrickGridHIP RendererHIP::grid_to_device(const Volume::GridPtr& grid) {
     return brick_grid_to_device(Volume::to_brick_grid(grid));
 }
 
+// power-of-two pitches of the brick records and of the majorant levels (vr_scene.h)
+static void set_layout(BrickGridHIP& out) {
+    for (int i = 0; i < 2; ++i) out.bshift[i] = ceil_log2((uint32_t)out.nb[i]);
+    for (int i = 0; i < 3; ++i) out.mshift[i] = std::max(3, ceil_log2((uint32_t)out.nb[i]));
+    if (out.mshift[0] + out.mshift[1] + out.mshift[2] > 30 || out.bshift[0] + out.bshift[1] + ceil_log2((uint32_t)out.nb[2]) > 30)
+        throw std::runtime_error("grid upload: more than 2^30 bricks after padding");
+    const size_t cells = majorant_padded_cells((uint32_t)(out.mshift[0] + out.mshift[1] + out.mshift[2]));
+    out.majorant = make_device_buffer(cells * sizeof(float));
+}
+static size_t padded_brick_records(const BrickGridHIP& g) { return (size_t)g.nb[2] << (g.bshift[0] + g.bshift[1]); }
+
 static void upload_range_words(BrickGridHIP& out, const uvec3 nb, const Buf3D<uint32_t>& range, const std::vector<Buf3D<uint32_t>>& mips) {
     if (mips.size() > 3) throw std::runtime_error("grid upload: at most 3 range mips are supported");
     std::vector<uint32_t> words(range.data);
@@ -102,7 +113,7 @@ static void upload_range_words(BrickGridHIP& out, const uvec3 nb, const Buf3D<ui
     out.n_cells = (int32_t)words.size();
     out.range_words = make_device_buffer(words.size() * sizeof(uint32_t));
     out.range_words->upload(words.data(), words.size() * sizeof(uint32_t));
-    out.majorant = make_device_buffer(words.size() * sizeof(float));
+    set_layout(out);
 }
 
 BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseGrid>& g) {
@@ -127,7 +138,7 @@ BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseG
     }
     out.n_cells = (int32_t)total;
     out.range_words = make_device_buffer(total * sizeof(uint32_t));
-    out.majorant = make_device_buffer(total * sizeof(float));
+    set_layout(out);
     uint32_t* words = out.range_words->as<uint32_t>();
     launch_encode_ranges(dense.as<float>(), dim, nb, words, flag.as<uint32_t>(), slot_of.as<uint32_t>(), stream);
     VR_HIP(hipGetLastError());
@@ -140,8 +151,9 @@ BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseG
     const size_t n_slots = per_layer * layers;                   // same atlas extent as the host encoder, + the zero slot
     out.atlas = make_device_buffer((n_slots + 1) * 512);
     VR_HIP(hipMemsetAsync(out.atlas->get(), 0, out.atlas->size_bytes(), stream));
-    out.bricks = make_device_buffer(n * sizeof(BrickRec));
-    launch_encode_bricks(dense.as<float>(), dim, nb, words, flag.as<uint32_t>(), slot_of.as<uint32_t>(), out.bricks->as<BrickRec>(), out.atlas->as<uint8_t>(), stream);
+    out.bricks = make_device_buffer(padded_brick_records(out) * sizeof(BrickRec));
+    VR_HIP(hipMemsetAsync(out.bricks->get(), 0, out.bricks->size_bytes(), stream));
+    launch_encode_bricks(dense.as<float>(), dim, nb, out.bshift, words, flag.as<uint32_t>(), slot_of.as<uint32_t>(), out.bricks->as<BrickRec>(), out.atlas->as<uint8_t>(), stream);
     for (int m = 1; m <= 3; ++m) launch_range_mip(words + out.mip_off[m - 1], mdim[m - 1], words + out.mip_off[m], mdim[m], stream);
     VR_HIP(hipGetLastError());
     VR_HIP(hipStreamSynchronize(stream));
@@ -169,6 +181,7 @@ BrickGridHIP RendererHIP::dense_grid_to_device(const std::shared_ptr<DenseGridF1
     const uvec3 nb = g->range.stride;
     out.nb[0] = (int)nb.x; out.nb[1] = (int)nb.y; out.nb[2] = (int)nb.z;
     out.dim[0] = (int)g->dim.x; out.dim[1] = (int)g->dim.y; out.dim[2] = (int)g->dim.z;
+    if (g->dim.x > 65535u || g->dim.y > 65535u || g->dim.z > 65535u) throw std::runtime_error("dense_grid_to_device: more than 65535 voxels along an axis");
     out.transform = g->transform;
     out.dense = make_device_buffer(g->voxels.size() * sizeof(uint16_t));
     out.dense->upload(g->voxels.data(), g->voxels.size() * sizeof(uint16_t));
@@ -198,7 +211,8 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
                     for (uint32_t y = 0; y < 8; ++y)
                         memcpy(dst + z * 64 + y * 8, &g->atlas.data[g->atlas.index(px * 8, py * 8 + y, pz * 8 + z)], 8);
             }
-    std::vector<BrickRec> recs(n_bricks);
+    upload_range_words(out, nb, g->range, g->range_mipmaps);        // also fixes the padded layout (bshift, mshift)
+    std::vector<BrickRec> recs(padded_brick_records(out), BrickRec{ 0u, 0.f, 0.f, 0u });
     for (size_t i = 0; i < n_bricks; ++i) {
         const uint32_t ind = g->indirection.data[i], rg = g->range.data[i];
         const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
@@ -208,9 +222,9 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
         r.rmin = lo;
         r.rdiff = hi - lo;
         r.range = rg;
-        recs[i] = r;
+        const size_t bx = i % nb.x, by = (i / nb.x) % nb.y, bz = i / ((size_t)nb.x * nb.y);
+        recs[(((bz << out.bshift[1]) + by) << out.bshift[0]) + bx] = r;
     }
-    upload_range_words(out, nb, g->range, g->range_mipmaps);
     out.bricks = make_device_buffer(recs.size() * sizeof(BrickRec));
     out.bricks->upload(recs.data(), recs.size() * sizeof(BrickRec));
     out.atlas = make_device_buffer(atlas.size());
@@ -246,7 +260,8 @@ static GridView make_view(const BrickGridHIP& g) {
     for (int i = 0; i < 3; ++i) v.dim[i] = g.dim[i];
     v.majorant = g.majorant->as<float>();
     for (int i = 0; i < 3; ++i) v.nb[i] = g.nb[i];
-    for (int i = 0; i < 4; ++i) v.mip_off[i] = g.mip_off[i];
+    for (int i = 0; i < 2; ++i) v.bshift[i] = g.bshift[i];
+    for (int i = 0; i < 3; ++i) v.mshift[i] = g.mshift[i];
     v.n_mips = g.n_mips;
     return v;
 }
@@ -334,7 +349,7 @@ void RendererHIP::update_majorants(const SceneParams& P, BrickGridHIP& g) {
     if (k.density_scale == maj_key_.density_scale && k.tf == maj_key_.tf && k.tf_version == maj_key_.tf_version &&
         k.wl == maj_key_.wl && k.ww == maj_key_.ww && k.frame == maj_key_.frame)
         return;
-    launch_majorants(P, g.range_words->as<uint32_t>(), g.n_cells, g.majorant->as<float>(), stream);
+    launch_majorants(P, g.range_words->as<uint32_t>(), g.nb, g.mip_off, g.n_mips, g.mshift, g.majorant->as<float>(), stream);
     VR_HIP(hipGetLastError());
     maj_key_ = k;
 }

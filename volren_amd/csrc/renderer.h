@@ -34,13 +34,15 @@ struct BrickGridHIP {
     DeviceBufferPtr bricks;        // BrickRec per brick
     DeviceBufferPtr atlas;         // brick-major u8 voxels, 512 B per slot
     DeviceBufferPtr range_words;   // fp16x2 range of every cell of mips 0..n_mips (input of the majorant kernel)
-    DeviceBufferPtr majorant;      // effective majorants (float), same indexing as range_words
+    DeviceBufferPtr majorant;      // effective majorants (float), padded power-of-two layout (vr_scene.h)
     DeviceBufferPtr dense;         // dense fp16 voxels (DenseGridF16), then bricks/atlas are empty
     int32_t dim[3] = { 0, 0, 0 };
     int32_t nb[3] = { 0, 0, 0 };
-    int32_t mip_off[4] = { 0, 0, 0, 0 };
+    int32_t mip_off[4] = { 0, 0, 0, 0 };   // word offset of each level inside range_words (compact)
     int32_t n_mips = 0;
-    int32_t n_cells = 0;
+    int32_t n_cells = 0;                   // words in range_words
+    int32_t bshift[2] = { 0, 0 };          // power-of-two pitches of `bricks` and padded extent of `majorant` (vr_scene.h)
+    int32_t mshift[3] = { 3, 3, 3 };
     mat4 transform;
 };
 

@@ -27,12 +27,13 @@ void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipSt
 // effective majorant of every cell of every range mip:
 //   m = density_scale * float(range.y);  with a LUT: m = vol_majorant * tf_lookup(m * vol_inv_majorant).a
 // (common.glsl:278-281, 425, 472)
-void launch_majorants(const SceneParams& P, const uint32_t* range_words_all_mips, int32_t n_cells, float* out, hipStream_t stream);
+void launch_majorants(const SceneParams& P, const uint32_t* range_words_all_mips, const int32_t nb[3], const int32_t mip_off[4], int32_t n_mips,
+                      const int32_t mshift[3], float* out_padded, hipStream_t stream);
 
 // Dense -> brick encoder on the device (Volume::to_brick_grid / commit(), src/renderer.cpp:63); see vr_kernels.hip.
 // ranges: range[nb] (fp16x2 words), flag[nb] (needs an atlas block), slot_of[nb + 1] (exclusive scan, [nb] = block count)
 void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_t nb[3], uint32_t* range, uint32_t* flag, uint32_t* slot_of, hipStream_t stream);
-void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const uint32_t* range, const uint32_t* flag, const uint32_t* slot_of,
+void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const int32_t bshift[2], const uint32_t* range, const uint32_t* flag, const uint32_t* slot_of,
                           BrickRec* recs, uint8_t* atlas, hipStream_t stream);
 void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream);
 

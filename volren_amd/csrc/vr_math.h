@@ -28,6 +28,14 @@ constexpr float kPiO4 = 0.7853981633974483096f;
 constexpr float kInv4Pi = 1.0f / (4.0f * kPi);   // common.glsl:7
 constexpr int32_t kIntMin = INT32_MIN;
 
+// a * b for a, b < 2^24 whose product fits 32 bits (full-rate v_mul_u32_u24 on the device)
+VR_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
 VR_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 VR_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 

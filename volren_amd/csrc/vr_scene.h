@@ -14,12 +14,30 @@ namespace vr {
 // replaces the indirection (RGB10_A2UI) + range + 3D-atlas texture triple of common.glsl:268-275.
 struct alignas(16) BrickRec { uint32_t slot; float rmin; float rdiff; uint32_t range; };
 
+#if defined(__HIPCC__)
+#define VR_SCENE_HD __host__ __device__ inline
+#else
+#define VR_SCENE_HD inline
+#endif
+
+// Index arithmetic of the hot loops is shifts only: brick records and majorant cells are stored with power-of-two
+// pitches.
+//   brick record of brick (bx, by, bz):  (((bz << bshift[1]) + by) << bshift[0]) + bx,  2^bshift[i] >= nb[i]
+//   majorant of cell (cx, cy, cz) of mip m:  level_offset(m) + (((cz << (mshift[1] - m)) + cy) << (mshift[0] - m)) + cx,
+//     level 0 has 2^mshift[i] >= max(nb[i], 8) cells per axis, every level half of that; cells beyond the real
+//     ceil(nb / 2^m) hold 0 (= "outside the grid reads 0"), so the whole padded extent may be indexed
+VR_SCENE_HD int32_t ceil_log2(uint32_t v) { int32_t s = 0; while (s < 31 && (1u << s) < v) ++s; return s; }
+// offset of level m = S0 * (0, 1, 9/8, 73/64)[m], S0 = 2^k cells on level 0 (k >= 9)
+VR_SCENE_HD uint32_t majorant_level_offset(uint32_t k, uint32_t mip) { const uint32_t s = 9u - 3u * mip; return ((0x49u >> s) << s) << (k - 6u); }
+VR_SCENE_HD size_t majorant_padded_cells(uint32_t k) { return (size_t)majorant_level_offset(k, 3u) + ((size_t)1 << (k - 9u)); }
+
 struct GridView {
-    const BrickRec* bricks;      // n_bricks.x*y*z, x fastest
+    const BrickRec* bricks;      // nb[2] << (bshift[0] + bshift[1]) records, power-of-two pitches (see above)
     const uint8_t* atlas;        // slots * 512 bytes, voxel (x&7) + 8*(y&7) + 64*(z&7)
-    const float* majorant;       // all mips, flat: "effective" majorant = density_scale * range.y, TF-remapped when a LUT is bound
+    const float* majorant;       // all mips, padded (see above): "effective" majorant = density_scale * range.y, TF-remapped when a LUT is bound
     int32_t nb[3];               // bricks per axis (mip 0); mip m has ceil(nb / 2^m) cells per axis
-    int32_t mip_off[4];          // float offset of each mip level inside `majorant`
+    int32_t bshift[2];           // log2 of the brick-record pitches (x, y)
+    int32_t mshift[3];           // log2 of the padded level-0 majorant extent per axis (each >= 3)
     int32_t n_mips;              // range mips available above level 0 (reference: 3)
     const uint16_t* dense;       // dense fp16 voxels [z][y][x] (then bricks/atlas are unused), or nullptr
     int32_t dim[3];              // voxel extent of the dense grid

@@ -99,27 +99,26 @@ VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
     if ((x | y | z) < 0) return 0.0f;
     if (g.dense) {          // dense fp16 grid: one 2-byte load, no indirection
         if ((uint32_t)x >= (uint32_t)g.dim[0] || (uint32_t)y >= (uint32_t)g.dim[1] || (uint32_t)z >= (uint32_t)g.dim[2]) return 0.0f;
-        return half2float(g.dense[((size_t)z * (uint32_t)g.dim[1] + (uint32_t)y) * (uint32_t)g.dim[0] + (uint32_t)x]);
+        return half2float(g.dense[(size_t)(mul24((uint32_t)z, (uint32_t)g.dim[1]) + (uint32_t)y) * (uint32_t)g.dim[0] + (uint32_t)x]);   // dims < 2^16
     }
     const uint32_t bx = (uint32_t)x >> 3, by = (uint32_t)y >> 3, bz = (uint32_t)z >> 3;
     if (bx >= (uint32_t)g.nb[0] || by >= (uint32_t)g.nb[1] || bz >= (uint32_t)g.nb[2]) return 0.0f;
-    const BrickRec rec = g.bricks[(bz * (uint32_t)g.nb[1] + by) * (uint32_t)g.nb[0] + bx];
+    const BrickRec rec = g.bricks[(((bz << g.bshift[1]) + by) << g.bshift[0]) + bx];
     const uint32_t b = g.atlas[(size_t)rec.slot * 512u + ((((uint32_t)z & 7u) << 6) | (((uint32_t)y & 7u) << 3) | ((uint32_t)x & 7u))];
     return rec.rmin + unorm8(b) * rec.rdiff;
 }
 VR_HD float majorant_at(const GridView& g, v3 ipos, int32_t mip) {
-    // cell = floor(ipos) >> (3 + mip); outside [0, cells) (or NaN) reads 0.  The range test is done on the floats
-    // (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails both), after which truncation equals floor.
+    // cell = floor(ipos) >> (3 + mip); outside the grid (or NaN) reads 0.  The padded layout (vr_scene.h) holds 0 in every
+    // cell beyond the real extent of a level, so only the padded extent -- the same for all levels -- is tested, on the
+    // floats (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails), after which truncation equals floor.
     if (mip > g.n_mips) return 0.0f;
-    const uint32_t sh = 3u + (uint32_t)mip;
-    const uint32_t rnd = (1u << mip) - 1u;
-    const uint32_t dx = ((uint32_t)g.nb[0] + rnd) >> mip, dy = ((uint32_t)g.nb[1] + rnd) >> mip, dz = ((uint32_t)g.nb[2] + rnd) >> mip;
-    const float lx = (float)(dx << sh), ly = (float)(dy << sh), lz = (float)(dz << sh);
+    const float lx = (float)(8u << g.mshift[0]), ly = (float)(8u << g.mshift[1]), lz = (float)(8u << g.mshift[2]);
     if (!(ipos.x >= 0.0f && ipos.x < lx && ipos.y >= 0.0f && ipos.y < ly && ipos.z >= 0.0f && ipos.z < lz)) return 0.0f;
+    const uint32_t sh = 3u + (uint32_t)mip;
     const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
-    // lane-varying mip: select the level offset instead of indexing the kernel-argument array
-    const int32_t off = mip == 0 ? g.mip_off[0] : (mip == 1 ? g.mip_off[1] : (mip == 2 ? g.mip_off[2] : g.mip_off[3]));
-    return g.majorant[(uint32_t)off + (bz * dy + by) * dx + bx];
+    const uint32_t sx = (uint32_t)g.mshift[0] - (uint32_t)mip, sy = (uint32_t)g.mshift[1] - (uint32_t)mip;
+    const uint32_t off = majorant_level_offset((uint32_t)(g.mshift[0] + g.mshift[1] + g.mshift[2]), (uint32_t)mip);
+    return g.majorant[off + (((bz << sy) + by) << sx) + bx];
 }
 VR_HD int32_t offs_i(int32_t base, int32_t o) { return base == kIntMin ? kIntMin : base + o; }
 
