@@ -96,7 +96,7 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         p[4] = f2u(h.idir.x); p[5] = f2u(h.idir.y); p[6] = f2u(h.idir.z);
         p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
         p[10] = f2u(h.Tr);
-        p[11] = (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)(int32_t)(h.mip * 4.0f) << 16);
+        p[11] = (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)h.mipq << 16);
         p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z);
     }
     __device__ __forceinline__ void load(Hot& h, int32_t slot) const {
@@ -109,7 +109,7 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         h.Tr = u2f(p[10]);
         const uint32_t f = p[11];
         h.state = (int32_t)(f & 0xFFu); h.shadow = (int32_t)((f >> 8) & 0xFFu);
-        h.mip = (float)(f >> 16) * 0.25f;
+        h.mipq = (int32_t)(f >> 16);
         h.majorant = 0.0f;
     }
 };
@@ -119,6 +119,7 @@ struct ColdGlobal {                    // one 128-byte line per path slot in thi
     __device__ __forceinline__ void st(int32_t f, float v) { static_cast<float*>(__builtin_assume_aligned(base, 128))[f] = v; }
 };
 
+__device__ __forceinline__ int32_t popc(uint64_t mask) { return (int32_t)__popcll(mask); }     // int: min(long long, int) would go through double
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -160,7 +161,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
 // push the slots of all lanes where COND holds onto stack QI (wave-synchronous)
 #define VR_PUSH(QI, CNT, COND, SLOTV) do { \
         const uint64_t m_ = __ballot(COND); \
-        if (m_) { if (COND) q[(QI) * NSLOT + (CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(SLOTV); (CNT) += __popcll(m_); } \
+        if (m_) { if (COND) q[(QI) * NSLOT + (CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(SLOTV); (CNT) += popc(m_); } \
     } while (0)
 
 // route the batch paths to the stack of their new state; an impossible state is reported and the slot recycled
@@ -188,7 +189,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
         // (1) idle lanes resume READY paths
         {
             const uint64_t idle = __ballot(slot < 0);
-            const int32_t take = min(__popcll(idle), cnt_ready);
+            const int32_t take = min(popc(idle), cnt_ready);
             if (take > 0) {
                 if (slot < 0) {
                     const int32_t r = (int32_t)lane_rank(idle);
@@ -197,17 +198,17 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                 cnt_ready -= take;
             }
         }
-        if (STATS) { occ[0] += (unsigned)__popcll(__ballot(slot >= 0)); occ[1] += (unsigned)cnt_ready; occ[2] += (unsigned)cnt_nee; occ[3] += (unsigned)cnt_post; occ[4] += (unsigned)cnt_esc; occ[5] += (unsigned)cnt_free; }
+        if (STATS) { occ[0] += (unsigned)popc(__ballot(slot >= 0)); occ[1] += (unsigned)cnt_ready; occ[2] += (unsigned)cnt_nee; occ[3] += (unsigned)cnt_post; occ[4] += (unsigned)cnt_esc; occ[5] += (unsigned)cnt_free; }
         // (2) the hot pair: up to thr[COLLIDE] march steps, then the collision code
         int32_t n;
         for (int32_t k = 0; k < S.thr[ST_COLLIDE]; ++k) {
-            n = __popcll(__ballot(slot >= 0 && l.state == ST_MARCH));
+            n = popc(__ballot(slot >= 0 && l.state == ST_MARCH));
             if (n == 0) break;
             VR_STAT(ST_MARCH, n);
             if (slot >= 0 && l.state == ST_MARCH) do_march(l, P);
             VR_STAT_END(ST_MARCH);
         }
-        n = __popcll(__ballot(slot >= 0 && l.state == ST_COLLIDE));
+        n = popc(__ballot(slot >= 0 && l.state == ST_COLLIDE));
         if (n > 0) {
             VR_STAT(ST_COLLIDE, n);
             if (slot >= 0 && l.state == ST_COLLIDE) {
@@ -229,7 +230,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
             }
         }
         // (4) event batches
-        const int32_t n_live = __popcll(__ballot(slot >= 0)) + cnt_ready;
+        const int32_t n_live = popc(__ballot(slot >= 0)) + cnt_ready;
         const bool hungry = n_live < S.thr[ST_MARCH];                    // the hot pair is about to run under-filled
         // a batch runs when it is full enough; a hungry wave additionally runs its LARGEST batch (only that one, so that the
         // others keep filling up)
@@ -348,327 +349,6 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
 #undef VR_ROUTE_ST
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Pool variant 4: compact event parking + batched collisions.
-//
-// Observation behind it (sched_stats of the variant above): more than half of a 136-slot pool sits in the event stacks,
-// although a path that waits for NEE / POSTNEE needs 2 dwords of its hot state (seed + t, seed + Tr) and one that waits for
-// ESCAPE needs none.  Here a wavefront owns NP path ids (cold line in global memory + 2 "mini" dwords in LDS each) and NF
-// full hot-state FRAMES; only paths that wait to march (READY) or to collide (COLL) occupy a frame.  That leaves room
-// to treat the tentative collision -- the most expensive frequent block -- as a batch too: a lane whose path reaches a
-// collision parks it in a frame and resumes a READY path as long as READY paths are available; the collision code runs
-// for a full-width mix of parked paths and of paths still held by lanes ("stuck": no READY path could take their lane).
-// Marching paths never leave the registers.
-#ifndef VR_NP
-#define VR_NP 256
-#endif
-#ifndef VR_NF
-#define VR_NF 100
-#endif
-constexpr int32_t NP = VR_NP;              // path ids per wavefront (<= 256: ids are bytes)
-constexpr int32_t NF = VR_NF;              // hot-state frames per wavefront
-constexpr int32_t FR_STRIDE = 17;          // odd: conflict-free for lanes with different frames
-
-struct FrameStore {
-    uint32_t* base;
-    __device__ __forceinline__ void save(const Hot& h, int32_t pid, int32_t f) const {
-        uint32_t* p = base + f * FR_STRIDE;
-        p[0] = h.seed;
-        p[1] = f2u(h.ipos.x); p[2] = f2u(h.ipos.y); p[3] = f2u(h.ipos.z);
-        p[4] = f2u(h.idir.x); p[5] = f2u(h.idir.y); p[6] = f2u(h.idir.z);
-        p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
-        p[10] = f2u(h.Tr);
-        p[11] = (uint32_t)h.state | ((uint32_t)pid << 8) | ((uint32_t)(int32_t)(h.mip * 4.0f) << 16) | ((uint32_t)h.shadow << 24);
-        p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z);
-        p[15] = f2u(h.majorant);
-    }
-    __device__ __forceinline__ void load(Hot& h, int32_t& pid, int32_t f) const {
-        const uint32_t* p = base + f * FR_STRIDE;
-        h.seed = p[0];
-        h.ipos = v3{ u2f(p[1]), u2f(p[2]), u2f(p[3]) };
-        h.idir = v3{ u2f(p[4]), u2f(p[5]), u2f(p[6]) };
-        h.ri = v3{ u2f(p[12]), u2f(p[13]), u2f(p[14]) };
-        h.t = u2f(p[7]); h.far = u2f(p[8]); h.tau = u2f(p[9]);
-        h.Tr = u2f(p[10]);
-        const uint32_t fl = p[11];
-        h.state = (int32_t)(fl & 0xFFu); pid = (int32_t)((fl >> 8) & 0xFFu);
-        h.mip = (float)((fl >> 16) & 0xFFu) * 0.25f;
-        h.shadow = (int32_t)(fl >> 24);
-        h.majorant = u2f(p[15]);
-    }
-};
-
-template <bool USE_TF, bool STATS, bool BATCH_COLL>
-__global__ void __launch_bounds__(256, VR_WAVES_PER_SIMD)
-pathtrace_kernel_v4(const SceneParams P, float* __restrict__ sbuf, float* __restrict__ cold_ws, const LaunchDesc D, const SchedParams S,
-                    uint32_t* __restrict__ status, unsigned long long* __restrict__ stats) {
-    const int32_t W = P.u.resolution[0];
-    const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-
-    constexpr int32_t QBYTES = 3 * NF + 4 * NP;
-    __shared__ uint32_t lds_fr[4 * FR_STRIDE * NF];
-    __shared__ uint32_t lds_mini[4 * 2 * NP];
-    __shared__ uint8_t lds_st[4 * QBYTES];
-    const FrameStore fs{ lds_fr + wave * (FR_STRIDE * NF) };
-    uint32_t* const mini = lds_mini + wave * (2 * NP);
-    uint8_t* const q_ready = lds_st + wave * QBYTES;        // frames whose path may march
-    uint8_t* const q_coll = q_ready + NF;                   // frames whose path waits for the collision code
-    uint8_t* const q_ff = q_coll + NF;                      // free frames
-    uint8_t* const q_nee = q_ff + NF;                       // path ids waiting for an event
-    uint8_t* const q_post = q_nee + NP;
-    uint8_t* const q_esc = q_post + NP;
-    uint8_t* const q_free = q_esc + NP;                     // unused path ids
-    float* const cold_base = cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)(C_STRIDE * NP);
-
-    int32_t c_ready = 0, c_coll = 0, c_ff = NF, c_nee = 0, c_post = 0, c_esc = 0, c_free = NP;     // stack heights (wave-uniform)
-    for (int32_t i = lane; i < NF; i += 64) q_ff[i] = (uint8_t)i;
-    for (int32_t i = lane; i < NP; i += 64) q_free[i] = (uint8_t)i;
-    __builtin_amdgcn_wave_barrier();
-
-    WorkUnit wu;
-    wu.px0 = wu.py0 = 0; wu.first_sample = 1; wu.n_items = 0; wu.base = 0u; wu.out = sbuf;
-    uint32_t cursor = 0u;
-    bool exhausted = false;
-
-    Hot l;
-    hot_init(l);
-    int32_t pid = -1;                 // path held in this lane's registers (-1: none)
-
-    uint32_t iters = 0u;
-    const unsigned long long t_begin = __builtin_readcyclecounter();
-    uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
-    unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
-    unsigned long long occ[6] = { 0, 0, 0, 0, 0, 0 };      // summed per iteration: lanes with a path, READY, NEE, POSTNEE, ESCAPE, COLL
-#define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
-#define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
-#define VR_PUSHQ(Q, CNT, COND, V) do { \
-        const uint64_t m_ = __ballot(COND); \
-        if (m_) { if (COND) (Q)[(CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(V); (CNT) += __popcll(m_); } \
-    } while (0)
-// a path (hot state H, id PIDV >= 0 where valid) leaves a block: paths that go on marching / colliding get a frame (the
-// caller guarantees c_ff is large enough), paths that wait for an event keep 2 dwords, finished ones free their id
-#define VR_ROUTE_EV(H, PIDV) do { \
-        const bool v_ = (PIDV) >= 0; \
-        const int32_t s_ = (H).state; \
-        const bool hot_ = v_ && (s_ == ST_MARCH || s_ == ST_COLLIDE); \
-        const uint64_t mh_ = __ballot(hot_); \
-        if (mh_) { \
-            const int32_t r_ = (int32_t)lane_rank(mh_); \
-            if (hot_) { const int32_t f_ = q_ff[c_ff - 1 - r_]; fs.save(H, PIDV, f_); q_ready[c_ready + r_] = (uint8_t)f_; } \
-            c_ff -= __popcll(mh_); c_ready += __popcll(mh_); \
-        } \
-        if (v_ && (s_ == ST_NEE || s_ == ST_POSTNEE)) { mini[2 * (PIDV)] = (H).seed; mini[2 * (PIDV) + 1] = f2u(s_ == ST_NEE ? (H).t : (H).Tr); } \
-        VR_PUSHQ(q_nee, c_nee, v_ && s_ == ST_NEE, PIDV); \
-        VR_PUSHQ(q_post, c_post, v_ && s_ == ST_POSTNEE, PIDV); \
-        VR_PUSHQ(q_esc, c_esc, v_ && s_ == ST_ESCAPE, PIDV); \
-        const bool lost_ = v_ && (s_ < ST_NEW || s_ > ST_ESCAPE || s_ == ST_BEGIN); \
-        if (__ballot(lost_)) { if (lost_) atomicOr(status, 2u); } \
-        VR_PUSHQ(q_free, c_free, v_ && (s_ == ST_NEW || lost_), PIDV); \
-    } while (0)
-
-    const int32_t thr_coll = S.thr[ST_BEGIN];
-    for (;;) {
-        if (++iters > S.max_iters || ((iters & 1023u) == 0u && __builtin_readcyclecounter() - t_begin > 20000000000ull)) {
-            if (lane == 0) atomicOr(status, 1u);
-            break;
-        }
-        // (1) idle lanes resume READY paths; the frame is free again
-        {
-            const uint64_t idle = __ballot(pid < 0);
-            const int32_t take = min(__popcll(idle), c_ready);
-            if (take > 0) {
-                if (pid < 0) {
-                    const int32_t r = (int32_t)lane_rank(idle);
-                    if (r < take) { const int32_t f = q_ready[c_ready - 1 - r]; fs.load(l, pid, f); q_ff[c_ff + r] = (uint8_t)f; }
-                }
-                c_ready -= take; c_ff += take;
-            }
-        }
-        if (STATS) { occ[0] += (unsigned)__popcll(__ballot(pid >= 0)); occ[1] += (unsigned)c_ready; occ[2] += (unsigned)c_nee; occ[3] += (unsigned)c_post; occ[4] += (unsigned)c_esc; occ[5] += (unsigned)c_coll; }
-        // (2) march
-        int32_t n;
-        for (int32_t k = 0; k < S.thr[ST_COLLIDE]; ++k) {
-            n = __popcll(__ballot(pid >= 0 && l.state == ST_MARCH));
-            if (n == 0) break;
-            VR_STAT(ST_MARCH, n);
-            if (pid >= 0 && l.state == ST_MARCH) do_march(l, P);
-            VR_STAT_END(ST_MARCH);
-        }
-        // (3) lanes whose path reached an event park it: 2 dwords (NEE: seed, t; POSTNEE: seed, Tr) or nothing (ESCAPE)
-        {
-            const bool ev = pid >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE;
-            if (__ballot(ev)) {
-                int32_t epid = ev ? pid : -1;
-                VR_ROUTE_EV(l, epid);
-                if (ev) pid = -1;
-            }
-        }
-        //     lanes whose path reached a tentative collision park it in a frame -- as many as READY paths can replace
-        if (BATCH_COLL) {
-            const bool coll = pid >= 0 && l.state == ST_COLLIDE;
-            const uint64_t mc = __ballot(coll);
-            if (mc) {
-                const int32_t supply = c_ready - __popcll(__ballot(pid < 0));
-                const int32_t np = min(__popcll(mc), min(c_ff, supply));
-                if (np > 0) {
-                    const int32_t r = (int32_t)lane_rank(mc);
-                    if (coll && r < np) { const int32_t f = q_ff[c_ff - 1 - r]; fs.save(l, pid, f); q_coll[c_coll + r] = (uint8_t)f; pid = -1; }
-                    c_ff -= np; c_coll += np;
-                }
-            }
-        }
-        // (4) which blocks run: one that is full enough, or -- when the march is about to run under-filled -- the largest
-        if (!BATCH_COLL) {           // collisions stay in the lane (as in the variant above)
-            n = __popcll(__ballot(pid >= 0 && l.state == ST_COLLIDE));
-            if (n > 0) {
-                VR_STAT(ST_COLLIDE, n);
-                if (pid >= 0 && l.state == ST_COLLIDE) {
-                    ColdGlobal c{ cold_base + pid * C_STRIDE };
-                    if (P.u.integrator != 0) do_collide_global<USE_TF>(l, c, P); else do_collide<USE_TF>(l, c, P);
-                }
-                VR_STAT_END(ST_COLLIDE);
-            }
-        }
-        const bool stuck = BATCH_COLL && pid >= 0 && l.state == ST_COLLIDE;
-        const uint64_t ms = __ballot(stuck);
-        const int32_t n_stuck = __popcll(ms);
-        const int32_t march_supply = __popcll(__ballot(pid >= 0 && l.state == ST_MARCH)) + c_ready;
-        const bool hungry = march_supply < S.thr[ST_MARCH];
-        const int32_t a_coll = n_stuck + c_coll;
-        const int32_t a_new = exhausted ? 0 : min(c_free, c_ff);           // NEW / NEE / POSTNEE results need a frame each
-        const int32_t a_nee = min(c_nee, c_ff), a_post = min(c_post, c_ff);
-        int32_t big = a_coll;
-        if (a_new > big) big = a_new;
-        if (a_nee > big) big = a_nee;
-        if (a_post > big) big = a_post;
-        if (c_esc > big) big = c_esc;
-        const bool want_coll = BATCH_COLL && a_coll > 0 && (a_coll >= thr_coll || (hungry && a_coll == big));
-        const bool want_new = a_new > 0 && (a_new >= S.thr[ST_NEW] || (hungry && a_new == big));
-        const bool want_nee = a_nee > 0 && (a_nee >= S.thr[ST_NEE] || (hungry && a_nee == big));
-        const bool want_post = a_post > 0 && (a_post >= S.thr[ST_POSTNEE] || (hungry && a_post == big));
-        const bool want_esc = c_esc > 0 && (c_esc >= S.thr[ST_ESCAPE] || (hungry && c_esc == big));
-        if (want_coll) {
-            // stuck lanes work on their own path, the others take parked ones
-            const int32_t r = (int32_t)lane_rank(~ms);
-            const int32_t nt = min(64 - n_stuck, c_coll);
-            const bool takes = !stuck && r < nt;
-            VR_STAT(ST_COLLIDE, n_stuck + nt);
-            Hot b;
-            int32_t bpid = -1, bf = -1;
-            if (takes) { bf = q_coll[c_coll - 1 - r]; fs.load(b, bpid, bf); }
-            if (stuck) { b = l; bpid = pid; }
-            c_coll -= nt;
-            if (bpid >= 0) {
-                ColdGlobal c{ cold_base + bpid * C_STRIDE };
-                if (P.u.integrator != 0) do_collide_global<USE_TF>(b, c, P); else do_collide<USE_TF>(b, c, P);
-            }
-            if (stuck) l = b;
-            // parked paths: back into their frame (READY, or COLL again for the global-majorant trackers) or to an event
-            {
-                const bool back = takes && (b.state == ST_MARCH || b.state == ST_COLLIDE);
-                if (back) fs.save(b, bpid, bf);
-                VR_PUSHQ(q_ready, c_ready, back && b.state == ST_MARCH, bf);
-                VR_PUSHQ(q_coll, c_coll, back && b.state == ST_COLLIDE, bf);
-                VR_PUSHQ(q_ff, c_ff, takes && !back, bf);
-                int32_t epid = (takes && !back) ? bpid : -1;
-                VR_ROUTE_EV(b, epid);
-            }
-            VR_STAT_END(ST_COLLIDE);
-        }
-        if (want_new || want_nee || want_post || want_esc) {
-            Hot b;
-            if (want_esc) {
-                n = min(64, c_esc);
-                VR_STAT(ST_ESCAPE, n);
-                int32_t bpid = -1;
-                hot_init(b);
-                if (lane < n) {
-                    bpid = q_esc[c_esc - 1 - lane];
-                    ColdGlobal c{ cold_base + bpid * C_STRIDE };
-                    do_escape(b, c, P, wu);
-                }
-                c_esc -= n;
-                VR_ROUTE_EV(b, bpid);
-                VR_STAT_END(ST_ESCAPE);
-            }
-            if (want_post) {
-                n = min(min(64, c_post), c_ff);
-                if (n > 0) {
-                    VR_STAT(ST_POSTNEE, n);
-                    int32_t bpid = -1;
-                    hot_init(b);
-                    if (lane < n) {
-                        bpid = q_post[c_post - 1 - lane];
-                        b.seed = mini[2 * bpid]; b.Tr = u2f(mini[2 * bpid + 1]);
-                        ColdGlobal c{ cold_base + bpid * C_STRIDE };
-                        do_postnee(b, c, P, wu);
-                    }
-                    c_post -= n;
-                    VR_ROUTE_EV(b, bpid);
-                    VR_STAT_END(ST_POSTNEE);
-                }
-            }
-            if (want_new) {
-                if (cursor == (uint32_t)wu.n_items) {
-                    uint32_t u = 0u;
-                    if (lane == 0) u = atomicAdd(D.unit_counter, 1u);
-                    u = __builtin_amdgcn_readfirstlane(u);
-                    if (u >= D.n_units) exhausted = true;
-                    else { wu = make_unit(D, W, u, sbuf); cursor = 0u; }
-                }
-                n = min(min(64, min(c_free, c_ff)), (int32_t)((uint32_t)wu.n_items - cursor));
-                if (n > 0) {
-                    VR_STAT(ST_NEW, n);
-                    int32_t bpid = -1;
-                    hot_init(b);
-                    if (lane < n) {
-                        bpid = q_free[c_free - 1 - lane];
-                        ColdGlobal c{ cold_base + bpid * C_STRIDE };
-                        do_new(b, c, P, wu, cursor + (uint32_t)lane);
-                    }
-                    c_free -= n;
-                    cursor += (uint32_t)n;
-                    VR_ROUTE_EV(b, bpid);
-                    VR_STAT_END(ST_NEW);
-                }
-            }
-            if (want_nee) {
-                n = min(min(64, c_nee), c_ff);
-                if (n > 0) {
-                    VR_STAT(ST_NEE, n);
-                    int32_t bpid = -1;
-                    hot_init(b);
-                    if (lane < n) {
-                        bpid = q_nee[c_nee - 1 - lane];
-                        b.seed = mini[2 * bpid]; b.t = u2f(mini[2 * bpid + 1]);
-                        ColdGlobal c{ cold_base + bpid * C_STRIDE };
-                        do_nee(b, c, P);
-                    }
-                    c_nee -= n;
-                    VR_ROUTE_EV(b, bpid);
-                    VR_STAT_END(ST_NEE);
-                }
-            }
-        }
-        if (exhausted && c_free == NP) break;                              // every path of the pool has finished
-    }
-    if (STATS && stats && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < ST_DONE; ++k) { atomicAdd(&stats[2 * k], (unsigned long long)st_exec[k]); atomicAdd(&stats[2 * k + 1], (unsigned long long)st_lanes[k]); }
-        atomicAdd(&stats[16], (unsigned long long)iters);
-        atomicAdd(&stats[17], 1ull);
-#pragma unroll
-        for (int k = 0; k < ST_DONE; ++k) atomicAdd(&stats[18 + k], st_cyc[k]);
-        atomicAdd(&stats[25], __builtin_readcyclecounter() - t_start);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&stats[26 + k], occ[k]);
-    }
-#undef VR_STAT
-#undef VR_STAT_END
-#undef VR_PUSHQ
-#undef VR_ROUTE_EV
-}
-
 // integrator = 2: direct volume rendering, one thread per (pixel, sample) item, same sample-buffer layout
 __global__ void __launch_bounds__(256)
 dvr_kernel(const SceneParams P, float* __restrict__ sbuf, const LaunchDesc D) {
@@ -730,7 +410,6 @@ static void tuning_from_env() {
     done = true;
     if (const char* e = getenv("VR_SPU")) set_samples_per_unit(atoi(e));      // diagnostics only
     if (const char* e = getenv("VR_BLOCKS_PER_CU")) g_blocks_per_cu = atoi(e);
-    if (const char* e = getenv("VR_POOL_VARIANT")) { g_sched.thr[ST_DONE] = atoi(e); if (g_sched.thr[ST_BEGIN] == 0) g_sched.thr[ST_BEGIN] = 56; }
 }
 
 size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples) {
@@ -750,7 +429,7 @@ static int resident_blocks(K kernel) {
     return cus * per_cu;
 }
 
-size_t pathtrace_workspace_floats() { return (size_t)8192 * C_STRIDE * (NSLOT > NP ? NSLOT : NP); }      // cold state of up to 8192 resident wavefronts
+size_t pathtrace_workspace_floats() { return (size_t)8192 * C_STRIDE * NSLOT; }      // cold state of up to 8192 resident wavefronts
 
 void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream) {
@@ -764,16 +443,10 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     D.n_units = (uint32_t)chunks * (uint32_t)n_tiles * 4u;
     D.unit_counter = unit_counter;
     S.max_iters = 1u << 27;          // watchdog (see the kernel): ~100x the iterations of the heaviest wavefront seen
-    const bool v4 = S.thr[ST_DONE] != 0;
-    const bool bc = S.thr[ST_DONE] == 1;
-    auto kernel = v4 ? (bc ? (P.u.use_tf ? (g_stats ? pathtrace_kernel_v4<true, true, true> : pathtrace_kernel_v4<true, false, true>)
-                                         : (g_stats ? pathtrace_kernel_v4<false, true, true> : pathtrace_kernel_v4<false, false, true>))
-                           : (P.u.use_tf ? (g_stats ? pathtrace_kernel_v4<true, true, false> : pathtrace_kernel_v4<true, false, false>)
-                                         : (g_stats ? pathtrace_kernel_v4<false, true, false> : pathtrace_kernel_v4<false, false, false>)))
-                     : (P.u.use_tf ? (g_stats ? pathtrace_kernel<true, true> : pathtrace_kernel<true, false>)
-                                   : (g_stats ? pathtrace_kernel<false, true> : pathtrace_kernel<false, false>));
-    static int blocks_cache[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    int& blocks = blocks_cache[(v4 ? (bc ? 4 : 8) : 0) + (P.u.use_tf ? 2 : 0) + (g_stats ? 1 : 0)];
+    auto kernel = P.u.use_tf ? (g_stats ? pathtrace_kernel<true, true> : pathtrace_kernel<true, false>)
+                             : (g_stats ? pathtrace_kernel<false, true> : pathtrace_kernel<false, false>);
+    static int blocks_cache[4] = { 0, 0, 0, 0 };
+    int& blocks = blocks_cache[(P.u.use_tf ? 2 : 0) + (g_stats ? 1 : 0)];
     if (blocks == 0 || g_blocks_per_cu > 0) blocks = std::min(resident_blocks(kernel), 2048);      // workspace holds 2048 workgroups
     const uint32_t waves_needed = (D.n_units + 3u) / 4u;
     const dim3 grid((unsigned)std::min<uint32_t>((uint32_t)blocks, waves_needed > 0 ? waves_needed : 1u)), block(256);
@@ -914,7 +587,7 @@ encode_brick_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int
     const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
     const bool alloc = flag[brick] != 0u;
     const uint32_t slot = alloc ? slot_of[brick] : 0u;       // bricks without a block point at slot 0 (indirection word 0)
-    if (lane == 0) { BrickRec r; r.slot = slot; r.rmin = lo; r.rdiff = hi - lo; r.range = rg; recs[(((size_t)bz << bsy) + by << bsx) + bx] = r; }
+    if (lane == 0) { BrickRec r; r.slot = slot; r.rmin = lo; r.rdiff = hi - lo; r.range = rg; recs[((((size_t)bz << bsy) + by) << bsx) + bx] = r; }
     if (!alloc) return;
     const float inv = 255.0f / (hi - lo);
     uint8_t* dst = atlas + (size_t)slot * 512u;

@@ -61,6 +61,17 @@ VR_HD int32_t floor2i(float x) {
     if (!(f >= -2147483648.0f && f < 2147483648.0f)) return kIntMin;
     return (int32_t)f;
 }
+// Voxel index floor(x) + o for the grid fetches, which read 0 for every index outside [0, extent): there only "inside or
+// not" matters, so out-of-range values may land on ANY index that is negative or >= 2^30.  The device converts with
+// the saturating v_cvt_i32_f32 and lets the addition wrap; a NaN coordinate (converts to 0) is handled by the caller.
+VR_HD int32_t voxel_index(float floored, int32_t o) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int32_t)((uint32_t)(int32_t)floored + (uint32_t)o);       // |o| <= 2: INT_MAX + o wraps negative, INT_MIN + o lands >= 2^31 - 2
+#else
+    const int32_t b = (!(floored >= -2147483648.0f && floored < 2147483648.0f)) ? kIntMin : (int32_t)floored;
+    return b == kIntMin ? kIntMin : b + o;
+#endif
+}
 
 // GLSL round() with halves to even (only used for the DDA mip level in [0,3])
 VR_HD int32_t round_half_even(float x) {
@@ -75,6 +86,8 @@ VR_HD int32_t round_mip(float mip) {
     const uint32_t q = (uint32_t)(int32_t)(mip * 4.0f);
     return (int32_t)((0x3EAA540u >> (2u * q)) & 3u);
 }
+// the same with the mip carried as the integer q = 4*mip (what the path state stores)
+VR_HD int32_t round_mip_q(int32_t q) { return (int32_t)((0x3EAA540u >> (2u * (uint32_t)q)) & 3u); }
 
 VR_HD float scale2(float z, int n) {
     if (n > 254) n = 254;

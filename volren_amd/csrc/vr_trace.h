@@ -50,7 +50,8 @@ struct WorkUnit {
 struct Hot {
     uint32_t seed;
     v3 ipos, idir, ri;       // index-space ray of the current segment
-    float t, far, tau, mip, majorant, Tr;
+    float t, far, tau, majorant, Tr;
+    int32_t mipq;            // 4 * mip: the DDA level moves in quarter steps (common.glsl:433,450), kept as an integer
     int32_t shadow;          // 0: sample_volumeDDA segment, 1: transmittanceDDA segment
     int32_t state;
 };
@@ -111,22 +112,30 @@ VR_HD float majorant_at(const GridView& g, v3 ipos, int32_t mip) {
     // cell = floor(ipos) >> (3 + mip); outside the grid (or NaN) reads 0.  The padded layout (vr_scene.h) holds 0 in every
     // cell beyond the real extent of a level, so only the padded extent -- the same for all levels -- is tested, on the
     // floats (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails), after which truncation equals floor.
-    if (mip > g.n_mips) return 0.0f;
     const float lx = (float)(8u << g.mshift[0]), ly = (float)(8u << g.mshift[1]), lz = (float)(8u << g.mshift[2]);
-    if (!(ipos.x >= 0.0f && ipos.x < lx && ipos.y >= 0.0f && ipos.y < ly && ipos.z >= 0.0f && ipos.z < lz)) return 0.0f;
+    const bool inside = (mip <= g.n_mips) & (ipos.x >= 0.0f) & (ipos.x < lx) & (ipos.y >= 0.0f) & (ipos.y < ly) & (ipos.z >= 0.0f) & (ipos.z < lz);
+    if (!inside) return 0.0f;        // one branch: the tests are evaluated together
     const uint32_t sh = 3u + (uint32_t)mip;
     const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
     const uint32_t sx = (uint32_t)g.mshift[0] - (uint32_t)mip, sy = (uint32_t)g.mshift[1] - (uint32_t)mip;
     const uint32_t off = majorant_level_offset((uint32_t)(g.mshift[0] + g.mshift[1] + g.mshift[2]), (uint32_t)mip);
     return g.majorant[off + (((bz << sy) + by) << sx) + bx];
 }
-VR_HD int32_t offs_i(int32_t base, int32_t o) { return base == kIntMin ? kIntMin : base + o; }
+// a NaN coordinate must read "outside": on the device voxel_index turns NaN into index o, so one index is forced negative
+VR_HD int32_t nan_guard(int32_t ix, float fx, float fy, float fz) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ((fx != fx) | (fy != fy) | (fz != fz)) ? -1 : ix;
+#else
+    return ix;
+#endif
+}
 
 VR_HD float density_trilinear_raw(const GridView& g, v3 ipos) {
     const float qx = ipos.x - 0.5f, qy = ipos.y - 0.5f, qz = ipos.z - 0.5f;
-    const float fx = qx - floor_(qx), fy = qy - floor_(qy), fz = qz - floor_(qz);
-    const int32_t ix = floor2i(qx), iy = floor2i(qy), iz = floor2i(qz);
-    const int32_t x1 = offs_i(ix, 1), y1 = offs_i(iy, 1), z1 = offs_i(iz, 1);
+    const float flx = floor_(qx), fly = floor_(qy), flz = floor_(qz);
+    const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+    const int32_t ix = nan_guard(voxel_index(flx, 0), flx, fly, flz), iy = voxel_index(fly, 0), iz = voxel_index(flz, 0);
+    const int32_t x1 = nan_guard(voxel_index(flx, 1), flx, fly, flz), y1 = voxel_index(fly, 1), z1 = voxel_index(flz, 1);
     const float lx0 = mix_(brick_value(g, ix, iy, iz), brick_value(g, x1, iy, iz), fx);
     const float lx1 = mix_(brick_value(g, ix, y1, iz), brick_value(g, x1, y1, iz), fx);
     const float hx0 = mix_(brick_value(g, ix, iy, z1), brick_value(g, x1, iy, z1), fx);
@@ -136,7 +145,7 @@ VR_HD float density_trilinear_raw(const GridView& g, v3 ipos) {
 
 // stochastic tricubic tap (common.glsl:221-244): 9 draws in the order tap2.xyz, tap3.xyz, tap4.xyz;
 // tap k replaces the choice when draw < w_k / max(1e-3, w_1 + ... + w_k)
-struct AxisWeights { float w2, s2, w3, s3, w4, s4; int32_t base; };
+struct AxisWeights { float w2, s2, w3, s3, w4, s4, fl; };
 VR_HD AxisWeights tricubic_axis_weights(float q) {
     AxisWeights a;
     const float fl = floor_(q);
@@ -149,7 +158,7 @@ VR_HD AxisWeights tricubic_axis_weights(float q) {
     sum = a.w3 + sum; a.s3 = max_(1e-3f, sum);
     a.w4 = k * t * t2;
     sum = a.w4 + sum; a.s4 = max_(1e-3f, sum);
-    a.base = floor2i(q);
+    a.fl = fl;
     return a;
 }
 // one LCG step; the draw as the integer-valued float k = state & 0xFFFFFF (rng() would return k * 2^-24)
@@ -195,7 +204,7 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
 #if defined(__HIP_DEVICE_COMPILE__)
     }
 #endif
-    tx = offs_i(ax.base, jx - 1); ty = offs_i(ay.base, jy - 1); tz = offs_i(az.base, jz - 1);
+    tx = nan_guard(voxel_index(ax.fl, jx - 1), ax.fl, ay.fl, az.fl); ty = voxel_index(ay.fl, jy - 1); tz = voxel_index(az.fl, jz - 1);
 }
 
 // transfer function (common.glsl:203-212)
@@ -348,7 +357,8 @@ VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
 VR_HD void hot_init(Hot& h) {
     h.seed = 0u;
     h.ipos = h.idir = h.ri = v3{ 0, 0, 0 };
-    h.t = h.far = h.tau = h.mip = h.majorant = h.Tr = 0.0f;
+    h.t = h.far = h.tau = h.majorant = h.Tr = 0.0f;
+    h.mipq = 0;
     h.shadow = 0;
     h.state = ST_NEW;
 }
@@ -376,7 +386,7 @@ VR_HD void accumulate_sample(float acc[4], const float L[4], int32_t current_sam
 VR_HD void begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t shadow) {
     h.shadow = shadow;
     h.Tr = 1.0f;          // both set before the branch on purpose: conditional stores to different fields make the
-    h.mip = 3.0f;         // compiler address-select between them, which forces the state into scratch memory
+    h.mipq = 12;          // mip = 3; compiler address-select between them, which forces the state into scratch memory
     float tnear, tfar;
     if (!intersect_box(pos, d, P.u.vol_bb_min, P.u.vol_bb_max, tnear, tfar)) {
         h.state = shadow ? ST_POSTNEE : ST_ESCAPE;
@@ -424,12 +434,12 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
 VR_HD void do_march(Hot& h, const SceneParams& P) {
     if (!(h.t < h.far)) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
     const v3 curr = axpy(h.ipos, h.t, h.idir);
-    const int32_t m = round_mip(h.mip);
+    const int32_t m = round_mip_q(h.mipq);
     const float majorant = majorant_at(P.density, curr, m);
     const float dt = step_dda(curr, h.ri, m);
     h.t += dt;
     h.tau -= majorant * dt;
-    h.mip = min_(h.mip + 0.25f, 3.0f);
+    h.mipq = h.mipq < 12 ? h.mipq + 1 : 12;                 // mip = min(mip + 0.25, 3)
     if (h.tau > 0.0f) return;
     h.t += h.tau / majorant;
     if (h.t >= h.far) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
@@ -484,7 +494,7 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
         }
     }
     h.tau = neg_log_1m(rng(h.seed));
-    h.mip = max_(0.0f, h.mip - 2.0f);
+    h.mipq = h.mipq > 8 ? h.mipq - 8 : 0;                  // mip = max(0, mip - 2)
     h.state = ST_MARCH;
 }
 
