@@ -392,7 +392,7 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
 // thr[]: NEW, (unused), MARCH (= flush level of the hot pair), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE
 // thr[]: NEW (free slots that trigger a NEW batch), unused, MARCH (= low-water mark of live paths: below it every
 // non-empty batch runs), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
-static SchedParams g_sched = { { 64, 0, 32, 2, 48, 48, 64, 0 }, 0u };
+static SchedParams g_sched = { { 64, 0, 40, 2, 48, 48, 64, 0 }, 0u };
 static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
 static int32_t g_samples_per_unit = 4;
 static int32_t g_blocks_per_cu = 0;                 // 0 = from the occupancy query
