@@ -161,10 +161,12 @@ VR_HD AxisWeights tricubic_axis_weights(float q) {
     a.fl = fl;
     return a;
 }
-// one LCG step; the draw as the integer-valued float k = state & 0xFFFFFF (rng() would return k * 2^-24)
-VR_HD float rng_k(uint32_t& s) {
-    s = s * 1664525u + 1013904223u;
-    return (float)(s & 0x00FFFFFFu);
+// LCG jump-ahead: state_j = A_j * state_0 + C_j (mod 2^32) after j draws
+struct LcgJump { uint32_t A, C; };
+constexpr LcgJump lcg_jump(int j) {
+    uint32_t A = 1u, C = 0u;
+    for (int i = 0; i < j; ++i) { A = A * 1664525u; C = C * 1664525u + 1013904223u; }
+    return LcgJump{ A, C };
 }
 VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) {
     const AxisWeights ax = tricubic_axis_weights(ipos.x - 0.5f);
@@ -172,22 +174,29 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
     const AxisWeights az = tricubic_axis_weights(ipos.z - 0.5f);
     int32_t jx = 0, jy = 0, jz = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-    // Device: every test "k * 2^-24 < w / s" is first tried as "k < (w * 2^24) * rcp(s)" with an 8-ulp guard band
-    // (see lt_quot); the 9 tests share ONE exact fallback, taken when any of them lands inside its band (~1e-5 per call).
-    const uint32_t seed0 = seed;
+    // Device fast path, no division and no 32-bit multiply per test.
+    //  * draw j is r_j = k_j * 2^-24 with k_j = state_j & 0xFFFFFF, and the low 24 bits of state_j = A_j * seed + C_j only
+    //    need the low 24 bits of seed and A_j: one 24-bit multiply-add (full rate) instead of a chained 32-bit multiply;
+    //  * the reference's test r_j < w / s is decided as k_j * s < w * 2^24 (s > 0) whenever the two sides differ by more
+    //    than a guard band of 8 ulp (+1e-30 absolute, for vanishing weights) -- far more than the two roundings involved;
+    //  * a test inside its band (~1e-5 per call) sends all 9 to ONE exact fallback below.
+    const uint32_t seed0 = seed, lo24 = seed & 0x00FFFFFFu;
     bool unsure = false;
-#define VR_TAP(J, V, W, S) do { \
-        const float k_ = rng_k(seed); \
-        const float q_ = ((W) * 16777216.0f) * __builtin_amdgcn_rcpf(S); \
-        const float m_ = abs_(q_) * 9.5367431640625e-07f; \
-        const bool yes_ = k_ < q_ - m_, no_ = k_ > q_ + m_; \
+#define VR_TAP(J, V, W, S, N) do { \
+        constexpr LcgJump g_ = lcg_jump(N); \
+        const float k_ = (float)((mul24(lo24, g_.A & 0x00FFFFFFu) + g_.C) & 0x00FFFFFFu); \
+        const float x_ = k_ * (S); \
+        const float w_ = (W) * 16777216.0f; \
+        const float m_ = __builtin_fmaf(abs_(w_), 9.5367431640625e-07f, 1e-30f); \
+        const bool yes_ = x_ < w_ - m_, no_ = x_ > w_ + m_; \
         J = yes_ ? V : J; \
         unsure = unsure | !(yes_ | no_); \
     } while (0)
-    VR_TAP(jx, 1, ax.w2, ax.s2); VR_TAP(jy, 1, ay.w2, ay.s2); VR_TAP(jz, 1, az.w2, az.s2);
-    VR_TAP(jx, 2, ax.w3, ax.s3); VR_TAP(jy, 2, ay.w3, ay.s3); VR_TAP(jz, 2, az.w3, az.s3);
-    VR_TAP(jx, 3, ax.w4, ax.s4); VR_TAP(jy, 3, ay.w4, ay.s4); VR_TAP(jz, 3, az.w4, az.s4);
+    VR_TAP(jx, 1, ax.w2, ax.s2, 1); VR_TAP(jy, 1, ay.w2, ay.s2, 2); VR_TAP(jz, 1, az.w2, az.s2, 3);
+    VR_TAP(jx, 2, ax.w3, ax.s3, 4); VR_TAP(jy, 2, ay.w3, ay.s3, 5); VR_TAP(jz, 2, az.w3, az.s3, 6);
+    VR_TAP(jx, 3, ax.w4, ax.s4, 7); VR_TAP(jy, 3, ay.w4, ay.s4, 8); VR_TAP(jz, 3, az.w4, az.s4, 9);
 #undef VR_TAP
+    rng_skip9(seed);
     if (unsure) {
         seed = seed0; jx = jy = jz = 0;
 #endif
