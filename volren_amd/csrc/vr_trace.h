@@ -288,12 +288,15 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
 #else
         const float d = rec[0], e0 = rec[1], e1 = rec[2];
 #endif
-        posx *= 2; posy *= 2;
-        float e;
-        if (px < d) { px = px / d; e = e0; }
-        else { posx += 1; px = (px - d) / (1.0f - d); e = e1; }
-        if (py < e) { py = py / e; }
-        else { posy += 1; py = (py - e) / (1.0f - e); }
+        // common.glsl:118-131: "if (r < p) r /= p; else { pos += 1; r = (r - p) / (1 - p); }" per axis, written as operand
+        // selects + ONE division so that a wavefront whose lanes go both ways does not execute two
+        const bool right = !(px < d);
+        const float e = right ? e1 : e0;
+        px = (right ? px - d : px) / (right ? 1.0f - d : d);
+        const bool up = !(py < e);
+        py = (up ? py - e : py) / (up ? 1.0f - e : e);
+        posx = 2 * posx + (right ? 1 : 0);
+        posy = 2 * posy + (up ? 1 : 0);
     }
     const float u = ((float)posx + px) * P.u.env_imp_inv_dim[0];
     const float v = ((float)posy + py) * P.u.env_imp_inv_dim[1];
@@ -316,9 +319,10 @@ VR_HD float phase_hg(float cos_t, float g) {
     return kInv4Pi * (1.0f - sqr(g)) / (denom * sqrt_(denom));
 }
 VR_HD v3 align(v3 N, v3 v) {
-    v3 T;
-    if (abs_(N.x) > abs_(N.y)) T = v3{ -N.z, 0.0f, N.x } / sqrt_(N.x * N.x + N.z * N.z);
-    else T = v3{ 0.0f, N.z, -N.y } / sqrt_(N.y * N.y + N.z * N.z);
+    // common.glsl:27-28; both branches are "vector / sqrt(a*a + b*b)": select the operands, divide once
+    const bool xa = abs_(N.x) > abs_(N.y);
+    const float a = xa ? N.x : N.y;
+    const v3 T = (xa ? v3{ -N.z, 0.0f, N.x } : v3{ 0.0f, N.z, -N.y }) / sqrt_(a * a + N.z * N.z);
     const v3 B = cross(N, T);
     return normalize(v3{ v.x * T.x + v.y * B.x + v.z * N.x,
                          v.x * T.y + v.y * B.y + v.z * N.y,
