@@ -259,16 +259,18 @@ VR_HD float acos_(float x) {
     if (x != x) return nan_();
     if (x < -1.0f) x = -1.0f;
     if (x > 1.0f) x = 1.0f;
-    if (x < -0.5f) return kPi - 2.0f * asin_(sqrt_(0.5f * (1.0f + x)));
-    if (x > 0.5f) return 2.0f * asin_(sqrt_(0.5f * (1.0f - x)));
-    return kPiO2 - asin_(x);
+    // three cases, ONE asin_ evaluation: |x| > 0.5 uses asin(sqrt(0.5 * (1 - |x|))) (1 + x == 1 - |x| for x < 0, bit for bit)
+    const bool lo = x < -0.5f, hi = x > 0.5f;
+    const float a = asin_((lo | hi) ? sqrt_(0.5f * (1.0f - abs_(x))) : x);
+    return lo ? kPi - 2.0f * a : (hi ? 2.0f * a : kPiO2 - a);
 }
 VR_HD float atan_(float x) {
     const bool neg = x < 0.0f;
     float a = abs_(x), y;
-    if (a > 2.414213562373095f) { y = kPiO2; a = -(1.0f / a); }
-    else if (a > 0.4142135623730950f) { y = kPiO4; a = (a - 1.0f) / (a + 1.0f); }
-    else { y = 0.0f; }
+    // -(1/a), (a-1)/(a+1) or a: operands selected first, one division (a / 1 and (-1) / a are exact restatements)
+    const bool big = a > 2.414213562373095f, mid = !big && a > 0.4142135623730950f;
+    y = big ? kPiO2 : (mid ? kPiO4 : 0.0f);
+    a = (big ? -1.0f : (mid ? a - 1.0f : a)) / (big ? a : (mid ? a + 1.0f : 1.0f));
     const float z = a * a;
     float p = 8.05374449538e-2f;
     p = fma_(p, z, -1.38776856032E-1f);

@@ -235,7 +235,13 @@ VR_HD void tf_lookup(const SceneParams& P, float d, float rgba[4]) {
 
 // ---------------------------------------------------------------------------------------------------
 // environment (common.glsl:93-152)
-VR_HD int32_t wrap_repeat(int32_t i, int32_t n) { const int32_t m = i % n; return m < 0 ? m + n : m; }
+VR_HD int32_t wrap_repeat(int32_t i, int32_t n) {
+    // GL_REPEAT; texture coordinates in [0, 1] give i in [-1, n]: one conditional add/subtract, the integer division only
+    // for coordinates further out
+    if ((uint32_t)(i + n) < 3u * (uint32_t)n) return i < 0 ? i + n : (i >= n ? i - n : i);
+    const int32_t m = i % n;
+    return m < 0 ? m + n : m;
+}
 VR_HD int32_t clampi(int32_t i, int32_t lo, int32_t hi) { return i < lo ? lo : (i > hi ? hi : i); }
 
 VR_HD v3 env_texture(const SceneParams& P, float u, float v) {
