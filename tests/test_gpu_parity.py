@@ -280,6 +280,58 @@ def test_emission_grid_and_brick_upload():
     _assert_same(hip, o.render(8), "brick upload + emission")
 
 
+def _crop_bricks(a, nbc):
+    """Centred sub-block nbc = (cx, cy, cz) of an encode_arrays() brick grid: indirection/range cropped (the atlas pointers stay
+    valid), range mips rebuilt with the ceil(n / 2) rule (min of mins, max of maxes over the existing children)."""
+    nbx, nby, nbz = a["n_bricks"]
+    cx, cy, cz = nbc
+    ox, oy, oz = (nbx - cx) // 2, (nby - cy) // 2, (nbz - cz) // 2          # centred: the synthetic cloud is densest there
+    ind = a["indirection"].reshape(nbz, nby, nbx)[oz:oz + cz, oy:oy + cy, ox:ox + cx].copy()
+    rng = a["rng"].reshape(nbz, nby, nbx)[oz:oz + cz, oy:oy + cy, ox:ox + cx].copy()
+    lo = (rng & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)
+    hi = (rng >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+    mips = []
+    for _ in range(3):
+        z, y, x = lo.shape
+        z2, y2, x2 = (z + 1) // 2, (y + 1) // 2, (x + 1) // 2
+        plo = np.full((z2 * 2, y2 * 2, x2 * 2), np.inf, np.float32)
+        phi = np.full((z2 * 2, y2 * 2, x2 * 2), -np.inf, np.float32)
+        plo[:z, :y, :x] = lo
+        phi[:z, :y, :x] = hi
+        lo = plo.reshape(z2, 2, y2, 2, x2, 2).min((1, 3, 5))
+        hi = phi.reshape(z2, 2, y2, 2, x2, 2).max((1, 3, 5))
+        w = lo.astype(np.float16).view(np.uint16).astype(np.uint32) | (hi.astype(np.float16).view(np.uint16).astype(np.uint32) << 16)
+        mips.append(((x2, y2, z2), w.reshape(-1)))
+    out = dict(a)
+    out.update(n_bricks=(cx, cy, cz), indirection=ind.reshape(-1), rng=rng.reshape(-1), mips=mips)
+    return out
+
+
+@pytest.mark.parametrize("nbc", [(5, 3, 7), (1, 2, 1), (8, 7, 3)])
+def test_odd_brick_counts(nbc):
+    """Brick counts that are neither powers of two nor multiples of 8 (a .brick file may hold any): exercises the padded
+    power-of-two pitches of the brick records and majorant levels (vr_scene.h) against the oracle's plain indexing."""
+    from oracle import binding as ob
+    import encoder_ref
+    import volren_amd
+    a = _crop_bricks(encoder_ref.encode_arrays(scenes.synthetic_density(64)), nbc)
+    r = volren_amd.Renderer(64, 48)
+    r.load_envmap(scenes.HDR)
+    r.set_volume_brick(a["transform"], a["n_bricks"], a["min_maj"], a["indirection"], a["rng"], a["atlas_dim"], a["atlas"], a["mips"], commit=True)
+    g = ob.Grid()
+    g.set(a["transform"], a["n_bricks"], a["min_maj"], a["brick_counter"], a["indirection"], a["rng"], a["atlas_dim"], a["atlas"], a["mips"])
+    o = ob.OracleRenderer(64, 48)
+    o.load_envmap(scenes.HDR)
+    o.set_volume(g)
+    for x in (r, o):
+        x.cam_fov = 40.0
+        x.bounces = 6
+    r.render(6)
+    hip = r.framebuffer()
+    assert hip[..., 3].max() > 0
+    _assert_same(hip, o.render(6), "odd brick counts %s" % (nbc,))
+
+
 def test_dense_fp16_grid_matches_oracle():
     """vr_set_volume_dense_f16: the grid stays dense on the device (2 B voxels + macro-cell majorant mips built by the
     product's C++ code); the oracle gets the numpy reference arrays."""
