@@ -1,7 +1,8 @@
 """ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
-module; the product package volren_amd never does.  PARITY UNPINNED (see volren_oracle.h).
+module; the product package volren_amd never does.  Pinned against the reference's GLSL kernels run here
+(tests/test_glsl_pin.py, see volren_oracle.h).
 
 `OracleRenderer` mirrors the call protocol of the reference's RendererOpenGL
 (/root/reference/src/renderer.h:16-63, src/main.cpp:37-81,360-435): load_volume /
@@ -80,7 +81,8 @@ def lib():
         return _lib
     if not os.path.exists(_LIB_PATH):
         build()
-    L = C.CDLL(_LIB_PATH)
+    # VOLREN_ORACLE_SO: an alternative build of the same sources (the unfused variant used by make_golden_glsl.py)
+    L = C.CDLL(os.environ.get("VOLREN_ORACLE_SO", _LIB_PATH))
     L.orc_load_brick.argtypes = [C.c_char_p, C.POINTER(BrickGrid)]
     L.orc_load_brick.restype = C.c_int
     L.orc_free_brick.argtypes = [C.POINTER(BrickGrid)]

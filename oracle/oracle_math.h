@@ -24,6 +24,14 @@
 #include <stdint.h>
 #include <string.h>
 
+/* -DORC_UNFUSED builds the "unfused" variant of the oracle (oracle/_ref/liboracle_unfused.so): every fused multiply-add of
+ * the specification becomes a multiply followed by an add, which is how Mesa llvmpipe evaluates the reference's GLSL
+ * (fma() and a*b+c are both unfused there).  Only tests/golden/make_golden_glsl.py uses it, to show that the oracle's
+ * LOGIC reproduces the reference's kernels exactly once the contraction convention is the same. */
+#ifdef ORC_UNFUSED
+#define fmaf(a, b, c) ((a) * (b) + (c))
+#endif
+
 #define OM_PI      3.14159265358979323846f   /* common.glsl:4 M_PI as float */
 #define OM_PIO2    1.5707963267948966192f
 #define OM_PIO4    0.7853981633974483096f

@@ -4,7 +4,8 @@
  * Scalar CPU restatement of the reference's GLSL path tracer.  "ref:" comments
  * give the file:line in /root/reference that each function follows.  All
  * arithmetic is IEEE binary32; build with -O2 -ffp-contract=off -mfma.
- * PARITY UNPINNED (no golden vectors exist in the reference; see the header).
+ * Parity is pinned against outputs of the reference's own GLSL kernels run on Mesa llvmpipe
+ * (tests/test_glsl_pin.py; see the header).
  *
  * Expression conventions (shared with the product's own statement of them):
  *   dot3(a,b)      = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))

@@ -7,14 +7,20 @@
  * shader/env_setup.glsl, shader/tonemap.glsl).  Every function cites the reference
  * file:line it follows.
  *
- * PARITY UNPINNED: the reference has no tests, golden vectors or known-answer
- * fixtures for this path, and it cannot be compiled or run in the build
- * environment (GLSL on an OpenGL 4.5 driver; its cppgl/voldata submodules are not
- * vendored).  This oracle is therefore pinned only by (1) line-by-line restatement,
- * (2) structural known-answers on the reference's data files (tests/golden/
- * known_answers.json) and (3) a low-resolution comparison with
- * the reference's only output artefact imgs/example.jpg (tests/golden/
- * example_64.npy).  DESIGN.md states the same.
+ * PARITY PINNED AGAINST OUTPUTS OF THE REFERENCE ITSELF, RUN HERE.  The reference has no
+ * tests or golden vectors and its host program cannot be built (cppgl/voldata are not
+ * vendored), but its hot path is GLSL, and Mesa's software rasteriser is in the image:
+ * oracle/glref runs the reference's own shader files (read from /root/reference/shader)
+ * on llvmpipe, tests/golden/make_golden_glsl.py stores the outputs (tests/golden/
+ * glsl_golden.npz) and tests/test_glsl_pin.py checks this oracle against them: whole
+ * renders (path tracer with and without transfer function, emission) to ~1e-7 relative L2
+ * for the unfused build of this file (llvmpipe never fuses multiply-add), >= 99.5 % of
+ * the pixels to 1e-5 for the standard build; tea/rng, majorant fetches and a complete
+ * transmittanceDDA segment bit for bit.  In addition: structural known-answers on the
+ * reference's data files (tests/golden/known_answers.json) and the reference's only
+ * output artefact imgs/example.jpg (tests/golden/example_64.npy).  DESIGN.md 2 has the
+ * details, including the three points GLSL/GL leave to the driver (precision of
+ * log/acos/atan, multiply-add contraction, the generic GL_COMPRESSED_RED atlas format).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library.  The product (volren_amd/) never includes, links or calls it.
