@@ -45,6 +45,7 @@ def lib():
         L.glref_tex3d_level.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.glref_tex2d_rgb32f.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.glref_read_tex2d.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.glref_upload_tex2d.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.glref_ssbo.argtypes = [C.c_int, C.c_void_p, C.c_long]
         L.glref_read_ssbo.argtypes = [C.c_int, C.c_void_p, C.c_long]
         if L.glref_init() != 0:
@@ -206,11 +207,32 @@ class GLSLReference:
         _ck(L.glref_sampler(prog, b"env_impmap", unit, self.impmap, 0))
         return unit + 1
 
-    def render(self, spp, first_sample=1):
+    def _variant_program(self, variant):
+        """Kernels the reference contains but does not build: its text with one line changed, in memory.
+        "global": pathtracer_brick*.glsl without `#define USE_DDA` -> trace_path uses sample_volume / transmittance with the
+        global majorant (common.glsl:333-394, 606-624).  "dvr": main() calls direct_volume_rendering (common.glsl:571-591,
+        not called by any kernel of the reference) instead of trace_path."""
+        key = "variant:" + variant
+        if key not in self.programs:
+            name = "pathtracer_brick_tf.glsl" if self.scene.lut is not None else "pathtracer_brick.glsl"
+            text = shader_source(name, spec_math=self.spec_math)
+            if variant == "global":
+                assert text.count("#define USE_DDA") == 1
+                text = text.replace("#define USE_DDA", "")
+            elif variant == "dvr":
+                call = "trace_path(pos, dir, seed)"
+                assert text.count(call) == 1
+                text = text.replace(call, "vec4(direct_volume_rendering(pos, dir, seed), 1)")
+            else:
+                raise ValueError(variant)
+            self.programs[key] = _ck(self.L.glref_program(text.encode()))
+        return self.programs[key]
+
+    def render(self, spp, first_sample=1, variant=None):
         """`spp` dispatches of pathtracer_brick.glsl (or _tf with a LUT) = RendererOpenGL::trace() x spp. Returns RGBA [H][W][4], row 0 = bottom."""
         s = self.scene
         L = self.L
-        prog = self._program("pathtracer_brick_tf.glsl" if s.lut is not None else "pathtracer_brick.glsl")
+        prog = self._variant_program(variant) if variant else self._program("pathtracer_brick_tf.glsl" if s.lut is not None else "pathtracer_brick.glsl")
         color = _ck(L.glref_tex2d_empty(s.w, s.h, 4))
         _ck(L.glref_use(prog))
         _ck(L.glref_bind_image(0, color, 4, 0))
@@ -244,4 +266,22 @@ class GLSLReference:
         _ck(L.glref_dispatch((n + 63) // 64, 1, 1))
         _ck(L.glref_read_ssbo(bo, out.ctypes.data, out.nbytes))
         del bi
+        return out
+
+    # -- tonemap.glsl (renderer.cpp tonemap(): exposure, gamma) ---------------------------------------------------------
+    def tonemap(self, rgba, exposure, gamma):
+        L = self.L
+        a = np.ascontiguousarray(rgba, np.float32)
+        h, w, _ = a.shape
+        prog = self._program("tonemap.glsl")
+        tex = _ck(L.glref_tex2d_empty(w, h, 4))
+        _ck(L.glref_upload_tex2d(tex, w, h, a.ctypes.data))
+        _ck(L.glref_use(prog))
+        _ck(L.glref_bind_image(0, tex, 4, 0))
+        set_uniform(prog, "exposure", "f", exposure)
+        set_uniform(prog, "gamma", "f", gamma)
+        set_uniform(prog, "resolution", "2i", (w, h))
+        _ck(L.glref_dispatch((w + 15) // 16, (h + 15) // 16, 1))
+        out = np.zeros_like(a)
+        _ck(L.glref_read_tex2d(tex, 0, 4, out.ctypes.data))
         return out

@@ -199,6 +199,11 @@ int glref_tex2d_empty(int w, int h, int channels) {
     if (check("glTexImage2D empty")) return -1;
     return (int)t;
 }
+int glref_upload_tex2d(int tex, int w, int h, const float* rgba) {
+    p_glBindTexture(GL_TEXTURE_2D, (GLuint)tex);
+    p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, w, h, 0, GL_RGBA, GL_FLOAT, rgba);
+    return check("glTexImage2D upload");
+}
 int glref_bind_image(int unit, int tex, int channels, int access) {        /* access 0 read-write, 1 write-only */
     p_glBindImageTexture((GLuint)unit, (GLuint)tex, 0, GL_FALSE, 0, access ? GL_WRITE_ONLY : GL_READ_WRITE, channels == 1 ? GL_R32F : GL_RGBA32F);
     return check("glBindImageTexture");

@@ -53,11 +53,18 @@ def main():
             o = scenes.oracle_scene(m["config"], W, H)
             if m["white_env"]:
                 o.set_envmap(np.ones((1, 1, 3), np.float32))
+            o.integrator = m.get("integrator", 0)
         res["images"][name] = image_metrics(G["img_" + name], o.render(SPP))
     o = scenes.oracle_scene("c2", W, H)
     o.set_envmap(np.ones((1, 1, 3), np.float32))
     res["images"]["c2_white_driver_atlas_rgtc1"] = image_metrics(G["img_c2_white_driver_atlas_rgtc1"], o.render(SPP))
 
+    tm = {}
+    for key, (e, gm) in (("tonemap_e3_g2", (3.0, 2.0)), ("tonemap_e5_g22", (5.0, 2.2))):
+        t = G["img_c2_hdr_spec"].copy()
+        L.orc_tonemap(t.ctypes.data_as(C.POINTER(C.c_float)), W, H, C.c_float(e), C.c_float(gm))
+        tm[key] = float(np.abs(t - G[key]).max())
+    res["tonemap_max_abs"] = tm
     o = scenes.oracle_scene("c2", W, H)
     p, s = o.params(), o.scene()
     lv = ob.impmap_levels(o.impmap)

@@ -69,11 +69,21 @@ def main():
     o = emission_scene(W, H)
     out["img_emission_spec"] = gb.GLSLReference(o, spec_math=True).render(SPP)
     meta["images"]["emission_spec"] = dict(config="synthetic 40^3 density + temperature (tests/test_gpu_parity.py emission scene)", white_env=False, spec_math=True)
+    # kernels the reference contains but does not build (binding._variant_program): global-majorant trackers = trace_path without
+    # USE_DDA (the product's integrator 1), direct_volume_rendering (integrator 2)
+    for name, cfg, variant in (("c2_global_spec", "c2", "global"), ("c3_global_spec", "c3", "global"), ("c3_dvr_spec", "c3", "dvr")):
+        o = scenes.oracle_scene(cfg, W, H)
+        out["img_" + name] = gb.GLSLReference(o, spec_math=True).render(SPP, variant=variant)
+        meta["images"][name] = dict(config=cfg, white_env=False, spec_math=True, integrator=1 if variant == "global" else 2)
     # what Mesa's choice for GL_COMPRESSED_RED (RGTC1) does to the image
     o = scenes.oracle_scene("c2", W, H)
     o.set_envmap(np.ones((1, 1, 3), np.float32))
     out["img_c2_white_driver_atlas_rgtc1"] = gb.GLSLReference(o, literal_compressed_atlas=True).render(SPP)
 
+    # tonemap.glsl on the c2 render (README settings exposure 3, gamma 2; defaults 5 / 2.2)
+    g2 = gb.GLSLReference(scenes.oracle_scene("c2", W, H))
+    out["tonemap_e3_g2"] = g2.tonemap(out["img_c2_hdr_spec"], 3.0, 2.0)
+    out["tonemap_e5_g22"] = g2.tonemap(out["img_c2_hdr_spec"], 5.0, 2.2)
     # importance map of env_setup.glsl + glGenerateMipmap (environment.cpp:11-37): levels 3..9 whole, level 0 as row/column sums
     o = scenes.oracle_scene("c2", W, H)
     g = gb.GLSLReference(o)
