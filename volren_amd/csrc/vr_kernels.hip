@@ -389,7 +389,6 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
     *texel = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
-// thr[]: NEW, (unused), MARCH (= flush level of the hot pair), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE
 // thr[]: NEW (free slots that trigger a NEW batch), unused, MARCH (= low-water mark of live paths: below it every
 // non-empty batch runs), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
 static SchedParams g_sched = { { 64, 0, 40, 2, 48, 48, 64, 0 }, 0u };
