@@ -55,6 +55,11 @@ def test_device_math_bit_exact():
     assert np.array_equal(_bits(volren_amd.math_probe(9, a, b)), _bits(a / b))
     assert np.array_equal(_bits(volren_amd.math_probe(10, np.abs(a), b)), _bits(np.sqrt(np.abs(a))))
     assert np.array_equal(_bits(volren_amd.math_probe(14, a, b)), _bits((a * b).astype(np.float32) + a))
+    halves = np.arange(65536, dtype=np.uint32)                                 # every binary16 value through the device's conversion
+    dev = volren_amd.math_probe(15, halves.view(np.float32), halves.view(np.float32))
+    ref = halves.astype(np.uint16).view(np.float16).astype(np.float32)
+    same = (_bits(dev) == _bits(ref)) | (np.isnan(dev) & np.isnan(ref))
+    assert same.all(), "half2float differs at %d codes" % (~same).sum()
     u8 = np.arange(256, dtype=np.float32)
     assert np.array_equal(_bits(volren_amd.math_probe(12, u8, u8)), _bits(u8 / np.float32(255)))
 

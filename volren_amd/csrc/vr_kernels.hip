@@ -745,6 +745,7 @@ math_probe_kernel(int32_t fn, const float* __restrict__ a, const float* __restri
     case 12: r = (float)((uint32_t)x & 255u) / 255.0f; break;
     case 13: { float s, c; sincos_(x, s, c); r = s * y + c; break; }
     case 14: r = x * y + x; break;     // must stay two roundings (-ffp-contract=off)
+    case 15: r = half2float(f2u(x)); break;     // bit pattern of x: low 16 bits = binary16
     default: r = nan_(); break;
     }
     out[i] = r;

@@ -314,6 +314,10 @@ VR_HD float pow_(float x, float y) {
 }
 
 VR_HD float half2float(uint32_t h) {   // low 16 bits
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cvt_f32_f16: exact for every binary16 value (gfx9 keeps f16 denormals; every half is representable in binary32)
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+#endif
     const uint32_t s = (h & 0x8000u) << 16;
     const uint32_t e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
     if (e == 0u) {
