@@ -79,13 +79,13 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 // Everything is wave-synchronous (ballots, mbcnt ranks, scalar counters): no atomics, no barriers, no spinning; the only
 // global atomic is the work-queue head.  Which lane runs which path never changes a result.
 #ifndef VR_NSLOT
-#define VR_NSLOT 136
+#define VR_NSLOT 152
 #endif
 constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
 
 enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
 
-constexpr int32_t HOT_STRIDE = 17;     // dwords per slot in LDS: odd, so that lanes with different slots spread over the banks
+constexpr int32_t HOT_STRIDE = 15;     // dwords per slot in LDS (= the parked fields): odd, so that lanes with different slots spread over the banks
 struct HotStore {                      // [slot][field]: a path's 15 parked dwords are adjacent (ds_read2/ds_write2 pairs)
     uint32_t* base;
     // mip (a multiple of 1/4 in [0,3]) rides in the flag word
@@ -391,7 +391,7 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
 
 // thr[]: NEW (free slots that trigger a NEW batch), unused, MARCH (= low-water mark of live paths: below it every
 // non-empty batch runs), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
-static SchedParams g_sched = { { 64, 0, 40, 2, 48, 48, 64, 0 }, 0u };
+static SchedParams g_sched = { { 64, 0, 48, 2, 56, 56, 64, 0 }, 0u };
 static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
 static int32_t g_samples_per_unit = 4;
 static int32_t g_blocks_per_cu = 0;                 // 0 = from the occupancy query
