@@ -152,7 +152,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     int32_t slot = -1;                // path held in this lane's registers (-1: none)
 
     uint32_t iters = 0u;
-    const unsigned long long t_begin = __builtin_readcyclecounter();
+    unsigned long long t_last = __builtin_readcyclecounter(), t_elapsed = 0ull;
     uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
     unsigned long long occ[6] = { 0, 0, 0, 0, 0, 0 };      // summed per iteration: marching lanes, READY, NEE, POSTNEE, ESCAPE, FREE
@@ -182,7 +182,17 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     for (;;) {
         // watchdog: a wavefront's share of a launch is tens of milliseconds; give up (and report) after S.max_iters
         // scheduler iterations or ~8 s of shader clock, whichever comes first -- a kernel must never hang the GPU
-        if (++iters > S.max_iters || ((iters & 1023u) == 0u && __builtin_readcyclecounter() - t_begin > 20000000000ull)) {
+        bool give_up = ++iters > S.max_iters;
+        if ((iters & 1023u) == 0u) {
+            // elapsed shader-clock time, summed over 1024-iteration windows.  A window that appears to take more than 2^34 ticks (or
+            // a negative time) is a counter discontinuity -- a wavefront that was saved and restored on another XCD when several
+            // processes time-share the GPU reads a different counter -- and is not counted.
+            const unsigned long long now = __builtin_readcyclecounter(), d = now - t_last;
+            t_last = now;
+            if (d < (1ull << 34)) t_elapsed += d;
+            give_up = give_up || t_elapsed > 20000000000ull;
+        }
+        if (give_up) {
             if (lane == 0) atomicOr(status, 1u);
             break;
         }
