@@ -40,8 +40,8 @@ void RendererHIP::init() {
     }
     if (!ev0_) { VR_HIP(hipEventCreate(&ev0_)); VR_HIP(hipEventCreate(&ev1_)); }
     if (!status_) {
-        status_ = make_device_buffer(2 * sizeof(uint32_t));          // [0] watchdog flag, [1] work-queue head
-        VR_HIP(hipMemset(status_->get(), 0, 2 * sizeof(uint32_t)));
+        status_ = make_device_buffer(16 * sizeof(uint32_t));         // [0] watchdog flag, [1..8] work-queue heads (one per XCD segment)
+        VR_HIP(hipMemset(status_->get(), 0, 16 * sizeof(uint32_t)));
     }
     if (!color && resolution.x > 0 && resolution.y > 0) resize((uint32_t)resolution.x, (uint32_t)resolution.y);
 }

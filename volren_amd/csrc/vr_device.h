@@ -12,7 +12,7 @@ namespace vr {
 // for every pixel of the listed 16x16 tiles (kernel 1: per-sample radiances into `sample_pool`) and folds them in
 // sample order into the RGBA32F running mean `fb` (kernel 2; W*H texels, row 0 at the bottom).
 // tiles == nullptr: all tiles of the frame (n_tiles = their count).  sample_pool must hold
-// pathtrace_pool_floats(n_tiles, n_samples) floats; unit_counter is one device word (the work queue head).  status[0] is set non-zero if a wavefront trips the watchdog.
+// pathtrace_pool_floats(n_tiles, n_samples) floats; unit_counter is 8 device words (the work queue heads, one per XCD segment).  status[0] is set non-zero if a wavefront trips the watchdog.
 size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples);
 size_t pathtrace_workspace_floats();      // cold path state of all resident wavefronts
 void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,

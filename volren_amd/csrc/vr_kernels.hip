@@ -29,18 +29,23 @@ struct SchedParams {
 
 // Persistent wavefronts.  The frame's work is cut into units = one 8x8 pixel tile x `spu` consecutive samples
 // (64*spu items); unit u = ((chunk * n_tiles + tile_slot) * 4 + sub_tile) and its items occupy slots
-// [u*64*spu, (u+1)*64*spu) of the sample buffer.  Every wavefront pulls units from one global counter and refills
+// [u*64*spu, (u+1)*64*spu) of the sample buffer.  Every wavefront pulls units from a global queue and refills
 // idle lanes item by item, WITHOUT waiting for its other lanes to finish: the only drain is at the end of the launch.
+// The queue is XCD-aware: queue position j enumerates the units tile-major (all sample chunks of a sub-tile are adjacent) and
+// the positions are cut into 8 contiguous segments, one per XCD (workgroups are dealt round-robin to the 8 XCDs, so
+// blockIdx.x & 7 names the XCD): the waves of one XCD -- which share one L2 -- work on one band of tile rows; a wave whose
+// segment is empty takes units from the next one.
+constexpr uint32_t kQueueSegments = 8u;
 struct LaunchDesc {
     const int32_t* tiles;     // 16x16 tile ids (raster, row 0 = bottom) or nullptr = all tiles
     int32_t n_tiles, first_sample, n_samples, spu;
-    uint32_t n_units;
-    uint32_t* unit_counter;   // zeroed before the launch
+    uint32_t n_units, chunks, seg_len;
+    uint32_t* unit_counter;   // kQueueSegments counters, zeroed before the launch
 };
 
-__device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, uint32_t u, float* sbuf) {
-    const uint32_t per_chunk = (uint32_t)D.n_tiles * 4u;
-    const uint32_t chunk = u / per_chunk, rem = u - chunk * per_chunk;
+__device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, uint32_t j, float* sbuf) {
+    const uint32_t rem = j / D.chunks, chunk = j - rem * D.chunks;        // queue position -> (tile slot, sub-tile), sample chunk
+    const uint32_t u = chunk * ((uint32_t)D.n_tiles * 4u) + rem;
     const uint32_t slot = rem >> 2, sub = rem & 3u;
     const int32_t tiles_x = (W + 15) >> 4;
     const int32_t tile = D.tiles ? D.tiles[slot] : (int32_t)slot;
@@ -146,6 +151,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     wu.px0 = wu.py0 = 0; wu.first_sample = 1; wu.n_items = 0; wu.base = 0u; wu.out = sbuf;
     uint32_t cursor = 0u;             // next item of the current unit (wave-uniform)
     bool exhausted = false;           // the global queue has no more units
+    uint32_t seg_tries = 0u;          // queue segments this wavefront has found empty (wave-uniform)
 
     Hot l;
     hot_init(l);
@@ -295,11 +301,17 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
             }
             if (want_new) {
                 if (cursor == (uint32_t)wu.n_items) {
-                    uint32_t u = 0u;
-                    if (lane == 0) u = atomicAdd(D.unit_counter, 1u);
-                    u = __builtin_amdgcn_readfirstlane(u);
-                    if (u >= D.n_units) exhausted = true;
-                    else { wu = make_unit(D, W, u, sbuf); cursor = 0u; }
+                    uint32_t j = 0xFFFFFFFFu;
+                    while (seg_tries < kQueueSegments) {                    // own segment first, then the following ones
+                        const uint32_t k = ((blockIdx.x & (kQueueSegments - 1u)) + seg_tries) & (kQueueSegments - 1u);
+                        const uint32_t lo = k * D.seg_len, hi = min(lo + D.seg_len, D.n_units);
+                        uint32_t v = 0xFFFFFFFFu;
+                        if (lo < hi) { if (lane == 0) v = atomicAdd(D.unit_counter + k, 1u); v = __builtin_amdgcn_readfirstlane(v); }
+                        if (lo < hi && v < hi - lo) { j = lo + v; break; }
+                        ++seg_tries;                                        // this segment is used up for good
+                    }
+                    if (j == 0xFFFFFFFFu) exhausted = true;
+                    else { wu = make_unit(D, W, j, sbuf); cursor = 0u; }
                 }
                 n = min(min(64, cnt_free), (int32_t)((uint32_t)wu.n_items - cursor));
                 if (n > 0) {
@@ -364,7 +376,7 @@ __global__ void __launch_bounds__(256)
 dvr_kernel(const SceneParams P, float* __restrict__ sbuf, const LaunchDesc D) {
     const uint32_t per_unit = (uint32_t)(D.spu * 64);
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t u = g / per_unit, item = g - u * per_unit;
+    const uint32_t u = g / per_unit, item = g - u * per_unit;      // dvr: queue position order, one thread per item
     if (u >= D.n_units) return;
     const WorkUnit wu = make_unit(D, P.u.resolution[0], u, sbuf);
     if ((int32_t)item >= wu.n_items) return;
@@ -372,7 +384,7 @@ dvr_kernel(const SceneParams P, float* __restrict__ sbuf, const LaunchDesc D) {
     if (px >= P.u.resolution[0] || py >= P.u.resolution[1]) return;
     float L[4];
     dvr_sample(P, px, py, wu.first_sample + (int32_t)(item >> 6), L);
-    reinterpret_cast<float4*>(sbuf)[g] = make_float4(L[0], L[1], L[2], L[3]);
+    reinterpret_cast<float4*>(sbuf)[wu.base + item] = make_float4(L[0], L[1], L[2], L[3]);
 }
 
 // Running mean over the samples of one launch, in sample order (pathtracer_brick.glsl:36): one thread per pixel.
@@ -450,6 +462,8 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     D.spu = n_samples < g_samples_per_unit ? n_samples : g_samples_per_unit;
     const int32_t chunks = (n_samples + D.spu - 1) / D.spu;
     D.n_units = (uint32_t)chunks * (uint32_t)n_tiles * 4u;
+    D.chunks = (uint32_t)chunks;
+    D.seg_len = (D.n_units + kQueueSegments - 1u) / kQueueSegments;
     D.unit_counter = unit_counter;
     S.max_iters = 1u << 27;          // watchdog (see the kernel): ~100x the iterations of the heaviest wavefront seen
     auto kernel = P.u.use_tf ? (g_stats ? pathtrace_kernel<true, true> : pathtrace_kernel<true, false>)
@@ -463,7 +477,7 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
         const uint64_t items = (uint64_t)D.n_units * (uint64_t)(D.spu * 64);
         hipLaunchKernelGGL(dvr_kernel, dim3((unsigned)((items + 255) / 256)), block, 0, stream, P, sample_pool, D);
     } else {
-        (void)hipMemsetAsync(unit_counter, 0, sizeof(uint32_t), stream);
+        (void)hipMemsetAsync(unit_counter, 0, kQueueSegments * sizeof(uint32_t), stream);
         hipLaunchKernelGGL(kernel, grid, block, 0, stream, P, sample_pool, workspace, D, S, status, g_stats);
     }
     hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)n_tiles), block, 0, stream, sample_pool, fb, tiles, n_tiles,
