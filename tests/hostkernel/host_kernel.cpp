@@ -91,7 +91,16 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
     HostGrid dg, eg;
     build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true);
     P.density = dg.view;
-    P.density.dense = density->dense;
+    std::vector<uint16_t> blocked;                 // == dense_grid_to_device: 4x4x4 blocks
+    if (density->dense) {
+        const uint32_t dx = density->dim[0], dy = density->dim[1], dz = density->dim[2];
+        const uint32_t bx = (dx + 3u) / 4u, by = (dy + 3u) / 4u, bz = (dz + 3u) / 4u;
+        blocked.assign((size_t)bx * by * bz * 64u, 0);
+        for (uint32_t z = 0; z < dz; ++z) for (uint32_t y = 0; y < dy; ++y) for (uint32_t x = 0; x < dx; ++x)
+            blocked[dense_blocked_index(x, y, z, bx, by)] = density->dense[((size_t)z * dy + y) * dx + x];
+        P.density.dense = blocked.data();
+        P.density.dblk[0] = (int32_t)bx; P.density.dblk[1] = (int32_t)by;
+    }
     for (int i = 0; i < 3; ++i) P.density.dim[i] = (int32_t)density->dim[i];
     if (emission && u.has_emission) {
         build_grid(eg, u, lut, emission->nb, emission->indirection, emission->range, emission->atlas_dim, emission->atlas, emission->n_mips, emission->mips, false);

@@ -183,8 +183,18 @@ BrickGridHIP RendererHIP::dense_grid_to_device(const std::shared_ptr<DenseGridF1
     out.dim[0] = (int)g->dim.x; out.dim[1] = (int)g->dim.y; out.dim[2] = (int)g->dim.z;
     if (g->dim.x > 65535u || g->dim.y > 65535u || g->dim.z > 65535u) throw std::runtime_error("dense_grid_to_device: more than 65535 voxels along an axis");
     out.transform = g->transform;
-    out.dense = make_device_buffer(g->voxels.size() * sizeof(uint16_t));
-    out.dense->upload(g->voxels.data(), g->voxels.size() * sizeof(uint16_t));
+    // re-tile [z][y][x] into 4x4x4 blocks of 128 contiguous bytes (vr_scene.h), zero padded
+    const uint32_t bx = (g->dim.x + 3u) / 4u, by = (g->dim.y + 3u) / 4u, bz = (g->dim.z + 3u) / 4u;
+    if ((uint64_t)bx * by * bz > (1ull << 31)) throw std::runtime_error("dense_grid_to_device: more than 2^31 blocks");
+    out.dblk[0] = (int)bx; out.dblk[1] = (int)by;
+    std::vector<uint16_t> blocked((size_t)bx * by * bz * 64u, 0);
+    for (uint32_t z = 0; z < g->dim.z; ++z)
+        for (uint32_t y = 0; y < g->dim.y; ++y) {
+            const uint16_t* row = &g->voxels[((size_t)z * g->dim.y + y) * g->dim.x];
+            for (uint32_t x = 0; x < g->dim.x; ++x) blocked[dense_blocked_index(x, y, z, bx, by)] = row[x];
+        }
+    out.dense = make_device_buffer(blocked.size() * sizeof(uint16_t));
+    out.dense->upload(blocked.data(), blocked.size() * sizeof(uint16_t));
     upload_range_words(out, nb, g->range, g->range_mipmaps);
     return out;
 }
@@ -258,6 +268,7 @@ static GridView make_view(const BrickGridHIP& g) {
     v.atlas = g.atlas ? g.atlas->as<uint8_t>() : nullptr;
     v.dense = g.dense ? g.dense->as<uint16_t>() : nullptr;
     for (int i = 0; i < 3; ++i) v.dim[i] = g.dim[i];
+    for (int i = 0; i < 2; ++i) v.dblk[i] = g.dblk[i];
     v.majorant = g.majorant->as<float>();
     for (int i = 0; i < 3; ++i) v.nb[i] = g.nb[i];
     for (int i = 0; i < 2; ++i) v.bshift[i] = g.bshift[i];

@@ -35,8 +35,9 @@ struct BrickGridHIP {
     DeviceBufferPtr atlas;         // brick-major u8 voxels, 512 B per slot
     DeviceBufferPtr range_words;   // fp16x2 range of every cell of mips 0..n_mips (input of the majorant kernel)
     DeviceBufferPtr majorant;      // effective majorants (float), padded power-of-two layout (vr_scene.h)
-    DeviceBufferPtr dense;         // dense fp16 voxels (DenseGridF16), then bricks/atlas are empty
+    DeviceBufferPtr dense;         // dense fp16 voxels in 4x4x4 blocks (DenseGridF16), then bricks/atlas are empty
     int32_t dim[3] = { 0, 0, 0 };
+    int32_t dblk[2] = { 0, 0 };            // 4x4x4 blocks per axis (x, y) of the dense layout
     int32_t nb[3] = { 0, 0, 0 };
     int32_t mip_off[4] = { 0, 0, 0, 0 };   // word offset of each level inside range_words (compact)
     int32_t n_mips = 0;

@@ -31,6 +31,11 @@ VR_SCENE_HD int32_t ceil_log2(uint32_t v) { int32_t s = 0; while (s < 31 && (1u 
 VR_SCENE_HD uint32_t majorant_level_offset(uint32_t k, uint32_t mip) { const uint32_t s = 9u - 3u * mip; return ((0x49u >> s) << s) << (k - 6u); }
 VR_SCENE_HD size_t majorant_padded_cells(uint32_t k) { return (size_t)majorant_level_offset(k, 3u) + ((size_t)1 << (k - 9u)); }
 
+// element index of voxel (x, y, z) in the blocked dense layout (see GridView::dense)
+VR_SCENE_HD size_t dense_blocked_index(uint32_t x, uint32_t y, uint32_t z, uint32_t blocks_x, uint32_t blocks_y) {
+    return (((size_t)(z >> 2) * blocks_y + (y >> 2)) * blocks_x + (x >> 2)) * 64u + (((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u));
+}
+
 struct GridView {
     const BrickRec* bricks;      // nb[2] << (bshift[0] + bshift[1]) records, power-of-two pitches (see above)
     const uint8_t* atlas;        // slots * 512 bytes, voxel (x&7) + 8*(y&7) + 64*(z&7)
@@ -39,8 +44,10 @@ struct GridView {
     int32_t bshift[2];           // log2 of the brick-record pitches (x, y)
     int32_t mshift[3];           // log2 of the padded level-0 majorant extent per axis (each >= 3)
     int32_t n_mips;              // range mips available above level 0 (reference: 3)
-    const uint16_t* dense;       // dense fp16 voxels [z][y][x] (then bricks/atlas are unused), or nullptr
+    const uint16_t* dense;       // dense fp16 voxels in 4x4x4 blocks of 128 contiguous bytes (one cache line): block (x>>2, y>>2, z>>2),
+                                 // x fastest over dblk[0] x dblk[1] x ceil(dim.z/4) blocks, voxel (x&3) + 4*(y&3) + 16*(z&3) inside; or nullptr
     int32_t dim[3];              // voxel extent of the dense grid
+    int32_t dblk[2];             // blocks per axis (x, y) = ceil(dim / 4)
 };
 
 struct Uniforms {                // names follow the GLSL uniforms

@@ -100,7 +100,9 @@ VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
     if ((x | y | z) < 0) return 0.0f;
     if (g.dense) {          // dense fp16 grid: one 2-byte load, no indirection
         if ((uint32_t)x >= (uint32_t)g.dim[0] || (uint32_t)y >= (uint32_t)g.dim[1] || (uint32_t)z >= (uint32_t)g.dim[2]) return 0.0f;
-        return half2float(g.dense[(size_t)(mul24((uint32_t)z, (uint32_t)g.dim[1]) + (uint32_t)y) * (uint32_t)g.dim[0] + (uint32_t)x]);   // dims < 2^16
+        // 4x4x4 blocks (vr_scene.h): neighbouring rays and the +-2-voxel stochastic taps share 128-byte lines; block counts < 2^14 per axis
+        const uint32_t blk = (mul24((uint32_t)z >> 2, (uint32_t)g.dblk[1]) + ((uint32_t)y >> 2)) * (uint32_t)g.dblk[0] + ((uint32_t)x >> 2);
+        return half2float(g.dense[(size_t)blk * 64u + ((((uint32_t)z & 3u) << 4) | (((uint32_t)y & 3u) << 2) | ((uint32_t)x & 3u))]);
     }
     const uint32_t bx = (uint32_t)x >> 3, by = (uint32_t)y >> 3, bz = (uint32_t)z >> 3;
     if (bx >= (uint32_t)g.nb[0] || by >= (uint32_t)g.nb[1] || bz >= (uint32_t)g.nb[2]) return 0.0f;
