@@ -1,6 +1,6 @@
 // vr_kernels.hip -- gfx950 kernels of the volume path tracer.
 //
-// pathtrace_kernel (the hot path): persistent wavefronts pull (8x8 pixel tile x 4 samples) work units from one global
+// pathtrace_kernel (the hot path): persistent wavefronts pull (8x8 pixel tile x 8 samples) work units from an XCD-aware
 // counter; each wavefront keeps a private pool of more path slots than it has lanes, so that the frequent march/collide
 // code always finds lanes to fill and the rare, expensive events (new sample with the 32-round TEA hash, next-event
 // estimation, scatter, escape) run as near-full-width batches of parked paths.  The per-path code -- the reference's
@@ -413,9 +413,9 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
 
 // thr[]: NEW (free slots that trigger a NEW batch), unused, MARCH (= low-water mark of live paths: below it every
 // non-empty batch runs), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
-static SchedParams g_sched = { { 64, 0, 48, 2, 56, 56, 64, 0 }, 0u };
+static SchedParams g_sched = { { 64, 0, 56, 2, 60, 60, 64, 0 }, 0u };
 static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
-static int32_t g_samples_per_unit = 4;
+static int32_t g_samples_per_unit = 8;
 static int32_t g_blocks_per_cu = 0;                 // 0 = from the occupancy query
 
 void set_stats_buffer(unsigned long long* dev) { g_stats = dev; }
