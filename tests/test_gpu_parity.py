@@ -533,3 +533,47 @@ def test_hip_against_reference_glsl_golden():
         tol = 1e-3 if name == "c3_tf_spec" or name.endswith("global_spec") else 1e-5
         assert (rel <= tol).mean() > 0.995, (name, float((rel <= tol).mean()))
         assert rl2 < 5e-2 and abs(hip[..., :3].mean() / ref[..., :3].mean() - 1.0) < 1e-3, (name, rl2)
+
+
+@pytest.mark.parametrize("case", ["fov0", "fov180", "cam_inside", "axis_aligned", "huge_density", "zero_albedo"])
+def test_degenerate_inputs_match_oracle(case):
+    """Non-finite and boundary arithmetic: rays with infinite / NaN components (fov 0 gives z = -0.5 / tan(0) = -inf, hence NaN
+    directions), a camera inside the volume, a ray direction with exact zeros (1 / 0 in the DDA set-up), a density scale that
+    saturates every majorant, zero albedo.  The device-only shortcuts (saturating voxel indices, NaN guard, guard-banded
+    filter tests) must leave the result identical to the oracle's plain arithmetic."""
+    def setup(r):
+        if case == "fov0":
+            r.cam_fov = 0.0
+        elif case == "fov180":
+            r.cam_fov = 180.0
+        elif case == "cam_inside":
+            r.cam_pos, r.cam_dir = (0.0, 0.1, 0.0), (0.0, 0.0, -1.0)
+        elif case == "axis_aligned":
+            r.cam_pos, r.cam_dir, r.cam_fov = (0.0, 0.0, 1.0), (0.0, 0.0, -1.0), 1e-3
+        elif case == "huge_density":
+            r.density_scale = 1e6            # ~2300 DDA steps per sample, majorants near the fp16 range times 1e6
+        elif case == "zero_albedo":
+            r.albedo = (0.0, 0.0, 0.0)
+    o = scenes.oracle_scene("c1", 48, 40)
+    r = scenes.hip_scene("c1", 48, 40)
+    setup(o)
+    setup(r)
+    r.render(4)
+    _assert_same(r.framebuffer(), o.render(4), "degenerate input: " + case)
+
+
+def test_watchdog_turns_a_non_terminating_input_into_an_error():
+    """density_scale = 1e30 overflows every majorant to +inf; the reference's tracker then never terminates (the oracle
+    does not either: `timeout 60 python -c ...` in DESIGN.md).  The kernel must not hang the GPU: its watchdog ends the
+    wavefronts after ~8 s of shader clock and the next call reports it; the renderer stays usable."""
+    import volren_amd
+    r = scenes.hip_scene("c1", 32, 32)
+    good = r.density_scale
+    r.density_scale = 1e30
+    with pytest.raises(volren_amd.VolrenError, match="watchdog"):
+        r.render(1)
+    r.density_scale = good
+    r.reset()
+    r.render(2)
+    o = scenes.oracle_scene("c1", 32, 32)
+    _assert_same(r.framebuffer(), o.render(2), "render after a watchdog trip")
