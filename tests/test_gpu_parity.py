@@ -554,12 +554,15 @@ def test_degenerate_inputs_match_oracle(case):
             r.density_scale = 1e6            # ~2300 DDA steps per sample, majorants near the fp16 range times 1e6
         elif case == "zero_albedo":
             r.albedo = (0.0, 0.0, 0.0)
-    o = scenes.oracle_scene("c1", 48, 40)
-    r = scenes.hip_scene("c1", 48, 40)
-    setup(o)
-    setup(r)
-    r.render(4)
-    _assert_same(r.framebuffer(), o.render(4), "degenerate input: " + case)
+    for cfg in ("c1", "c3"):             # stochastic tricubic taps / trilinear + transfer function
+        o = scenes.oracle_scene(cfg, 48, 40)
+        r = scenes.hip_scene(cfg, 48, 40)
+        if cfg == "c3":
+            o.bounces = r.bounces = 6
+        setup(o)
+        setup(r)
+        r.render(4)
+        _assert_same(r.framebuffer(), o.render(4), "degenerate input: %s (%s)" % (case, cfg))
 
 
 def test_watchdog_turns_a_non_terminating_input_into_an_error():
