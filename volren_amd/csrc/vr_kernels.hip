@@ -143,8 +143,9 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NSLOT];
     const HotStore hs{ lds_hot + wave * (HOT_STRIDE * NSLOT) };
 
-    int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = NSLOT;     // stack heights (wave-uniform)
-    for (int32_t i = lane; i < NSLOT; i += 64) q[Q_FREE * NSLOT + i] = (uint8_t)i;
+    const int32_t pool = (S.thr[ST_BEGIN] > 0 && S.thr[ST_BEGIN] < NSLOT) ? S.thr[ST_BEGIN] : NSLOT;     // slots in use (diagnostic cap)
+    int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = pool;     // stack heights (wave-uniform)
+    for (int32_t i = lane; i < pool; i += 64) q[Q_FREE * NSLOT + i] = (uint8_t)i;
     __builtin_amdgcn_wave_barrier();
 
     WorkUnit wu;
@@ -350,7 +351,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
             if (my_slot >= 0) hs.load(l, my_slot);
 #endif
         }
-        if (exhausted && cnt_free == NSLOT) break;                        // every path of the pool has finished
+        if (exhausted && cnt_free == pool) break;                        // every path of the pool has finished
     }
     if (STATS && stats && lane == 0) {
 #pragma unroll
@@ -411,7 +412,7 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
     *texel = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
-// thr[]: NEW (free slots that trigger a NEW batch), unused, MARCH (= low-water mark of live paths: below it every
+// thr[]: NEW (free slots that trigger a NEW batch), diagnostic cap on the slots in use (0 = all NSLOT), MARCH (= low-water mark of live paths: below it every
 // non-empty batch runs), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
 static SchedParams g_sched = { { 64, 0, 56, 2, 60, 60, 64, 0 }, 0u };
 static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
