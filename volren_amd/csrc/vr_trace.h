@@ -132,16 +132,62 @@ VR_HD int32_t nan_guard(int32_t ix, float fx, float fy, float fz) {
 #endif
 }
 
+// The 8 corner fetches of the trilinear lookup share their per-axis arithmetic: 2 cell coordinates, 2 in-cell offsets and 2
+// validity tests per axis instead of 8 x 3.  A corner outside the grid reads 0 (as brick_value does); its address is clamped to
+// cell 0 so that all 16 loads are unconditional and independent.
+struct AxisCells { uint32_t c[2], o[2]; bool in[2]; };
+VR_HD AxisCells axis_cells(int32_t i0, int32_t i1, uint32_t extent_voxels, uint32_t log2_cell) {
+    AxisCells a;
+    const int32_t i[2] = { i0, i1 };
+    const uint32_t mask = (1u << log2_cell) - 1u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        a.in[t] = i[t] >= 0 && (uint32_t)i[t] < extent_voxels;
+        a.c[t] = a.in[t] ? (uint32_t)i[t] >> log2_cell : 0u;
+        a.o[t] = a.in[t] ? (uint32_t)i[t] & mask : 0u;
+    }
+    return a;
+}
 VR_HD float density_trilinear_raw(const GridView& g, v3 ipos) {
     const float qx = ipos.x - 0.5f, qy = ipos.y - 0.5f, qz = ipos.z - 0.5f;
     const float flx = floor_(qx), fly = floor_(qy), flz = floor_(qz);
     const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
     const int32_t ix = nan_guard(voxel_index(flx, 0), flx, fly, flz), iy = voxel_index(fly, 0), iz = voxel_index(flz, 0);
     const int32_t x1 = nan_guard(voxel_index(flx, 1), flx, fly, flz), y1 = voxel_index(fly, 1), z1 = voxel_index(flz, 1);
-    const float lx0 = mix_(brick_value(g, ix, iy, iz), brick_value(g, x1, iy, iz), fx);
-    const float lx1 = mix_(brick_value(g, ix, y1, iz), brick_value(g, x1, y1, iz), fx);
-    const float hx0 = mix_(brick_value(g, ix, iy, z1), brick_value(g, x1, iy, z1), fx);
-    const float hx1 = mix_(brick_value(g, ix, y1, z1), brick_value(g, x1, y1, z1), fx);
+    float v[2][2][2];      // [z][y][x]
+    if (g.dense) {
+        const AxisCells X = axis_cells(ix, x1, (uint32_t)g.dim[0], 2u), Y = axis_cells(iy, y1, (uint32_t)g.dim[1], 2u), Z = axis_cells(iz, z1, (uint32_t)g.dim[2], 2u);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t row = (mul24(Z.c[k], (uint32_t)g.dblk[1]) + Y.c[j]) * (uint32_t)g.dblk[0];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float val = half2float(g.dense[(size_t)(row + X.c[i]) * 64u + ((Z.o[k] << 4) | (Y.o[j] << 2) | X.o[i])]);
+                    v[k][j][i] = (X.in[i] & Y.in[j] & Z.in[k]) ? val : 0.0f;
+                }
+            }
+    } else {
+        const AxisCells X = axis_cells(ix, x1, (uint32_t)g.nb[0] << 3, 3u), Y = axis_cells(iy, y1, (uint32_t)g.nb[1] << 3, 3u), Z = axis_cells(iz, z1, (uint32_t)g.nb[2] << 3, 3u);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t row = ((Z.c[k] << g.bshift[1]) + Y.c[j]) << g.bshift[0];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const BrickRec rec = g.bricks[row + X.c[i]];
+                    const uint32_t b = g.atlas[(size_t)rec.slot * 512u + ((Z.o[k] << 6) | (Y.o[j] << 3) | X.o[i])];
+                    const float val = rec.rmin + unorm8(b) * rec.rdiff;
+                    v[k][j][i] = (X.in[i] & Y.in[j] & Z.in[k]) ? val : 0.0f;
+                }
+            }
+    }
+    const float lx0 = mix_(v[0][0][0], v[0][0][1], fx);
+    const float lx1 = mix_(v[0][1][0], v[0][1][1], fx);
+    const float hx0 = mix_(v[1][0][0], v[1][0][1], fx);
+    const float hx1 = mix_(v[1][1][0], v[1][1][1], fx);
     return mix_(mix_(lx0, lx1, fy), mix_(hx0, hx1, fy), fz);
 }
 
