@@ -191,6 +191,14 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("config") == args.config and tj.get("width") == w and tj.get("height") == h:
                 traffic = tj["hbm_bytes_per_sample"] * (my_samples / launches)
+        valu = None                                              # what actually bounds the kernel: VALU issue (PMC pass, profiles/)
+        ppath = os.path.join(ROOT, "profiles", "r1_g_pmc_counters.json")
+        if os.path.exists(ppath) and args.config == "c2" and (w, h) == (1024, 1024):
+            c = json.load(open(ppath))["counters"]
+            valu = {"busy": c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / 4.0),
+                    "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]),
+                    "valu_instructions_per_sample": c["SQ_INSTS_VALU"] / float(json.load(open(ppath))["samples"]),
+                    "source": "profiles/r1_g_pmc_counters.json (rocprofv3 --pmc, tests/tools_profile_run.py c2 1024 128)"}
         out = {
             "metric": "Msamples/s (pixels x spp / s), volume path tracing",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,7 +212,8 @@ def main():
                          "traffic": traffic, "kernel": "pathtrace_kernel<%s,false>" % ("true" if use_tf else "false"),
                          "kernel_ms": launch_ms, "launches_per_step": launches, "samples_per_launch": my_samples / launches,
                          "bytes_per_sample": b_sample, "events_per_sample": events,
-                         "note": "bytes = algorithmic (SURVEY 8d); the scene is cache resident and the kernel is VALU-issue/latency bound, see DESIGN.md 5/7"},
+                         "valu": valu,
+                         "note": "bytes = algorithmic (SURVEY 8d); the scene is cache resident and the kernel is bound by VALU issue (vector ALUs busy ~92 % of the time, see `valu` and DESIGN.md 7), not by HBM bandwidth"},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
