@@ -394,8 +394,18 @@ void RendererHIP::launch(int n) {
     int per_launch = (int)std::max<size_t>(1, sample_pool_bytes / per_sample);
     if (per_launch > 32) per_launch -= per_launch % 32;          // whole sample chunks (32 is a multiple of every unit size)
     per_launch = std::min(per_launch, n);
-    const size_t need = pathtrace_pool_floats(n_tiles, per_launch) * sizeof(float);
-    if (!pool_ || pool_->size_bytes() < need) { pool_.reset(); pool_ = make_device_buffer(need); }
+    for (;;) {                                                   // a pool that does not fit the free HBM: halve the sub-launch, never fail for it
+        const size_t need = pathtrace_pool_floats(n_tiles, per_launch) * sizeof(float);
+        if (pool_ && pool_->size_bytes() >= need) break;
+        pool_.reset();
+        try { pool_ = make_device_buffer(need); break; }
+        catch (const std::exception&) {
+            (void)hipGetLastError();
+            if (per_launch <= 1) throw;
+            per_launch = std::max(1, per_launch / 2);
+            if (per_launch > 32) per_launch -= per_launch % 32;
+        }
+    }
     if (!workspace_) workspace_ = make_device_buffer(pathtrace_workspace_floats() * sizeof(float));
     VR_HIP(hipEventRecord(ev0_, stream));
     last_launches = 0;
