@@ -9,7 +9,8 @@ CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unu
 HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 OBJDIR   := build
 SRCS_CPP := grids.cpp imageio.cpp environment.cpp transferfunc.cpp renderer.cpp capi.cpp
-OBJS     := $(OBJDIR)/vr_kernels.o $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
+PT_VARIANTS := 0 1 2 3
+OBJS     := $(OBJDIR)/vr_kernels.o $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_%.o) $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
 HDRS     := $(wildcard $(CSRC)/*.h) include/volren_amd.h
 
 all: volren_amd/libvolren_amd.so volren_amd/volren oracle
@@ -17,6 +18,11 @@ all: volren_amd/libvolren_amd.so volren_amd/volren oracle
 $(OBJDIR)/vr_kernels.o: $(CSRC)/vr_kernels.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+# the path-tracing kernel, one compilation per variant (vr_pathtrace.hip); resource usage goes to build/*.resources.txt
+$(OBJDIR)/vr_pathtrace_%.o: $(CSRC)/vr_pathtrace.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_pathtrace_$*.resources.txt || (cat $(OBJDIR)/vr_pathtrace_$*.resources.txt; false)
 
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)

@@ -5,18 +5,26 @@ A "step" is one full frame of BASELINE.json configs[1] ("c2": data/smoke.brick, 
 1024 spp, 100 bounces, fov 40, seed 42): W*H*spp pixel-samples through the fused HIP path-tracing kernel, scene
 resident in HBM before the timed region.  Metric: Msamples/s = W*H*spp / wall time of the sample loop.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): the frame's 16x16 tiles are sharded over the ranks
-(diagonal interleave), every rank renders its tiles, and the accumulated radiance is exchanged with ONE RCCL
-all_gather of the compact per-rank tile buffers per frame.  Total work is fixed, so scaling is "strong".
+`python bench.py --gpus N` starts its own N ranks (one per GPU, torch.distributed.run on 127.0.0.1) BEFORE anything touches
+the GPU and exits with their status; under an external torchrun (RANK/WORLD_SIZE set) it is a rank.  Multi-GPU: the
+frame's 16x16 tiles are sharded over the ranks (diagonal interleave), every rank renders its tiles, and the accumulated
+radiance is exchanged with ONE RCCL all_gather of the compact per-rank tile buffers per frame.  Total work is fixed, so
+scaling is "strong".
 
 Adds to the JSON line:
   roofline     -- algorithmic HBM bytes (SURVEY.md 8d formula, event counts from the oracle's instrumented counters on
                   the same config) / HIP-event duration of the path-tracing kernel, vs 8 TB/s.
-  cpu_baseline -- the CPU oracle ("port") timed on the host cores on a bounded sample of the same workload.
+  cpu_baseline -- the CPU oracle ("port") timed on the host cores on a bounded sample of the same workload, plus
+                  cpu_baseline_raymarch: the 64-step ray marcher (common.glsl:506-566) SURVEY 8d names.
+  configs      -- (N=1, headline config only) the same measurement for BASELINE configs[2] (c3) and configs[3]'s grid (c4,
+                  512^3 dense fp16) at 1024x1024 / 1024 spp, the resolution north_star quotes its 40 % target at.
+  fast_math    -- (when built) the tolerance-mode kernels: speed and relative L2 against the bit-exact default.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,9 +34,46 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}
 
 
-def algorithmic_bytes_per_sample(counters, spp, use_tf, has_emission, dense=False):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", help="c1 | c2 | c3 | readme | c4[:N] (synthetic N^3 dense fp16 grid, default 512) | c5[:N] (synthetic sparse brick grid + emission)")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
+    ap.add_argument("--extra-configs", default=None, help="comma list of further configs measured at N=1 and reported under 'configs' (default: c3,c4 for the headline run; 'none' to skip)")
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous and exchange one tile buffer (no rendering): checks the launcher path")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N ranks as CHILD processes and wait.  Nothing in this process has touched the GPU
+    (torch is not even imported yet), and no process that has is ever replaced by another program."""
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def algorithmic_bytes_per_sample(counters, use_tf, has_emission, dense=False):
     """B = 4*N_dda + b_tap*T*N_coll + b_em*N_coll_sv + 200*N_nee + 48*N_esc + B_fb, with
     B_fb = 32 B: 16 B written to the per-sample radiance pool + 16 B read back by the ordered accumulate pass
     (the same 32 B the reference's per-dispatch image read-modify-write costs)."""
@@ -45,13 +90,18 @@ def algorithmic_bytes_per_sample(counters, spp, use_tf, has_emission, dense=Fals
                    primary_miss=counters["n_primary_miss"] / n)
 
 
-def cpu_baseline_and_counters(config, w, h, budget_s):
+def cpu_baseline_and_counters(config, budget_s, integrator=0, kind="port"):
     """Oracle on the host cores: low-resolution full view of the same scene (same camera, so the same mix of
     box-missing and cloud pixels), spp chosen to fill ~budget_s seconds."""
     import scenes
     from oracle import binding as ob
     cw = ch = 512
-    o = scenes.oracle_scene(config, cw, ch)
+
+    def scene():
+        o = scenes.oracle_scene(config, cw, ch)
+        o.integrator = integrator
+        return o
+    o = scene()
     o.render(1)                                          # library load, thread pool start
     probe = 1
     while True:                                          # probe long enough (>= 1 s) that burst clocks / quotas do not skew the estimate
@@ -63,160 +113,232 @@ def cpu_baseline_and_counters(config, w, h, budget_s):
         probe *= 2
     rate = cw * ch * probe / max(dt, 1e-6)
     spp = int(max(1, min(4096, budget_s * rate / (cw * ch))))
-    o2 = scenes.oracle_scene(config, cw, ch)
+    o2 = scene()
     t0 = time.time()
     o2.render(spp)
     dt = time.time() - t0
     cores = ob.lib().orc_num_threads()
-    return dict(value=cw * ch * spp / dt / 1e6, unit="Msamples/s", cores=int(cores), kind="port",
-                sample="%s scene at %dx%d, %d spp (%.1f s of oracle/liboracle.so, OpenMP over rows)" % (config, cw, ch, spp, dt)), o2.counters.as_dict()
+    what = "oracle/liboracle.so, OpenMP over rows" + (", 64-step ray-marching trackers (common.glsl:506-566)" if integrator == 3 else "")
+    return dict(value=cw * ch * spp / dt / 1e6, unit="Msamples/s", cores=int(cores), kind=kind,
+                sample="%s scene at %dx%d, %d spp (%.1f s of %s)" % (config, cw, ch, spp, dt, what)), o2.counters.as_dict()
+
+
+def profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+class Bench:
+    """One configuration on this rank's GPU: scene resident, tile shard set up, step() = one frame."""
+
+    def __init__(self, config, w, h, spp, world, rank, local_rank, dist, fast_math=False):
+        import torch
+        import scenes
+        from volren_amd.shard import TileShard
+        self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
+        self.config, self.w, self.h, self.spp = config, w, h, spp
+        self.r = scenes.hip_scene(config, w, h, device=local_rank)
+        if fast_math:
+            self.r.fast_math = 1
+        self.r.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.shard = TileShard(w, h, world, rank)
+        self.staged = world > 1 and os.environ.get("VOLREN_DIST_BACKEND", "nccl") != "nccl"
+        if world > 1:
+            self.r.set_tiles(self.shard.mine)
+            self.tiles_dev = torch.from_numpy(self.shard.pack_ids).cuda()
+            self.all_tiles_dev = torch.from_numpy(self.shard.unpack_ids).cuda()
+            self.packed = torch.empty(self.shard.packed_floats, dtype=torch.float32, device="cuda")
+            self.gathered = torch.empty(self.shard.gathered_floats, dtype=torch.float32, device="cuda")
+
+    def step(self):
+        r, torch = self.r, self.torch
+        r.reset()
+        r.render(self.spp, sync=False)                                          # ONE fused launch: all spp of all owned tiles
+        if self.world > 1:
+            r.pack_tiles(self.tiles_dev.data_ptr(), self.shard.n_max, self.packed.data_ptr())
+            if self.staged:
+                hg = torch.empty(self.gathered.shape, dtype=self.gathered.dtype)
+                self.shard.all_gather(self.dist, hg, self.packed.cpu())
+                self.gathered.copy_(hg)
+            else:
+                self.shard.all_gather(self.dist, self.gathered, self.packed)    # RCCL over xGMI, once per frame
+            r.unpack_tiles(self.all_tiles_dev.data_ptr(), self.world * self.shard.n_max, self.gathered.data_ptr())
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, steps, warmup):
+        torch, dist = self.torch, self.dist
+        for _ in range(warmup):
+            self.step()
+        self.barrier()
+        self.r.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        self.r.synchronize()                                                    # also raises if the kernel watchdog tripped
+        last_ms = self.r.last_kernel_ms()                                       # HIP events on the renderer's stream around the last frame's launches
+        if self.world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if not self.staged else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        samples = float(self.w) * self.h * self.spp
+        launches = max(1, self.r.last_launches)                                 # a frame is split so that a sub-launch fits the sample pool
+        my_samples = len(self.shard.mine) * 256.0 * self.spp if self.world > 1 else samples
+        return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=last_ms / launches,
+                    launches=launches, samples_per_launch=my_samples / launches)
+
+    def roofline(self, m, counters):
+        cfg = self.config
+        use_tf = cfg == "c3"
+        b_sample, events = algorithmic_bytes_per_sample(counters, use_tf, cfg.startswith("c5"), dense=cfg.startswith("c4"))
+        achieved = b_sample * m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tj = profile_json("r2_hbm_traffic.json")                                # PMC passes (FETCH_SIZE / WRITE_SIZE), collected separately
+        if tj and cfg in tj.get("configs", {}):
+            traffic = tj["configs"][cfg]["hbm_bytes_per_sample"] * m["samples_per_launch"]
+            traffic_src = {"from_profile": "profiles/r2_hbm_traffic.json", "note": "not measured by this run: rocprofv3 --pmc passes of %s, scaled to this launch's samples" % tj["configs"][cfg].get("command", "?")}
+        variant = "dense" if cfg.startswith("c4") else ("emission" if cfg.startswith("c5") else "brick")
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "pathtrace_kernel<TraceCfg<tf=%s, %s>, false>" % ("true" if use_tf else "false", variant),
+                "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "samples_per_launch": m["samples_per_launch"],
+                "bytes_per_sample": b_sample, "events_per_sample": events,
+                "note": "bytes = algorithmic (SURVEY 8d); the kernel is bound by per-wavefront instruction issue and gather latency, not by HBM bandwidth (DESIGN.md 7)"}
+
+
+def workload_name(config, w, h, spp):
+    what = "synthetic dense fp16 grid" if config.startswith("c4") else ("synthetic sparse brick grid + temperature grid (emission)" if config.startswith("c5") else "smoke.brick")
+    tf = " + lut.txt" if config == "c3" else (", no transfer function" if not config.startswith(("c4", "c5")) else "")
+    return "BASELINE configs[%d] '%s': %s%s, %dx%d, %d spp, seed 42, fov 40" % (CONFIG_INDEX.get(config[:2], -1), config, what, tf, w, h, spp)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", help="c1 | c2 | c3 | readme | c4[:N] (synthetic N^3 dense fp16 grid, default 512) | c5[:N] (synthetic sparse brick grid + emission)")
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
-    args = ap.parse_args()
-
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                       # parent: children do the work, rank 0 prints the JSON line
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
 
+    backend = os.environ.get("VOLREN_DIST_BACKEND", "nccl")
     import torch
-    import scenes
-    import volren_amd
+    dist = None
+    if args.launch_check:
+        # launcher path only: rendezvous, one all_gather of a per-rank tile buffer, barrier -- no renderer, no GPU needed with gloo
+        import numpy as np
+        from volren_amd.shard import TileShard
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+        shard = TileShard(args.width, args.height, world, rank)
+        dev = "cuda" if backend == "nccl" and world > 1 else "cpu"
+        packed = torch.full((shard.packed_floats,), float(rank), dtype=torch.float32, device=dev)
+        gathered = torch.empty(shard.gathered_floats, dtype=torch.float32, device=dev)
+        if world > 1:
+            shard.all_gather(dist, gathered, packed)
+            dist.barrier()
+            ok = bool(np.array_equal(gathered.cpu().numpy().reshape(world, -1)[:, 0], np.arange(world, dtype=np.float32)))
+        else:
+            ok = True
+        if rank == 0:
+            print(json.dumps({"launch_check": ok, "n_gpus": world, "backend": backend if world > 1 else None, "tiles_per_rank": int(shard.n_max)}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
+
+    import scenes  # noqa: F401
+    import volren_amd  # noqa: F401
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the renderer has no CPU path")
     n_dev = torch.cuda.device_count()
-    if os.environ.get("VOLREN_DIST_BACKEND", "nccl") != "nccl":
+    if backend != "nccl":
         local_rank = local_rank % max(1, n_dev)                # test mode: ranks may share a device
     torch.cuda.set_device(local_rank)
-    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ("nccl") over xGMI is the real path; VOLREN_DIST_BACKEND=gloo exists only so that the multi-rank flow can be
         # exercised on a box where several ranks have to share one GPU (the collective is then staged through the host)
-        backend = os.environ.get("VOLREN_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
 
     w, h, spp = args.width, args.height, args.spp
-    r = scenes.hip_scene(args.config, w, h, device=local_rank)
-    stream = torch.cuda.current_stream()
-    r.set_stream(stream.cuda_stream)
-
-    from volren_amd.shard import TileShard
-    shard = TileShard(w, h, world, rank)
-    mine = shard.mine
-    packed = gathered = tiles_dev = all_tiles_dev = None
-    if world > 1:
-        r.set_tiles(mine)
-        tiles_dev = torch.from_numpy(shard.pack_ids).cuda()
-        all_tiles_dev = torch.from_numpy(shard.unpack_ids).cuda()
-        packed = torch.empty(shard.packed_floats, dtype=torch.float32, device="cuda")
-        gathered = torch.empty(shard.gathered_floats, dtype=torch.float32, device="cuda")
-
-    kernel_ms = []
-    staged = world > 1 and os.environ.get("VOLREN_DIST_BACKEND", "nccl") != "nccl"
-
-    def step():
-        r.reset()
-        r.render(spp, sync=False)                                           # ONE fused launch: all spp of all owned tiles
-        if world > 1:
-            r.pack_tiles(tiles_dev.data_ptr(), shard.n_max, packed.data_ptr())
-            if staged:
-                hg = torch.empty(gathered.shape, dtype=gathered.dtype)
-                shard.all_gather(dist, hg, packed.cpu())
-                gathered.copy_(hg)
-            else:
-                shard.all_gather(dist, gathered, packed)                    # RCCL over xGMI, once per frame
-            r.unpack_tiles(all_tiles_dev.data_ptr(), world * shard.n_max, gathered.data_ptr())
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    r.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(None)                                              # filled below without syncing inside the loop
-    barrier()
-    elapsed = time.perf_counter() - t0
-    r.synchronize()                                                         # also raises if the kernel watchdog tripped
-    last_ms = r.last_kernel_ms()                                            # HIP events around the last path-tracing launch
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    samples_per_step = float(w) * h * spp
-    value = samples_per_step * args.steps / elapsed / 1e6
+    b = Bench(args.config, w, h, spp, world, rank, local_rank, dist)
+    m = b.measure(args.steps, args.warmup)
 
     out = None
     if rank == 0:
         use_tf = args.config == "c3"
-        cpu = None
-        counters = None
+        cpu = cpu_rm = None
         if world == 1 and args.cpu_budget > 0:
-            cpu, counters = cpu_baseline_and_counters(args.config, w, h, args.cpu_budget)
+            cpu, counters = cpu_baseline_and_counters(args.config, args.cpu_budget)
         else:
-            _, counters = cpu_baseline_and_counters(args.config, w, h, 0.5)
-        b_sample, events = algorithmic_bytes_per_sample(counters, spp, use_tf, args.config.startswith("c5"), dense=args.config.startswith("c4"))
-        my_samples = len(mine) * 256.0 * spp if world > 1 else samples_per_step
-        launches = max(1, r.last_launches)                       # a frame is split so that a sub-launch fits the sample pool
-        launch_ms = last_ms / launches                           # HIP events on the renderer's stream around the frame's launches
-        achieved = b_sample * (my_samples / launches) / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass (FETCH_SIZE/WRITE_SIZE), collected separately
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("config") == args.config and tj.get("width") == w and tj.get("height") == h:
-                traffic = tj["hbm_bytes_per_sample"] * (my_samples / launches)
-        valu = None                                              # what actually bounds the kernel: VALU issue (PMC pass, profiles/)
-        ppath = os.path.join(ROOT, "profiles", "r1_g_pmc_counters.json")
-        if os.path.exists(ppath) and args.config == "c2" and (w, h) == (1024, 1024):
-            c = json.load(open(ppath))["counters"]
-            valu = {"busy": c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / 4.0),
-                    "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]),
-                    "valu_instructions_per_sample": c["SQ_INSTS_VALU"] / float(json.load(open(ppath))["samples"]),
-                    "source": "profiles/r1_g_pmc_counters.json (rocprofv3 --pmc, tests/tools_profile_run.py c2 1024 128)"}
+            _, counters = cpu_baseline_and_counters(args.config, 0.5)
         out = {
             "metric": "Msamples/s (pixels x spp / s), volume path tracing",
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "value": m["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else
                                       "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
-            "config": {"workload": "BASELINE configs[%d] '%s': %s%s, %dx%d, %d spp, seed 42, fov 40" % (
-                {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}.get(args.config[:2], -1), args.config, "synthetic dense fp16 grid" if args.config.startswith("c4") else ("synthetic sparse brick grid + temperature grid (emission)" if args.config.startswith("c5") else "smoke.brick"), " + lut.txt" if use_tf else ", no transfer function", w, h, spp),
-                "parallelism": "tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame" % world if world > 1 else "1 GPU, 1 fused launch/frame"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "pathtrace_kernel<%s,false>" % ("true" if use_tf else "false"),
-                         "kernel_ms": launch_ms, "launches_per_step": launches, "samples_per_launch": my_samples / launches,
-                         "bytes_per_sample": b_sample, "events_per_sample": events,
-                         "valu": valu,
-                         "note": "bytes = algorithmic (SURVEY 8d); the scene is cache resident and the kernel is bound by VALU issue (vector ALUs busy ~92 % of the time, see `valu` and DESIGN.md 7), not by HBM bandwidth"},
+            "config": {"workload": workload_name(args.config, w, h, spp),
+                       "parallelism": "tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame" % world if world > 1 else "1 GPU, 1 fused launch/frame"},
+            "roofline": b.roofline(m, counters),
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+            try:                                               # second baseline SURVEY 8d names: the 64-step ray marcher
+                cpu_rm, _ = cpu_baseline_and_counters(args.config, min(args.cpu_budget, 6.0), integrator=3, kind="raymarch-64")
+                out["cpu_baseline_raymarch"] = cpu_rm
+            except Exception as e:                             # noqa: BLE001 -- a missing optional leg must not lose the headline line
+                out["cpu_baseline_raymarch"] = {"error": str(e)}
+
+    # tolerance-mode kernels (v_log/v_rcp/v_sin hardware math): speed and distance from the bit-exact default, same frame
+    if world == 1 and args.extra_configs != "none" and b.r.has_fast_math():
+        ref = b.r.framebuffer().copy()
+        bf = Bench(args.config, w, h, spp, world, rank, local_rank, dist, fast_math=True)
+        mf = bf.measure(max(1, args.steps - 1), 1)
+        import numpy as np
+        img = bf.r.framebuffer()
+        rl2 = float(np.sqrt(((img[..., :3].astype(np.float64) - ref[..., :3]) ** 2).sum() / max((ref[..., :3].astype(np.float64) ** 2).sum(), 1e-30)))
+        out["fast_math"] = {"value": mf["value"], "unit": "Msamples/s", "kernel_ms": mf["kernel_ms"], "speedup": mf["value"] / m["value"],
+                            "rel_l2_vs_bit_exact": rl2, "tolerance": 1e-3, "within_tolerance": bool(rl2 <= 1e-3),
+                            "note": "opt-in mode (vr_set_int fast_math 1): hardware transcendentals and reciprocal-based divisions; the headline value above is the bit-exact default"}
+        del bf
+
+    # the other single-GPU BASELINE configs at the resolution north_star quotes (driver-run, not builder-only)
+    extra = args.extra_configs
+    if extra is None:
+        extra = "c3,c4" if (args.config == "c2" and world == 1) else "none"
+    if rank == 0 and world == 1 and extra != "none":
+        del b
+        out["configs"] = []
+        for name in [x for x in extra.split(",") if x]:
+            try:
+                bx = Bench(name, w, h, spp, 1, 0, local_rank, None)
+                mx = bx.measure(2, 1)
+                _, cx = cpu_baseline_and_counters(name, 0.5)
+                out["configs"].append({"name": name, "workload": workload_name(name, w, h, spp), "value": mx["value"], "unit": "Msamples/s",
+                                       "ms_per_step": mx["ms_per_step"], "steps": 2, "warmup": 1, "roofline": bx.roofline(mx, cx)})
+                del bx
+            except Exception as e:                             # noqa: BLE001
+                out["configs"].append({"name": name, "error": str(e)})
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -31,7 +31,7 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
             memcpy(&g.atlas[(((size_t)pz * sy + py) * sx + px) * 512 + z * 64 + y * 8],
                    atlas + (((size_t)(pz * 8 + z) * ad[1] + (py * 8 + y)) * ad[0] + px * 8), 8);
     for (int i = 0; i < 2; ++i) g.view.bshift[i] = ceil_log2(nb[i]);
-    for (int i = 0; i < 3; ++i) g.view.mshift[i] = ceil_log2(nb[i]) < 3 ? 3 : ceil_log2(nb[i]);
+    for (int i = 0; i < 3; ++i) { g.view.mshift[i] = ceil_log2(nb[i]) < 3 ? 3 : ceil_log2(nb[i]); g.view.mlim[i] = (float)(8u << g.view.mshift[i]); }
     g.recs.assign((size_t)nb[2] << (g.view.bshift[0] + g.view.bshift[1]), BrickRec{ 0u, 0.f, 0.f, 0u });
     for (size_t i = 0; i < n; ++i) {
         const uint32_t ind = indirection[i], rg = range[i];
@@ -169,7 +169,7 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
                         Hot& l = lanes[i];
                         if (l.state == ST_DONE) continue;
                         live = true;
-                        if (u.use_tf) lane_step<true>(l, cold[i], P, wu, next_item); else lane_step<false>(l, cold[i], P, wu, next_item);
+                        if (u.use_tf) lane_step<TraceCfg<true, 2, 2, 2>>(l, cold[i], P, wu, next_item); else lane_step<TraceCfg<false, 2, 2, 2>>(l, cold[i], P, wu, next_item);
                         if (++steps > (1ll << 40)) return -1;
                     }
                 }

@@ -1,7 +1,7 @@
 """Diagnostic: instruction histogram of the path-tracing kernels from the device assembly (build/asm/vr_kernels.s)."""
 import re, collections, sys
 txt = open(sys.argv[1] if len(sys.argv) > 1 else "build/asm/vr_kernels.s").read()
-for m in re.finditer(r"\n(_ZN2vr16pathtrace_kernelILb([01])ELb0E[^\n:]*):[^\n]*\n", txt):
+for m in re.finditer(r"\n(_ZN2vr16pathtrace_kernelINS_8TraceCfgILb([01])E[A-Za-z0-9]*EELb0E[^\n:]*):[^\n]*\n", txt):
     body = txt[m.end():]
     body = body[:body.index(".Lfunc_end")]
     ops = collections.Counter()

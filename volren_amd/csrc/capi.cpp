@@ -212,7 +212,7 @@ int vr_set_int(vr_renderer* r, const char* name, int v) {
         else if (n == "tonemapping") R.tonemapping = v != 0;
         else if (n == "integrator") R.integrator = v;
         else if (n == "gpu_encoder") R.gpu_encoder = v != 0;
-        else if (n == "sample_pool_mb") { if (v < 16) throw std::runtime_error("sample_pool_mb must be >= 16"); R.sample_pool_bytes = (size_t)v << 20; }
+        else if (n == "sample_pool_mb") { if (v < 16 || v > 49152) throw std::runtime_error("sample_pool_mb must be in [16, 49152] (item indices of a sub-launch are 32-bit: < 2^32 RGBA32F items)"); R.sample_pool_bytes = (size_t)v << 20; }
         else if (n == "grid_frame_counter") {
             if (!R.volume || v < 0 || (size_t)v >= R.volume->n_grid_frames()) throw std::runtime_error("grid_frame_counter out of range");
             R.volume->grid_frame_counter = (size_t)v;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -20,7 +21,15 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 class DeviceBuffer {
 public:
     DeviceBuffer() = default;
-    explicit DeviceBuffer(size_t bytes) { if (bytes) { VR_HIP(hipMalloc(&ptr_, bytes)); bytes_ = bytes; } }
+    explicit DeviceBuffer(size_t bytes) {
+        if (!bytes) return;
+        // test hook: VR_TEST_MAX_ALLOC_MB makes larger allocations fail like an exhausted device would, so that the
+        // out-of-memory paths can be exercised without taking the HBM away from other users of the GPU
+        if (const char* cap = getenv("VR_TEST_MAX_ALLOC_MB"))
+            if (bytes > ((size_t)strtoull(cap, nullptr, 10) << 20)) hip_check(hipErrorOutOfMemory, "hipMalloc (VR_TEST_MAX_ALLOC_MB)", __FILE__, __LINE__);
+        VR_HIP(hipMalloc(&ptr_, bytes));
+        bytes_ = bytes;
+    }
     ~DeviceBuffer() { if (ptr_) (void)hipFree(ptr_); }
     DeviceBuffer(const DeviceBuffer&) = delete;
     DeviceBuffer& operator=(const DeviceBuffer&) = delete;

@@ -272,7 +272,7 @@ static GridView make_view(const BrickGridHIP& g) {
     v.majorant = g.majorant->as<float>();
     for (int i = 0; i < 3; ++i) v.nb[i] = g.nb[i];
     for (int i = 0; i < 2; ++i) v.bshift[i] = g.bshift[i];
-    for (int i = 0; i < 3; ++i) v.mshift[i] = g.mshift[i];
+    for (int i = 0; i < 3; ++i) { v.mshift[i] = g.mshift[i]; v.mlim[i] = (float)(8u << g.mshift[i]); }
     v.n_mips = g.n_mips;
     return v;
 }
@@ -352,12 +352,11 @@ void RendererHIP::fill_params(SceneParams& P) {
 void RendererHIP::update_majorants(const SceneParams& P, BrickGridHIP& g) {
     MajKey k;
     k.density_scale = density_scale;
-    k.tf = transferfunc.get();
     k.tf_version = transferfunc ? transferfunc->version : 0;
     k.wl = transferfunc ? transferfunc->window_left : 0.f;
     k.ww = transferfunc ? transferfunc->window_width : 0.f;
     k.frame = volume->grid_frame_counter;
-    if (k.density_scale == maj_key_.density_scale && k.tf == maj_key_.tf && k.tf_version == maj_key_.tf_version &&
+    if (k.density_scale == maj_key_.density_scale && k.tf_version == maj_key_.tf_version &&
         k.wl == maj_key_.wl && k.ww == maj_key_.ww && k.frame == maj_key_.frame)
         return;
     launch_majorants(P, g.range_words->as<uint32_t>(), g.nb, g.mip_off, g.n_mips, g.mshift, g.majorant->as<float>(), stream);
@@ -392,6 +391,8 @@ void RendererHIP::launch(int n) {
     // per-sample radiances live in a device pool; split the request so that one sub-launch fits the pool
     const size_t per_sample = pathtrace_pool_floats(n_tiles, 1) * sizeof(float);
     int per_launch = (int)std::max<size_t>(1, sample_pool_bytes / per_sample);
+    // item indices inside a sub-launch are 32-bit (WorkUnit::base, C_ITEM): keep n_tiles * 256 * per_launch below 2^32
+    per_launch = (int)std::min<size_t>((size_t)per_launch, std::max<size_t>(1, ((size_t)1 << 32) / ((size_t)n_tiles * 256u) - 32u));
     if (per_launch > 32) per_launch -= per_launch % 32;          // whole sample chunks (32 is a multiple of every unit size)
     per_launch = std::min(per_launch, n);
     for (;;) {                                                   // a pool that does not fit the free HBM: halve the sub-launch, never fail for it

@@ -132,7 +132,7 @@ private:
     double last_ms_ = 0.0;
     bool timing_pending_ = false;
     // majorant cache key
-    struct MajKey { float density_scale = -1.f; uint64_t tf_version = ~0ull; float wl = 0, ww = 0; const void* tf = nullptr; size_t frame = ~(size_t)0; } maj_key_;
+    struct MajKey { float density_scale = -1.f; uint64_t tf_version = ~0ull; float wl = 0, ww = 0; size_t frame = ~(size_t)0; } maj_key_;   // tf_version: TransferFunction::version (unique per upload), 0 = no LUT
 };
 
 using Renderer = RendererHIP;

@@ -2,6 +2,8 @@
 // and :79-106 (text IO); written from the behaviour, not from the text.
 #include "transferfunc.h"
 
+#include <atomic>
+
 #include <cstdio>
 #include <filesystem>
 #include <iostream>
@@ -55,7 +57,8 @@ void TransferFunction::upload_gpu() {
     lut_gpu = alpha_is_monotone(lut) ? lut : compute_lut_cdf(lut);
     lut_ssbo = make_device_buffer(lut_gpu.size() * sizeof(vec4));
     lut_ssbo->upload(lut_gpu.data(), lut_gpu.size() * sizeof(vec4));
-    ++version;
+    static std::atomic<uint64_t> next_upload_id{ 1 };
+    version = next_upload_id.fetch_add(1);
 }
 
 void TransferFunction::load_from_file(const std::string& path) {

@@ -34,7 +34,8 @@ public:
     std::vector<vec4> lut;
     std::vector<vec4> lut_gpu;        // what was uploaded (after the CDF fix-up)
     DeviceBufferPtr lut_ssbo;
-    uint64_t version = 0;             // bumped by upload_gpu (majorant cache key)
+    uint64_t version = 0;             // process-wide unique id of the last upload (majorant cache key): never reused, so a new
+                                      // TransferFunction that happens to land at a freed one's address cannot match a stale key
 };
 
 }  // namespace vr

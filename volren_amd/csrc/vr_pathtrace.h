@@ -1,0 +1,379 @@
+// vr_pathtrace.h -- the path-tracing kernel (scheduling part; the per-path code is vr_trace.h).
+//
+// pathtrace_kernel<K, STATS>: persistent wavefronts pull (8x8 pixel tile x 8 samples) work units from an XCD-aware
+// counter; each wavefront keeps a private pool of more path slots than it has lanes, so that the frequent march/collide
+// code always finds lanes to fill and the rare, expensive events (new sample with the 32-round TEA hash, next-event
+// estimation, scatter, escape) run as near-full-width batches of parked paths.
+// K (TraceCfg, vr_trace.h) selects the variant at compile time; vr_pathtrace.hip is compiled once per variant.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "vr_trace.h"
+
+namespace vr {
+
+struct SchedParams {
+    int32_t thr[ST_COUNT];     // minimum number of lanes that must wait in a state before its code runs
+    uint32_t max_iters;        // watchdog: scheduler iterations per wavefront
+};
+
+// Persistent wavefronts.  The frame's work is cut into units = one 8x8 pixel tile x `spu` consecutive samples
+// (64*spu items); unit u = ((chunk * n_tiles + tile_slot) * 4 + sub_tile) and its items occupy slots
+// [u*64*spu, (u+1)*64*spu) of the sample buffer.  Every wavefront pulls units from a global queue and refills
+// idle lanes item by item, WITHOUT waiting for its other lanes to finish: the only drain is at the end of the launch.
+// The queue is XCD-aware: queue position j enumerates the units tile-major (all sample chunks of a sub-tile are adjacent) and
+// the positions are cut into 8 contiguous segments, one per XCD (workgroups are dealt round-robin to the 8 XCDs, so
+// blockIdx.x & 7 names the XCD): the waves of one XCD -- which share one L2 -- work on one band of tile rows; a wave whose
+// segment is empty takes units from the next one.
+constexpr uint32_t kQueueSegments = 8u;
+struct LaunchDesc {
+    const int32_t* tiles;     // 16x16 tile ids (raster, row 0 = bottom) or nullptr = all tiles
+    int32_t n_tiles, first_sample, n_samples, spu;
+    uint32_t n_units, chunks, seg_len;
+    uint32_t* unit_counter;   // kQueueSegments counters, zeroed before the launch
+};
+
+__device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, uint32_t j, float* sbuf) {
+    const uint32_t rem = j / D.chunks, chunk = j - rem * D.chunks;        // queue position -> (tile slot, sub-tile), sample chunk
+    const uint32_t u = chunk * ((uint32_t)D.n_tiles * 4u) + rem;
+    const uint32_t slot = rem >> 2, sub = rem & 3u;
+    const int32_t tiles_x = (W + 15) >> 4;
+    const int32_t tile = D.tiles ? D.tiles[slot] : (int32_t)slot;
+    const int32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    WorkUnit wu;
+    wu.px0 = tx * 16 + (int32_t)((sub & 1u) << 3);
+    wu.py0 = ty * 16 + (int32_t)((sub >> 1) << 3);
+    wu.first_sample = D.first_sample + (int32_t)chunk * D.spu;
+    wu.n_items = min(D.spu, D.n_samples - (int32_t)chunk * D.spu) * 64;
+    wu.base = u * (uint32_t)(D.spu * 64);
+    wu.out = sbuf;
+    return wu;
+}
+
+#ifndef VR_WAVES_PER_SIMD
+#define VR_WAVES_PER_SIMD 4
+#endif
+#ifndef VR_BATCH_REGS
+#define VR_BATCH_REGS 1
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// Wave-private path pool.
+//
+// A wavefront owns NSLOT path slots, more than it has lanes.  The 64 lanes hold, in registers, the hot state of the
+// paths that are currently marching; every other path of the pool is parked: its hot state (NHOT dwords) sits in LDS
+// and its slot id in one of the wave's LDS stacks -- READY (may march), NEE / POSTNEE / ESCAPE (wait for that event),
+// FREE.  Cold path state lives in global memory (one 128-byte line per slot, L2 / Infinity Cache resident); only the
+// events touch it.
+//   * a lane whose path reaches an event parks it (ds_write2 pairs + a stack push) and immediately resumes a READY path,
+//     so the march/collide code runs with most lanes holding a path;
+//   * an event's code runs when a (nearly) full-width batch of parked paths has piled up, or -- when the wave runs dry --
+//     for its largest batch: lane i loads parked path i, runs the unchanged per-path code of vr_trace.h, stores it and
+//     routes the slot to the stack of its new state.  The lanes double as batch workers; the batch path lives in its own
+//     register set so the marching path stays put (VR_BATCH_REGS=0 swaps it through its LDS slot instead).
+// Everything is wave-synchronous (ballots, mbcnt ranks, scalar counters): no atomics, no barriers, no spinning; the only
+// global atomic is the work-queue head.  Which lane runs which path never changes a result.
+#ifndef VR_NSLOT
+#define VR_NSLOT 152
+#endif
+constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
+
+enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
+
+constexpr int32_t HOT_STRIDE = 15;     // dwords per slot in LDS (= the parked fields): odd, so that lanes with different slots spread over the banks
+struct HotStore {                      // [slot][field]: a path's 15 parked dwords are adjacent (ds_read2/ds_write2 pairs)
+    uint32_t* base;
+    // mip (a multiple of 1/4 in [0,3]) rides in the flag word
+    __device__ __forceinline__ void save(const Hot& h, int32_t slot) const {
+        uint32_t* p = base + slot * HOT_STRIDE;
+        p[0] = h.seed;
+        p[1] = f2u(h.ipos.x); p[2] = f2u(h.ipos.y); p[3] = f2u(h.ipos.z);
+        p[4] = f2u(h.idir.x); p[5] = f2u(h.idir.y); p[6] = f2u(h.idir.z);
+        p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
+        p[10] = f2u(h.Tr);
+        p[11] = (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)h.mipq << 16);
+        p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z);
+    }
+    __device__ __forceinline__ void load(Hot& h, int32_t slot) const {
+        const uint32_t* p = base + slot * HOT_STRIDE;
+        h.seed = p[0];
+        h.ipos = v3{ u2f(p[1]), u2f(p[2]), u2f(p[3]) };
+        h.idir = v3{ u2f(p[4]), u2f(p[5]), u2f(p[6]) };
+        h.ri = v3{ u2f(p[12]), u2f(p[13]), u2f(p[14]) };
+        h.t = u2f(p[7]); h.far = u2f(p[8]); h.tau = u2f(p[9]);
+        h.Tr = u2f(p[10]);
+        const uint32_t f = p[11];
+        h.state = (int32_t)(f & 0xFFu); h.shadow = (int32_t)((f >> 8) & 0xFFu);
+        h.mipq = (int32_t)(f >> 16);
+        h.majorant = 0.0f;
+    }
+};
+struct ColdGlobal {                    // one 128-byte line per path slot in this wavefront's slice of the workspace
+    float* base;
+    __device__ __forceinline__ float ld(int32_t f) const { return static_cast<const float*>(__builtin_assume_aligned(base, 128))[f]; }
+    __device__ __forceinline__ void st(int32_t f, float v) { static_cast<float*>(__builtin_assume_aligned(base, 128))[f] = v; }
+};
+
+__device__ __forceinline__ int32_t popc(uint64_t mask) { return (int32_t)__popcll(mask); }     // int: min(long long, int) would go through double
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// The scene parameters are ~1 KiB of uniforms.  The hot pair (march / collide) reads its few fields from the by-value
+// kernel argument `P`, which the compiler keeps in SGPRs for the whole launch.  The event code (new sample, NEE, scatter,
+// escape) reads everything else -- camera, environment, transforms -- through event_params(): the same kernel-argument
+// bytes, addressed through a pointer the optimiser cannot see through, so that those ~150 dwords are fetched by scalar
+// loads where an event needs them instead of being hoisted out of the scheduler loop and spilled (round 1: 217 SGPR spills,
+// i.e. a v_readlane/v_writelane + s_nop on every use).  `P` MUST stay the kernel's first parameter: the kernarg segment
+// lays arguments out in order from offset 0 (AMDGPU ABI).
+typedef const __attribute__((address_space(4))) SceneParams* KernargParams;
+__device__ __forceinline__ const SceneParams& event_params() {
+    KernargParams p = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const SceneParams*)p;
+}
+
+template <class K, bool STATS>
+__global__ void __launch_bounds__(256, VR_WAVES_PER_SIMD)
+pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restrict__ cold_ws, const LaunchDesc D, const SchedParams S,
+                 uint32_t* __restrict__ status, unsigned long long* __restrict__ stats) {
+    const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+
+    __shared__ uint8_t lds_q[4 * Q_COUNT * NSLOT];
+    uint8_t* const q = lds_q + wave * (Q_COUNT * NSLOT);
+    // per-wavefront slice of the workspace: the cold fields of its NSLOT paths
+    float* const cold_base = cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)(C_STRIDE * NSLOT);
+    __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NSLOT];
+    const HotStore hs{ lds_hot + wave * (HOT_STRIDE * NSLOT) };
+
+    const int32_t pool = (S.thr[ST_BEGIN] > 0 && S.thr[ST_BEGIN] < NSLOT) ? S.thr[ST_BEGIN] : NSLOT;     // slots in use (diagnostic cap)
+    int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = pool;     // stack heights (wave-uniform)
+    for (int32_t i = lane; i < pool; i += 64) q[Q_FREE * NSLOT + i] = (uint8_t)i;
+    __builtin_amdgcn_wave_barrier();
+
+    WorkUnit wu;
+    wu.px0 = wu.py0 = 0; wu.first_sample = 1; wu.n_items = 0; wu.base = 0u; wu.out = sbuf;
+    uint32_t cursor = 0u;             // next item of the current unit (wave-uniform)
+    bool exhausted = false;           // the global queue has no more units
+    uint32_t seg_tries = 0u;          // queue segments this wavefront has found empty (wave-uniform)
+
+    Hot l;
+    hot_init(l);
+    int32_t slot = -1;                // path held in this lane's registers (-1: none)
+
+    uint32_t iters = 0u;
+    unsigned long long t_last = __builtin_readcyclecounter(), t_elapsed = 0ull;
+    uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long occ[6] = { 0, 0, 0, 0, 0, 0 };      // summed per iteration: marching lanes, READY, NEE, POSTNEE, ESCAPE, FREE
+#define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
+#define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
+// push the slots of all lanes where COND holds onto stack QI (wave-synchronous)
+#define VR_PUSH(QI, CNT, COND, SLOTV) do { \
+        const uint64_t m_ = __ballot(COND); \
+        if (m_) { if (COND) q[(QI) * NSLOT + (CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(SLOTV); (CNT) += popc(m_); } \
+    } while (0)
+
+// route the batch paths to the stack of their new state; an impossible state is reported and the slot recycled
+#define VR_ROUTE_ST(BS, STV) do { \
+        const bool v_ = (BS) >= 0; \
+        const int32_t s_ = (STV); \
+        VR_PUSH(Q_READY, cnt_ready, v_ && (s_ == ST_MARCH || s_ == ST_COLLIDE), BS); \
+        VR_PUSH(Q_NEE, cnt_nee, v_ && s_ == ST_NEE, BS); \
+        VR_PUSH(Q_POST, cnt_post, v_ && s_ == ST_POSTNEE, BS); \
+        VR_PUSH(Q_ESC, cnt_esc, v_ && s_ == ST_ESCAPE, BS); \
+        const bool lost_ = v_ && (s_ < ST_NEW || s_ > ST_ESCAPE || s_ == ST_BEGIN); \
+        if (__ballot(lost_)) { if (lost_) atomicOr(status, 2u); } \
+        VR_PUSH(Q_FREE, cnt_free, v_ && (s_ == ST_NEW || lost_), BS); \
+    } while (0)
+#define VR_ROUTE(BS) VR_ROUTE_ST(BS, l.state)
+#define VR_ROUTE_B(BS) VR_ROUTE_ST(BS, b.state)
+
+    for (;;) {
+        // watchdog: a wavefront's share of a launch is tens of milliseconds; give up (and report) after S.max_iters
+        // scheduler iterations or ~8 s of shader clock, whichever comes first -- a kernel must never hang the GPU
+        bool give_up = ++iters > S.max_iters;
+        if ((iters & 1023u) == 0u) {
+            // elapsed shader-clock time, summed over 1024-iteration windows.  A window that appears to take more than 2^34 ticks (or
+            // a negative time) is a counter discontinuity -- a wavefront that was saved and restored on another XCD when several
+            // processes time-share the GPU reads a different counter -- and is not counted.
+            const unsigned long long now = __builtin_readcyclecounter(), d = now - t_last;
+            t_last = now;
+            if (d < (1ull << 34)) t_elapsed += d;
+            give_up = give_up || t_elapsed > 20000000000ull;
+        }
+        if (give_up) {
+            if (lane == 0) atomicOr(status, 1u);
+            break;
+        }
+        // (1) idle lanes resume READY paths
+        {
+            const uint64_t idle = __ballot(slot < 0);
+            const int32_t take = min(popc(idle), cnt_ready);
+            if (take > 0) {
+                if (slot < 0) {
+                    const int32_t r = (int32_t)lane_rank(idle);
+                    if (r < take) { slot = q[Q_READY * NSLOT + cnt_ready - 1 - r]; hs.load(l, slot); }
+                }
+                cnt_ready -= take;
+            }
+        }
+        if (STATS) { occ[0] += (unsigned)popc(__ballot(slot >= 0)); occ[1] += (unsigned)cnt_ready; occ[2] += (unsigned)cnt_nee; occ[3] += (unsigned)cnt_post; occ[4] += (unsigned)cnt_esc; occ[5] += (unsigned)cnt_free; }
+        // (2) the hot pair: up to thr[COLLIDE] march steps, then the collision code
+        int32_t n;
+        for (int32_t k = 0; k < S.thr[ST_COLLIDE]; ++k) {
+            n = popc(__ballot(slot >= 0 && l.state == ST_MARCH));
+            if (n == 0) break;
+            VR_STAT(ST_MARCH, n);
+            if (slot >= 0 && l.state == ST_MARCH) do_march(l, P);
+            VR_STAT_END(ST_MARCH);
+        }
+        n = popc(__ballot(slot >= 0 && l.state == ST_COLLIDE));
+        if (n > 0) {
+            VR_STAT(ST_COLLIDE, n);
+            if (slot >= 0 && l.state == ST_COLLIDE) {
+                ColdGlobal c{ cold_base + slot * C_STRIDE };
+                if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) do_collide_global<K>(l, c, P); else do_collide<K>(l, c, P);
+            }
+            VR_STAT_END(ST_COLLIDE);
+        }
+        // (3) park paths that reached an event
+        {
+            const bool parked = slot >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE;
+            if (__ballot(parked)) {
+                if (parked) hs.save(l, slot);
+                // the hot pair can only leave a path in NEE, POSTNEE or ESCAPE
+                VR_PUSH(Q_NEE, cnt_nee, parked && l.state == ST_NEE, slot);
+                VR_PUSH(Q_POST, cnt_post, parked && l.state == ST_POSTNEE, slot);
+                VR_PUSH(Q_ESC, cnt_esc, parked && l.state == ST_ESCAPE, slot);
+                if (parked) slot = -1;
+            }
+        }
+        // (4) event batches
+        const int32_t n_live = popc(__ballot(slot >= 0)) + cnt_ready;
+        const bool hungry = n_live < S.thr[ST_MARCH];                    // the hot pair is about to run under-filled
+        // a batch runs when it is full enough; a hungry wave additionally runs its LARGEST batch (only that one, so that the
+        // others keep filling up)
+        const int32_t c_new = exhausted ? 0 : cnt_free;
+        int32_t big = c_new;
+        if (cnt_nee > big) big = cnt_nee;
+        if (cnt_post > big) big = cnt_post;
+        if (cnt_esc > big) big = cnt_esc;
+        const bool want_new = c_new > 0 && (c_new >= S.thr[ST_NEW] || (hungry && c_new == big));
+        const bool want_nee = cnt_nee > 0 && (cnt_nee >= S.thr[ST_NEE] || (hungry && cnt_nee == big));
+        const bool want_post = cnt_post > 0 && (cnt_post >= S.thr[ST_POSTNEE] || (hungry && cnt_post == big));
+        const bool want_esc = cnt_esc > 0 && (cnt_esc >= S.thr[ST_ESCAPE] || (hungry && cnt_esc == big));
+        if (want_new || want_nee || want_post || want_esc) {
+            // the lanes double as batch workers.  VR_BATCH_REGS=1: the batch path lives in its own register set `b` and the
+            // marching path `l` stays put; =0: the marching path is saved to its LDS slot and `l` is reused (fewer VGPRs)
+#if VR_BATCH_REGS
+            Hot b;
+#else
+            const int32_t my_slot = slot;
+            if (my_slot >= 0) hs.save(l, my_slot);
+            __builtin_amdgcn_wave_barrier();
+            Hot& b = l;
+#endif
+            if (want_esc) {
+                n = min(64, cnt_esc);
+                VR_STAT(ST_ESCAPE, n);
+                int32_t bs = -1;
+                if (lane < n) {
+                    bs = q[Q_ESC * NSLOT + cnt_esc - 1 - lane];
+                    hs.load(b, bs);
+                    ColdGlobal c{ cold_base + bs * C_STRIDE };
+                    do_escape(b, c, event_params(), wu);                              // writes the sample; the slot becomes free
+                }
+                cnt_esc -= n;
+                VR_ROUTE_B(bs);                                            // ST_NEW: the slot is free again
+                VR_STAT_END(ST_ESCAPE);
+            }
+            if (want_post) {
+                n = min(64, cnt_post);
+                VR_STAT(ST_POSTNEE, n);
+                int32_t bs = -1;
+                if (lane < n) {
+                    bs = q[Q_POST * NSLOT + cnt_post - 1 - lane];
+                    hs.load(b, bs);
+                    ColdGlobal c{ cold_base + bs * C_STRIDE };
+                    do_postnee<K>(b, c, event_params(), wu);
+                    hs.save(b, bs);
+                }
+                cnt_post -= n;
+                VR_ROUTE_B(bs);                                            // ST_NEW = path ended (bounce cap / roulette)
+                VR_STAT_END(ST_POSTNEE);
+            }
+            if (want_new) {
+                if (cursor == (uint32_t)wu.n_items) {
+                    uint32_t j = 0xFFFFFFFFu;
+                    while (seg_tries < kQueueSegments) {                    // own segment first, then the following ones
+                        const uint32_t k = ((blockIdx.x & (kQueueSegments - 1u)) + seg_tries) & (kQueueSegments - 1u);
+                        const uint32_t lo = k * D.seg_len, hi = min(lo + D.seg_len, D.n_units);
+                        uint32_t v = 0xFFFFFFFFu;
+                        if (lo < hi) { if (lane == 0) v = atomicAdd(D.unit_counter + k, 1u); v = __builtin_amdgcn_readfirstlane(v); }
+                        if (lo < hi && v < hi - lo) { j = lo + v; break; }
+                        ++seg_tries;                                        // this segment is used up for good
+                    }
+                    if (j == 0xFFFFFFFFu) exhausted = true;
+                    else { wu = make_unit(D, event_params().u.resolution[0], j, sbuf); cursor = 0u; }
+                }
+                n = min(min(64, cnt_free), (int32_t)((uint32_t)wu.n_items - cursor));
+                if (n > 0) {
+                    VR_STAT(ST_NEW, n);
+                    int32_t bs = -1;
+                    if (lane < n) {
+                        bs = q[Q_FREE * NSLOT + cnt_free - 1 - lane];
+                        hot_init(b);
+                        ColdGlobal c{ cold_base + bs * C_STRIDE };
+                        do_new<K>(b, c, event_params(), wu, cursor + (uint32_t)lane);
+                        hs.save(b, bs);
+                    }
+                    cnt_free -= n;
+                    cursor += (uint32_t)n;
+                    VR_ROUTE_B(bs);                                        // ST_NEW = pixel outside a ragged frame
+                    VR_STAT_END(ST_NEW);
+                }
+            }
+            if (want_nee) {
+                n = min(64, cnt_nee);
+                VR_STAT(ST_NEE, n);
+                int32_t bs = -1;
+                if (lane < n) {
+                    bs = q[Q_NEE * NSLOT + cnt_nee - 1 - lane];
+                    hs.load(b, bs);
+                    ColdGlobal c{ cold_base + bs * C_STRIDE };
+                    do_nee<K>(b, c, event_params());
+                    hs.save(b, bs);
+                }
+                cnt_nee -= n;
+                VR_ROUTE_B(bs);
+                VR_STAT_END(ST_NEE);
+            }
+#if !VR_BATCH_REGS
+            __builtin_amdgcn_wave_barrier();
+            if (my_slot >= 0) hs.load(l, my_slot);
+#endif
+        }
+        if (exhausted && cnt_free == pool) break;                        // every path of the pool has finished
+    }
+    if (STATS && stats && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < ST_DONE; ++k) { atomicAdd(&stats[2 * k], (unsigned long long)st_exec[k]); atomicAdd(&stats[2 * k + 1], (unsigned long long)st_lanes[k]); }
+        atomicAdd(&stats[16], (unsigned long long)iters);
+        atomicAdd(&stats[17], 1ull);
+#pragma unroll
+        for (int k = 0; k < ST_DONE; ++k) atomicAdd(&stats[18 + k], st_cyc[k]);
+        atomicAdd(&stats[25], __builtin_readcyclecounter() - t_start);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&stats[26 + k], occ[k]);
+    }
+#undef VR_STAT
+#undef VR_STAT_END
+#undef VR_PUSH
+#undef VR_ROUTE
+#undef VR_ROUTE_B
+#undef VR_ROUTE_ST
+}
+
+}  // namespace vr

@@ -43,6 +43,7 @@ struct GridView {
     int32_t nb[3];               // bricks per axis (mip 0); mip m has ceil(nb / 2^m) cells per axis
     int32_t bshift[2];           // log2 of the brick-record pitches (x, y)
     int32_t mshift[3];           // log2 of the padded level-0 majorant extent per axis (each >= 3)
+    float mlim[3];               // the same extent in voxels, (float)(8 << mshift[i]): the inside test of the DDA compares against it
     int32_t n_mips;              // range mips available above level 0 (reference: 3)
     const uint16_t* dense;       // dense fp16 voxels in 4x4x4 blocks of 128 contiguous bytes (one cache line): block (x>>2, y>>2, z>>2),
                                  // x fastest over dblk[0] x dblk[1] x ceil(dim.z/4) blocks, voxel (x&3) + 4*(y&3) + 16*(z&3) inside; or nullptr

@@ -35,6 +35,16 @@ enum LaneState : int32_t {
     ST_COUNT = 8
 };
 
+// Compile-time configuration of the lane code.  One kernel is instantiated per combination that matters for speed, so that
+// code (and registers) of variants a scene does not use stay out of its kernel; 2 = "decided at run time from the uniforms"
+// (the host harness and the rarely used variants).
+//   TF        transfer-function kernel (pathtracer_brick_tf.glsl) or not (pathtracer_brick.glsl)
+//   GLOBAL    0: DDA trackers (USE_DDA, both reference kernels)  1: global-majorant trackers (common.glsl:333-394)  2: run time
+//   EMISSION  0: no emission grid bound (the 9 draws of lookup_emission are still consumed)  1: bound  2: run time
+//   DENSE     0: density grid = bricks  1: dense fp16 voxels  2: run time
+template <bool TF, int GLOBAL, int EMISSION, int DENSE>
+struct TraceCfg { static constexpr bool tf = TF; static constexpr int global = GLOBAL, emission = EMISSION, dense = DENSE; };
+
 // the pool of work items of one wavefront: pixel p = item & 63 of the 8x8 tile at (px0, py0), sample
 // first_sample + (item >> 6) (1-based like the reference's current_sample)
 struct WorkUnit {
@@ -96,9 +106,12 @@ VR_HD void rng_skip9(uint32_t& s) {
 
 // ---------------------------------------------------------------------------------------------------
 // grids  (common.glsl:268-297); out-of-range fetches read 0 (GL: undefined)
+template <int DENSE>
+VR_HD bool grid_is_dense(const GridView& g) { return DENSE == 2 ? g.dense != nullptr : DENSE == 1; }
+template <int DENSE = 2>
 VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
     if ((x | y | z) < 0) return 0.0f;
-    if (g.dense) {          // dense fp16 grid: one 2-byte load, no indirection
+    if (grid_is_dense<DENSE>(g)) {          // dense fp16 grid: one 2-byte load, no indirection
         if ((uint32_t)x >= (uint32_t)g.dim[0] || (uint32_t)y >= (uint32_t)g.dim[1] || (uint32_t)z >= (uint32_t)g.dim[2]) return 0.0f;
         // 4x4x4 blocks (vr_scene.h): neighbouring rays and the +-2-voxel stochastic taps share 128-byte lines; block counts < 2^14 per axis
         const uint32_t blk = (mul24((uint32_t)z >> 2, (uint32_t)g.dblk[1]) + ((uint32_t)y >> 2)) * (uint32_t)g.dblk[0] + ((uint32_t)x >> 2);
@@ -114,8 +127,7 @@ VR_HD float majorant_at(const GridView& g, v3 ipos, int32_t mip) {
     // cell = floor(ipos) >> (3 + mip); outside the grid (or NaN) reads 0.  The padded layout (vr_scene.h) holds 0 in every
     // cell beyond the real extent of a level, so only the padded extent -- the same for all levels -- is tested, on the
     // floats (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails), after which truncation equals floor.
-    const float lx = (float)(8u << g.mshift[0]), ly = (float)(8u << g.mshift[1]), lz = (float)(8u << g.mshift[2]);
-    const bool inside = (mip <= g.n_mips) & (ipos.x >= 0.0f) & (ipos.x < lx) & (ipos.y >= 0.0f) & (ipos.y < ly) & (ipos.z >= 0.0f) & (ipos.z < lz);
+    const bool inside = (mip <= g.n_mips) & (ipos.x >= 0.0f) & (ipos.x < g.mlim[0]) & (ipos.y >= 0.0f) & (ipos.y < g.mlim[1]) & (ipos.z >= 0.0f) & (ipos.z < g.mlim[2]);
     if (!inside) return 0.0f;        // one branch: the tests are evaluated together
     const uint32_t sh = 3u + (uint32_t)mip;
     const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
@@ -148,6 +160,7 @@ VR_HD AxisCells axis_cells(int32_t i0, int32_t i1, uint32_t extent_voxels, uint3
     }
     return a;
 }
+template <int DENSE = 2>
 VR_HD float density_trilinear_raw(const GridView& g, v3 ipos) {
     const float qx = ipos.x - 0.5f, qy = ipos.y - 0.5f, qz = ipos.z - 0.5f;
     const float flx = floor_(qx), fly = floor_(qy), flz = floor_(qz);
@@ -155,7 +168,7 @@ VR_HD float density_trilinear_raw(const GridView& g, v3 ipos) {
     const int32_t ix = nan_guard(voxel_index(flx, 0), flx, fly, flz), iy = voxel_index(fly, 0), iz = voxel_index(flz, 0);
     const int32_t x1 = nan_guard(voxel_index(flx, 1), flx, fly, flz), y1 = voxel_index(fly, 1), z1 = voxel_index(flz, 1);
     float v[2][2][2];      // [z][y][x]
-    if (g.dense) {
+    if (grid_is_dense<DENSE>(g)) {
         const AxisCells X = axis_cells(ix, x1, (uint32_t)g.dim[0], 2u), Y = axis_cells(iy, y1, (uint32_t)g.dim[1], 2u), Z = axis_cells(iz, z1, (uint32_t)g.dim[2], 2u);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -450,6 +463,7 @@ VR_HD void accumulate_sample(float acc[4], const float L[4], int32_t current_sam
 }
 
 // head of sample_volumeDDA / transmittanceDDA (common.glsl:413-421, 459-468) for the ray (pos, d)
+template <class K>
 VR_HD void begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t shadow) {
     h.shadow = shadow;
     h.Tr = 1.0f;          // both set before the branch on purpose: conditional stores to different fields make the
@@ -462,7 +476,7 @@ VR_HD void begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
     h.ipos = mat4_point(P.u.vol_density_inv_transform, pos);
     h.idir = mat4_dir(P.u.vol_density_inv_transform, d);
     h.far = tfar;
-    if (P.u.integrator != 0) {
+    if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) {
         // global-majorant delta / ratio tracking (common.glsl:333-394; compiled out in the reference by USE_DDA):
         // t = near - log(1 - xi) * vol_inv_majorant, then straight to the first tentative collision
         h.ri = v3{ 0, 0, 0 };
@@ -479,7 +493,7 @@ VR_HD void begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
 }
 
 // pathtracer_brick.glsl:27-30 + common.glsl:76-80; the lane has just been given `item` (< n_items)
-template <class Cold>
+template <class K, class Cold>
 VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uint32_t item) {
     const int32_t W = P.u.resolution[0], H = P.u.resolution[1];
     const int32_t px = wu.px0 + (int32_t)(item & 7u), py = wu.py0 + (int32_t)((item >> 3) & 7u);
@@ -494,7 +508,7 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
     st3(c, C_POS, pos); st3(c, C_DIR, dir);
     st3(c, C_L, v3{ 0, 0, 0 }); st3(c, C_THR, v3{ 1, 1, 1 });
     stu(c, C_NPATHS, 0u); c.st(C_FP, 0.0f); stu(c, C_ITEM, wu.base + item);    // C_ITEM: global slot in the sample buffer
-    begin_segment(h, P, pos, dir, 0);
+    begin_segment<K>(h, P, pos, dir, 0);
 }
 
 // loop body of both DDA trackers up to the collision test (common.glsl:422-435, 469-482)
@@ -515,23 +529,24 @@ VR_HD void do_march(Hot& h, const SceneParams& P) {
 }
 
 // tentative collision (common.glsl:436-452, 483-498)
-template <bool USE_TF, class Cold>
+template <class K, class Cold>
 VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
+    constexpr bool USE_TF = K::tf;
     const Uniforms& u = P.u;
     const v3 ip = axpy(h.ipos, h.t, h.idir);
     float d;
     float rgba[4] = { 0, 0, 0, 0 };
     if (USE_TF) {
-        tf_lookup(P, (u.vol_density_scale * density_trilinear_raw(P.density, ip)) * u.vol_inv_majorant, rgba);
+        tf_lookup(P, (u.vol_density_scale * density_trilinear_raw<K::dense>(P.density, ip)) * u.vol_inv_majorant, rgba);
         d = u.vol_majorant * rgba[3];
     } else {
         int32_t tx, ty, tz;
         tricubic_tap(ip, h.seed, tx, ty, tz);
-        d = u.vol_density_scale * brick_value(P.density, tx, ty, tz);
+        d = u.vol_density_scale * brick_value<K::dense>(P.density, tx, ty, tz);
     }
     if (!h.shadow) {
         // Le += throughput * (1 - albedo) * lookup_emission(...) * d * vol_inv_majorant  (9 draws, always)
-        if (u.has_emission) {
+        if (K::emission == 2 ? u.has_emission != 0 : K::emission == 1) {
             const v3 ie = mat4_point(P.emission_from_density, ip);
             int32_t ex, ey, ez;
             tricubic_tap(ie, h.seed, ex, ey, ez);
@@ -567,23 +582,24 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
 
 // tentative collision of the global-majorant trackers (common.glsl:342-359, 372-392): stays in ST_COLLIDE while the
 // ray is inside the box
-template <bool USE_TF, class Cold>
+template <class K, class Cold>
 VR_HD void do_collide_global(Hot& h, Cold& c, const SceneParams& P) {
+    constexpr bool USE_TF = K::tf;
     const Uniforms& u = P.u;
     const v3 ip = axpy(h.ipos, h.t, h.idir);
     float d;
     float rgba[4] = { 0, 0, 0, 0 };
     if (USE_TF) {
-        tf_lookup(P, (u.vol_density_scale * density_trilinear_raw(P.density, ip)) * u.vol_inv_majorant, rgba);
+        tf_lookup(P, (u.vol_density_scale * density_trilinear_raw<K::dense>(P.density, ip)) * u.vol_inv_majorant, rgba);
         d = u.vol_majorant * rgba[3];
     } else {
         int32_t tx, ty, tz;
         tricubic_tap(ip, h.seed, tx, ty, tz);
-        d = u.vol_density_scale * brick_value(P.density, tx, ty, tz);
+        d = u.vol_density_scale * brick_value<K::dense>(P.density, tx, ty, tz);
     }
     if (!h.shadow) {
         const float P_real = d * u.vol_inv_majorant;
-        if (u.has_emission) {
+        if (K::emission == 2 ? u.has_emission != 0 : K::emission == 1) {
             const v3 ie = mat4_point(P.emission_from_density, ip);
             int32_t ex, ey, ez;
             tricubic_tap(ie, h.seed, ex, ey, ez);
@@ -616,7 +632,7 @@ VR_HD void do_collide_global(Hot& h, Cold& c, const SceneParams& P) {
 }
 
 // real collision: common.glsl:611-626 up to (and including the set-up of) the transmittance call
-template <class Cold>
+template <class K, class Cold>
 VR_HD void do_nee(Hot& h, Cold& c, const SceneParams& P) {
     const v3 dir = ld3(c, C_DIR);
     const v3 pos = axpy(ld3(c, C_POS), h.t, dir);
@@ -632,7 +648,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const SceneParams& P) {
         c.st(C_FP, f_p);
         st3(c, C_SHA, (ld3(c, C_THR) * mis) * f_p);
         st3(c, C_SHLE, Le);
-        begin_segment(h, P, pos, w_i, 1);
+        begin_segment<K>(h, P, pos, w_i, 1);
     } else {
         c.st(C_SHPDF, 0.0f);           // marks "no next-event estimate" for do_postnee (pdf <= 0 or NaN)
         h.shadow = 0;
@@ -641,7 +657,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const SceneParams& P) {
 }
 
 // common.glsl:625-641, then the head of the next sample_volumeDDA call
-template <class Cold>
+template <class K, class Cold>
 VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
     v3 L = ld3(c, C_L);
     const float sh_pdf = c.ld(C_SHPDF);
@@ -665,7 +681,7 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
     const v3 sd = sample_phase_hg(dir, P.u.vol_phase_g, s0, s1);
     c.st(C_FP, phase_hg(dot(-dir, sd), P.u.vol_phase_g));
     st3(c, C_DIR, sd);
-    begin_segment(h, P, ld3(c, C_POS), sd, 0);
+    begin_segment<K>(h, P, ld3(c, C_POS), sd, 0);
 }
 
 // common.glsl:644-651
@@ -727,17 +743,17 @@ VR_HD void dvr_sample(const SceneParams& P, int32_t px, int32_t py, int32_t smp,
 }
 
 // sequential driver (host harness / reference order): one state transition of one lane
-template <bool USE_TF, class Cold>
+template <class K, class Cold>
 VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uint32_t& next_item) {
     switch (h.state) {
     case ST_NEW:
         if (next_item >= (uint32_t)wu.n_items) { h.state = ST_DONE; break; }
-        do_new(h, c, P, wu, next_item++);
+        do_new<K>(h, c, P, wu, next_item++);
         break;
     case ST_MARCH: do_march(h, P); break;
-    case ST_COLLIDE: if (P.u.integrator != 0) do_collide_global<USE_TF>(h, c, P); else do_collide<USE_TF>(h, c, P); break;
-    case ST_NEE: do_nee(h, c, P); break;
-    case ST_POSTNEE: do_postnee(h, c, P, wu); break;
+    case ST_COLLIDE: if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) do_collide_global<K>(h, c, P); else do_collide<K>(h, c, P); break;
+    case ST_NEE: do_nee<K>(h, c, P); break;
+    case ST_POSTNEE: do_postnee<K>(h, c, P, wu); break;
     case ST_ESCAPE: do_escape(h, c, P, wu); break;
     default: break;
     }
