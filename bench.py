@@ -309,7 +309,7 @@ def main():
                 out["cpu_baseline_raymarch"] = {"error": str(e)}
 
     # tolerance-mode kernels (v_log/v_rcp/v_sin hardware math): speed and distance from the bit-exact default, same frame
-    if world == 1 and args.extra_configs != "none" and b.r.has_fast_math():
+    if world == 1 and args.extra_configs != "none" and getattr(b.r, "has_fast_math", lambda: False)():
         ref = b.r.framebuffer().copy()
         bf = Bench(args.config, w, h, spp, world, rank, local_rank, dist, fast_math=True)
         mf = bf.measure(max(1, args.steps - 1), 1)

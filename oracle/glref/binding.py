@@ -219,6 +219,14 @@ class GLSLReference:
             if variant == "global":
                 assert text.count("#define USE_DDA") == 1
                 text = text.replace("#define USE_DDA", "")
+            elif variant == "raymarch":
+                # trace_path with the 64-step ray-marching trackers (common.glsl:506-566; no kernel of the reference calls them)
+                inc = reference_include("common.glsl")
+                for old, new in (("while (sample_volumeDDA(pos, dir, t, throughput, L, seed)) {", "float rm_pdf; while (sample_volume_raymarch(pos, dir, t, throughput, rm_pdf, seed)) {"),
+                                 ("const float Tr = transmittanceDDA(pos, w_i, seed);", "const float Tr = transmittance_raymarch(pos, w_i, seed);")):
+                    assert text.count(old) == 1, old
+                    text = text.replace(old, new)
+                del inc
             elif variant == "dvr":
                 call = "trace_path(pos, dir, seed)"
                 assert text.count(call) == 1

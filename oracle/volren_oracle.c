@@ -543,10 +543,94 @@ static int sample_volumeDDA(ctx_t* c, v3 wpos, v3 wdir, float* tout, v3* through
     return 0;
 }
 
+/* function-level probes (tests/glsl_pin_worker.py; probe.glsl modes 4, 5, 9) */
+void orc_view_dir(const orc_params* p, int32_t x, int32_t y, int32_t w, int32_t h, float jx, float jy, float out[3]) {
+    const v3 d = view_dir(p, x, y, w, h, jx, jy);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+int orc_intersect_box(const orc_params* p, const float pos[3], const float dir[3], float near_far[2]) {
+    return intersect_box(V3(pos[0], pos[1], pos[2]), V3(dir[0], dir[1], dir[2]), p->vol_bb_min, p->vol_bb_max, &near_far[0], &near_far[1]);
+}
+/* one camera segment of the DDA tracker: returns real-collision flag; out = (t, throughput rgb) */
+int orc_sample_volume(const orc_params* p, const orc_scene* s, const float pos[3], const float dir[3], uint32_t* seed, float out[4]) {
+    ctx_t c; memset(&c, 0, sizeof c); c.p = p; c.s = s;
+    v3 thr = V3(1, 1, 1), Le = V3(0, 0, 0);
+    float t = 0.0f;
+    int hit = 0;
+    const int real = sample_volumeDDA(&c, V3(pos[0], pos[1], pos[2]), V3(dir[0], dir[1], dir[2]), &t, &thr, &Le, seed, &hit);
+    out[0] = t; out[1] = thr.x; out[2] = thr.y; out[3] = thr.z;
+    return real;
+}
+
 float orc_transmittance(const orc_params* p, const orc_scene* s, const float pos[3], const float dir[3], uint32_t* seed) {
     ctx_t c; memset(&c, 0, sizeof c); c.p = p; c.s = s;
     v3 P = V3(pos[0], pos[1], pos[2]), D = V3(dir[0], dir[1], dir[2]);
     return p->integrator == 0 ? transmittanceDDA(&c, P, D, seed) : transmittance_global(&c, P, D, seed);
+}
+
+/* ------------------------------------------------------------------ */
+/* ray-marching trackers  ref: common.glsl:506-566 (RAYMARCH_STEPS 64).  Dead code in the reference (no kernel calls them;
+ * trace_path only switches between the DDA and the global-majorant pair).  Offered as integrator = 3: trace_path with
+ * sample_volume_raymarch / transmittance_raymarch in place of sample_volumeDDA / transmittanceDDA; the `pdf` output of
+ * sample_volume_raymarch has no consumer in trace_path.  Both use lookup_density_stochastic, also with a transfer function. */
+#define RAYMARCH_STEPS 64
+static float transmittance_raymarch(ctx_t* c, v3 wpos, v3 wdir, uint32_t* seed) {
+    const orc_params* p = c->p;
+    float near, far;
+    if (!intersect_box(wpos, wdir, p->vol_bb_min, p->vol_bb_max, &near, &far)) return 1.0f;
+    const v3 ipos = mat4point(p->vol_density_inv_transform, wpos);
+    const v3 idir = mat4dir(p->vol_density_inv_transform, wdir);
+    const float dt = (far - near) / (float)RAYMARCH_STEPS;
+    near += rng(seed) * dt;
+    float tau = 0.0f;
+    for (int i = 0; i < RAYMARCH_STEPS; ++i) {
+        const float d = lookup_density_stochastic(c, v3axpy(ipos, om_min(near + (float)i * dt, far), idir), seed);
+        c->c.n_coll_tr++;
+        if (p->use_tf) {
+            float rgba[4];
+            tf_lookup(c, d * p->vol_inv_majorant, rgba);
+            tau += rgba[3] * p->vol_majorant * dt;
+        } else {
+            tau += d * dt;
+        }
+    }
+    return om_exp(-tau);
+}
+static int sample_volume_raymarch(ctx_t* c, v3 wpos, v3 wdir, float* tout, v3* throughput, float* pdf, uint32_t* seed, int* hit_box) {
+    const orc_params* p = c->p;
+    *pdf = 1.0f;
+    float near, far;
+    *hit_box = 0;
+    if (!intersect_box(wpos, wdir, p->vol_bb_min, p->vol_bb_max, &near, &far)) return 0;
+    *hit_box = 1;
+    const v3 ipos = mat4point(p->vol_density_inv_transform, wpos);
+    const v3 idir = mat4dir(p->vol_density_inv_transform, wdir);
+    const float tau_target = -om_log(1.0f - rng(seed));
+    const float dt = (far - near) / (float)RAYMARCH_STEPS;
+    near += rng(seed) * dt;
+    float tau = 0.0f;
+    for (int i = 0; i < RAYMARCH_STEPS; ++i) {
+        const float t = om_min(near + (float)i * dt, far);
+        *tout = t;
+        const float d = lookup_density_stochastic(c, v3axpy(ipos, t, idir), seed);
+        c->c.n_coll_sv++;
+        float rgba[4] = { 0, 0, 0, 0 };
+        if (p->use_tf) {
+            tf_lookup(c, d * p->vol_inv_majorant, rgba);
+            tau += rgba[3] * p->vol_majorant * dt;
+        } else {
+            tau += d * dt;
+        }
+        if (tau >= tau_target) {
+            const v3 albedo = p->use_tf ? V3(rgba[0] * p->vol_albedo[0], rgba[1] * p->vol_albedo[1], rgba[2] * p->vol_albedo[2])
+                                        : V3(p->vol_albedo[0], p->vol_albedo[1], p->vol_albedo[2]);
+            *pdf = ((((albedo.x + albedo.y) + albedo.z) / 3.0f) * d) * om_exp(-tau_target);      /* mean(albedo) * d * exp(-tau_target) */
+            *throughput = v3mul(*throughput, albedo);
+            return 1;
+        }
+    }
+    *pdf = om_exp(-tau);
+    return 0;
 }
 
 /* ------------------------------------------------------------------ */
@@ -559,8 +643,10 @@ static void trace_path(ctx_t* c, v3 pos, v3 dir, uint32_t* seed, float out[4]) {
     float t = 0.0f, f_p = 0.0f;
     for (;;) {
         int hit_box = 1, real;
-        if (p->integrator == 0) real = sample_volumeDDA(c, pos, dir, &t, &throughput, &L, seed, &hit_box);
-        else                    real = sample_volume_global(c, pos, dir, &t, &throughput, &L, seed);
+        float rm_pdf;
+        if (p->integrator == 0)      real = sample_volumeDDA(c, pos, dir, &t, &throughput, &L, seed, &hit_box);
+        else if (p->integrator == 3) real = sample_volume_raymarch(c, pos, dir, &t, &throughput, &rm_pdf, seed, &hit_box);
+        else                         real = sample_volume_global(c, pos, dir, &t, &throughput, &L, seed);
         if (n_paths == 0 && !hit_box) c->c.n_primary_miss++;
         if (!real) break;
         pos = v3axpy(pos, t, dir);
@@ -572,7 +658,8 @@ static void trace_path(ctx_t* c, v3 pos, v3 dir, uint32_t* seed, float out[4]) {
         if (le_pdf[3] > 0.0f) {
             f_p = orc_phase_hg(dot3(v3neg(dir), w_i), p->vol_phase_g);
             const float mis_weight = p->show_environment > 0 ? power_heuristic(le_pdf[3], f_p) : 1.0f;
-            const float Tr = p->integrator == 0 ? transmittanceDDA(c, pos, w_i, seed) : transmittance_global(c, pos, w_i, seed);
+            const float Tr = p->integrator == 0 ? transmittanceDDA(c, pos, w_i, seed)
+                           : (p->integrator == 3 ? transmittance_raymarch(c, pos, w_i, seed) : transmittance_global(c, pos, w_i, seed));
             /* L += throughput * mis_weight * f_p * Tr * Le_pdf.rgb / Le_pdf.w */
             v3 a = v3scale(v3scale(v3scale(throughput, mis_weight), f_p), Tr);
             a = v3mul(a, V3(le_pdf[0], le_pdf[1], le_pdf[2]));
@@ -603,7 +690,6 @@ static void trace_path(ctx_t* c, v3 pos, v3 dir, uint32_t* seed, float out[4]) {
 /* ref: common.glsl:571-591 direct_volume_rendering: 64 jittered steps of emission-absorption compositing through the
  * transfer function (dead code in the reference: no kernel calls it; selectable here as integrator = 2, needs a LUT).
  * out[3] (not defined by the reference): opacity 1 - Tr. */
-#define RAYMARCH_STEPS 64
 static void direct_volume_rendering(ctx_t* c, v3 pos, v3 dir, uint32_t* seed, float out[4]) {
     const orc_params* p = c->p;
     v3 L = V3(0, 0, 0);

@@ -70,7 +70,8 @@ typedef struct {
     int32_t use_tf;          /* pathtracer_brick_tf.glsl vs pathtracer_brick.glsl */
     int32_t has_emission;    /* emission grid bound (renderer.cpp:117-124) */
     int32_t integrator;      /* 0 = USE_DDA (both reference kernels), 1 = global-majorant delta/ratio tracking (common.glsl:333-394),
-                              * 2 = direct volume rendering, 64-step ray marcher (common.glsl:571-591; needs a LUT) */
+                              * 2 = direct volume rendering, 64-step ray marcher (common.glsl:571-591; needs a LUT),
+                              * 3 = trace_path with the 64-step ray-marching trackers (common.glsl:506-566) */
 } orc_params;
 
 typedef struct {
@@ -148,6 +149,9 @@ float    orc_rng(uint32_t* state);
 float    orc_lookup_density_brick(const orc_brickgrid* g, int32_t x, int32_t y, int32_t z);
 float    orc_lookup_majorant_raw(const orc_brickgrid* g, int32_t x, int32_t y, int32_t z, int32_t mip);
 void     orc_sample_environment(const orc_params* p, const orc_scene* s, float r0, float r1, float w_i[3], float le_pdf[4]);
+void     orc_view_dir(const orc_params* p, int32_t x, int32_t y, int32_t w, int32_t h, float jx, float jy, float out[3]);
+int      orc_intersect_box(const orc_params* p, const float pos[3], const float dir[3], float near_far[2]);
+int      orc_sample_volume(const orc_params* p, const orc_scene* s, const float pos[3], const float dir[3], uint32_t* seed, float out[4]);
 void     orc_sample_phase_hg(const float dir[3], float g, float r0, float r1, float out[3]);
 float    orc_phase_hg(float cos_t, float g);
 float    orc_transmittance(const orc_params* p, const orc_scene* s, const float pos[3], const float dir[3], uint32_t* seed);

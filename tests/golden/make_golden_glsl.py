@@ -126,5 +126,38 @@ def main():
     print("wrote glsl_golden.npz (%d arrays), %s" % (len(out), meta["gl"]))
 
 
+HI_SPP = 1024
+
+
+def main_r2():
+    """Round-2 additions, written to glsl_golden_r2.npz (glsl_golden.npz stays byte-identical):
+      hi_<name>        the images of IMAGES / the emission scene at HI_SPP samples per pixel -- the sample count at which the
+                       north star's "within 1e-3 relative L2 of the GLSL reference" is meaningful (at 8 spp one flipped
+                       stochastic decision moves the norm by more than that);
+      rm_<cfg>_spec    trace_path with the ray-marching trackers of common.glsl:506-566 (binding._variant_program "raymarch":
+                       code the reference contains but calls from no kernel; the product's integrator 3), 8 spp."""
+    out = {}
+    meta = {"width": W, "height": H, "hi_spp": HI_SPP, "spp": SPP, "images": {}}
+    for name, (cfg, white, spec) in IMAGES.items():
+        o = scenes.oracle_scene(cfg, W, H)
+        if white:
+            o.set_envmap(np.ones((1, 1, 3), np.float32))
+        out["hi_" + name] = gb.GLSLReference(o, spec_math=spec).render(HI_SPP)
+        meta["images"]["hi_" + name] = dict(config=cfg, white_env=white, spec_math=spec, spp=HI_SPP)
+        print("hi", name, "done", flush=True)
+    out["hi_emission_spec"] = gb.GLSLReference(emission_scene(W, H), spec_math=True).render(HI_SPP)
+    meta["images"]["hi_emission_spec"] = dict(config="emission", white_env=False, spec_math=True, spp=HI_SPP)
+    for cfg in ("c2", "c3"):
+        o = scenes.oracle_scene(cfg, W, H)
+        out["rm_%s_spec" % cfg] = gb.GLSLReference(o, spec_math=True).render(SPP, variant="raymarch")
+        meta["images"]["rm_%s_spec" % cfg] = dict(config=cfg, white_env=False, spec_math=True, spp=SPP, integrator=3)
+    np.savez_compressed(os.path.join(HERE, "glsl_golden_r2.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "glsl_golden_r2.json"), "w"), indent=1)
+    print("wrote glsl_golden_r2.npz (%d arrays)" % len(out))
+
+
 if __name__ == "__main__":
-    main()
+    if "--r2" in sys.argv:
+        main_r2()
+    else:
+        main()

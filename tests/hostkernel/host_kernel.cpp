@@ -24,23 +24,21 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
                 const uint32_t ad[3], const uint8_t* atlas, int n_mips, const uint32_t* const* mips, bool density) {
     const size_t n = (size_t)nb[0] * nb[1] * nb[2];
     const uint32_t sx = ad[0] / 8, sy = ad[1] / 8, sz = ad[2] / 8;
-    const size_t slots = (size_t)sx * sy * sz;
-    g.atlas.assign((slots + 1) * 512, 0);
-    for (uint32_t pz = 0; pz < sz; ++pz) for (uint32_t py = 0; py < sy; ++py) for (uint32_t px = 0; px < sx; ++px)
-        for (uint32_t z = 0; z < 8; ++z) for (uint32_t y = 0; y < 8; ++y)
-            memcpy(&g.atlas[(((size_t)pz * sy + py) * sx + px) * 512 + z * 64 + y * 8],
-                   atlas + (((size_t)(pz * 8 + z) * ad[1] + (py * 8 + y)) * ad[0] + px * 8), 8);
     for (int i = 0; i < 2; ++i) g.view.bshift[i] = ceil_log2(nb[i]);
     for (int i = 0; i < 3; ++i) { g.view.mshift[i] = ceil_log2(nb[i]) < 3 ? 3 : ceil_log2(nb[i]); g.view.mlim[i] = (float)(8u << g.view.mshift[i]); }
     g.recs.assign((size_t)nb[2] << (g.view.bshift[0] + g.view.bshift[1]), BrickRec{ 0u, 0.f, 0.f, 0u });
+    g.atlas.assign(g.recs.size() * 512, 0);                                 // brick-linear blocks == brick_grid_to_device
     for (size_t i = 0; i < n; ++i) {
         const uint32_t ind = indirection[i], rg = range[i];
         const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
         const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
         const size_t bx = i % nb[0], by = (i / nb[0]) % nb[1], bz = i / ((size_t)nb[0] * nb[1]);
-        BrickRec& r = g.recs[(((bz << g.view.bshift[1]) + by) << g.view.bshift[0]) + bx];      // == brick_grid_to_device
-        r.slot = (px < sx && py < sy && pz < sz) ? (uint32_t)(((size_t)pz * sy + py) * sx + px) : (uint32_t)slots;
-        r.rmin = lo; r.rdiff = hi - lo; r.range = rg;
+        const size_t idx = (((bz << g.view.bshift[1]) + by) << g.view.bshift[0]) + bx;
+        BrickRec& r = g.recs[idx];
+        r.slot = (uint32_t)idx; r.rmin = lo; r.rdiff = hi - lo; r.range = rg;
+        if (r.rdiff != 0.f && px < sx && py < sy && pz < sz)
+            for (uint32_t z = 0; z < 8; ++z) for (uint32_t y = 0; y < 8; ++y)
+                memcpy(&g.atlas[idx * 512 + z * 64 + y * 8], atlas + (((size_t)(pz * 8 + z) * ad[1] + (py * 8 + y)) * ad[0] + px * 8), 8);
     }
     std::vector<uint32_t> words(range, range + n);
     uint32_t mip_off[4] = { 0u, 0u, 0u, 0u };

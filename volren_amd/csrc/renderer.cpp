@@ -122,10 +122,9 @@ BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseG
     const int32_t dim[3] = { (int32_t)g->dim.x, (int32_t)g->dim.y, (int32_t)g->dim.z };
     const int32_t nb[3] = { (int32_t)up8(g->dim.x), (int32_t)up8(g->dim.y), (int32_t)up8(g->dim.z) };
     const size_t n = (size_t)nb[0] * nb[1] * nb[2];
-    if (nb[0] > 1023 || nb[1] > 1023) throw std::runtime_error("dense_to_bricks_on_device: grid too large for 10-bit brick pointers");
     for (int i = 0; i < 3; ++i) out.nb[i] = nb[i];
     out.transform = g->transform;
-    DeviceBuffer dense(g->voxels.size() * sizeof(float)), flag(n * sizeof(uint32_t)), slot_of((n + 1) * sizeof(uint32_t));
+    DeviceBuffer dense(g->voxels.size() * sizeof(float)), flag(n * sizeof(uint32_t));
     dense.upload(g->voxels.data(), g->voxels.size() * sizeof(float), stream);
     // range words of all mips in one buffer (mip m has ceil(nb / 2^m) cells per axis)
     int32_t mdim[4][3];
@@ -140,20 +139,13 @@ BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseG
     out.range_words = make_device_buffer(total * sizeof(uint32_t));
     set_layout(out);
     uint32_t* words = out.range_words->as<uint32_t>();
-    launch_encode_ranges(dense.as<float>(), dim, nb, words, flag.as<uint32_t>(), slot_of.as<uint32_t>(), stream);
+    launch_encode_ranges(dense.as<float>(), dim, nb, words, flag.as<uint32_t>(), stream);
     VR_HIP(hipGetLastError());
-    uint32_t count = 0;
-    VR_HIP(hipMemcpyAsync(&count, slot_of.as<uint32_t>() + n, sizeof count, hipMemcpyDeviceToHost, stream));
-    VR_HIP(hipStreamSynchronize(stream));
-    const size_t per_layer = (size_t)nb[0] * nb[1];
-    const size_t layers = std::max<size_t>(1, (count + per_layer - 1) / per_layer);
-    if (layers > 1023) throw std::runtime_error("dense_to_bricks_on_device: grid too large for 10-bit brick pointers");
-    const size_t n_slots = per_layer * layers;                   // same atlas extent as the host encoder, + the zero slot
-    out.atlas = make_device_buffer((n_slots + 1) * 512);
+    out.atlas = make_device_buffer(padded_brick_records(out) * 512);        // brick-linear blocks (see brick_grid_to_device)
     VR_HIP(hipMemsetAsync(out.atlas->get(), 0, out.atlas->size_bytes(), stream));
     out.bricks = make_device_buffer(padded_brick_records(out) * sizeof(BrickRec));
     VR_HIP(hipMemsetAsync(out.bricks->get(), 0, out.bricks->size_bytes(), stream));
-    launch_encode_bricks(dense.as<float>(), dim, nb, out.bshift, words, flag.as<uint32_t>(), slot_of.as<uint32_t>(), out.bricks->as<BrickRec>(), out.atlas->as<uint8_t>(), stream);
+    launch_encode_bricks(dense.as<float>(), dim, nb, out.bshift, words, flag.as<uint32_t>(), out.bricks->as<BrickRec>(), out.atlas->as<uint8_t>(), stream);
     for (int m = 1; m <= 3; ++m) launch_range_mip(words + out.mip_off[m - 1], mdim[m - 1], words + out.mip_off[m], mdim[m], stream);
     VR_HIP(hipGetLastError());
     VR_HIP(hipStreamSynchronize(stream));
@@ -206,34 +198,33 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
     if (n_bricks == 0) throw std::runtime_error("brick_grid_to_device: empty grid");
     out.nb[0] = (int)nb.x; out.nb[1] = (int)nb.y; out.nb[2] = (int)nb.z;
     out.transform = g->transform;
-    // atlas: 3D texture of 8^3 blocks -> brick-major slots of 512 contiguous bytes, plus one all-zero slot that
-    // absorbs pointers outside the atlas (GL: undefined fetch)
+    // atlas: 3D texture of 8^3 blocks addressed through the indirection words -> brick-LINEAR blocks of 512 contiguous bytes:
+    // the block of brick record i is bytes [512 i, 512 i + 512), so that a tap fetches record and voxel in one round trip
+    // instead of chasing the pointer (vr_trace.h tap_load).  A brick whose range is a single value keeps a zero block (its
+    // voxels never matter: rmin + u * 0), and so does a pointer outside the atlas (GL: undefined fetch).
     const uvec3 ad = g->atlas.stride;
     const uint32_t sx = ad.x / 8, sy = ad.y / 8, sz = ad.z / 8;
-    const size_t n_slots = (size_t)sx * sy * sz;
-    const uint32_t zero_slot = (uint32_t)n_slots;
-    std::vector<uint8_t> atlas((n_slots + 1) * 512, 0);
-    for (uint32_t pz = 0; pz < sz; ++pz)
-        for (uint32_t py = 0; py < sy; ++py)
-            for (uint32_t px = 0; px < sx; ++px) {
-                uint8_t* dst = &atlas[(((size_t)pz * sy + py) * sx + px) * 512];
-                for (uint32_t z = 0; z < 8; ++z)
-                    for (uint32_t y = 0; y < 8; ++y)
-                        memcpy(dst + z * 64 + y * 8, &g->atlas.data[g->atlas.index(px * 8, py * 8 + y, pz * 8 + z)], 8);
-            }
     upload_range_words(out, nb, g->range, g->range_mipmaps);        // also fixes the padded layout (bshift, mshift)
     std::vector<BrickRec> recs(padded_brick_records(out), BrickRec{ 0u, 0.f, 0.f, 0u });
+    std::vector<uint8_t> atlas(recs.size() * 512, 0);
     for (size_t i = 0; i < n_bricks; ++i) {
         const uint32_t ind = g->indirection.data[i], rg = g->range.data[i];
         const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
         const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
+        const size_t bx = i % nb.x, by = (i / nb.x) % nb.y, bz = i / ((size_t)nb.x * nb.y);
+        const size_t idx = (((bz << out.bshift[1]) + by) << out.bshift[0]) + bx;
         BrickRec r;
-        r.slot = (px < sx && py < sy && pz < sz) ? (uint32_t)(((size_t)pz * sy + py) * sx + px) : zero_slot;
+        r.slot = (uint32_t)idx;
         r.rmin = lo;
         r.rdiff = hi - lo;
         r.range = rg;
-        const size_t bx = i % nb.x, by = (i / nb.x) % nb.y, bz = i / ((size_t)nb.x * nb.y);
-        recs[(((bz << out.bshift[1]) + by) << out.bshift[0]) + bx] = r;
+        recs[idx] = r;
+        if (r.rdiff != 0.f && px < sx && py < sy && pz < sz) {
+            uint8_t* dst = &atlas[idx * 512];
+            for (uint32_t z = 0; z < 8; ++z)
+                for (uint32_t y = 0; y < 8; ++y)
+                    memcpy(dst + z * 64 + y * 8, &g->atlas.data[g->atlas.index(px * 8, py * 8 + y, pz * 8 + z)], 8);
+        }
     }
     out.bricks = make_device_buffer(recs.size() * sizeof(BrickRec));
     out.bricks->upload(recs.data(), recs.size() * sizeof(BrickRec));

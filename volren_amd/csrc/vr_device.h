@@ -31,9 +31,9 @@ void launch_majorants(const SceneParams& P, const uint32_t* range_words_all_mips
                       const int32_t mshift[3], float* out_padded, hipStream_t stream);
 
 // Dense -> brick encoder on the device (Volume::to_brick_grid / commit(), src/renderer.cpp:63); see vr_kernels.hip.
-// ranges: range[nb] (fp16x2 words), flag[nb] (needs an atlas block), slot_of[nb + 1] (exclusive scan, [nb] = block count)
-void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_t nb[3], uint32_t* range, uint32_t* flag, uint32_t* slot_of, hipStream_t stream);
-void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const int32_t bshift[2], const uint32_t* range, const uint32_t* flag, const uint32_t* slot_of,
+// ranges: range[nb] (fp16x2 words), flag[nb] (range is not a single value: the voxels matter)
+void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_t nb[3], uint32_t* range, uint32_t* flag, hipStream_t stream);
+void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const int32_t bshift[2], const uint32_t* range, const uint32_t* flag,
                           BrickRec* recs, uint8_t* atlas, hipStream_t stream);
 void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream);
 

@@ -134,7 +134,7 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     D.chunks = (uint32_t)chunks;
     D.seg_len = (D.n_units + kQueueSegments - 1u) / kQueueSegments;
     D.unit_counter = unit_counter;
-    S.max_iters = 1u << 27;          // watchdog (see the kernel): ~100x the iterations of the heaviest wavefront seen
+    S.max_iters = kMaxIters;
     const int variant = pathtrace_variant(P);
     const bool tf = P.u.use_tf != 0, stats = g_stats != nullptr;
     static int blocks_cache[4][4] = {};
@@ -224,10 +224,9 @@ void launch_build_impmap(const float* envmap_rgba, int32_t env_w, int32_t env_h,
 // src/renderer.cpp:63).  Same rules, same arithmetic and same slot order as the host encoder in grids.cpp, so both
 // produce identical device arrays (tests compare checksums):
 //   1. encode_range_kernel : per brick, (min, max) over the brick dilated by 2 voxels, rounded outwards to fp16;
-//                            flag = the brick needs an atlas block (max != min)
-//   2. exclusive scan of the flags (brick index order = slot order)
-//   3. encode_brick_kernel : per brick, BrickRec + 512 quantised voxels straight into the brick-major atlas
-//   4. range_mip_kernel    : (min of mins, max of maxes) over 2x2x2 children, three levels
+//                            flag = the brick's voxels matter (max != min)
+//   2. encode_brick_kernel : per brick, BrickRec + 512 quantised voxels straight into its block of the brick-linear atlas
+//   3. range_mip_kernel    : (min of mins, max of maxes) over 2x2x2 children, three levels
 __global__ void __launch_bounds__(256)
 encode_range_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int32_t nz, int32_t nbx, int32_t nby, int32_t nbz,
                     uint32_t* __restrict__ range, uint32_t* __restrict__ flag) {
@@ -255,34 +254,20 @@ encode_range_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int
         flag[brick] = half2float(hhi) != half2float(hlo) ? 1u : 0u;
     }
 }
-// single-workgroup exclusive scan (brick counts are modest: 2M for a 1024^3 grid); out[n] = total
-__global__ void __launch_bounds__(1024)
-exclusive_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int32_t n) {
-    __shared__ uint32_t part[1024];
-    const int32_t per = (n + 1023) / 1024, b = threadIdx.x * per, e = min(n, b + per);
-    uint32_t sum = 0u;
-    for (int32_t i = b; i < e; ++i) sum += in[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t acc = 0u; for (int32_t i = 0; i < 1024; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; } out[n] = acc; }
-    __syncthreads();
-    uint32_t acc = part[threadIdx.x];
-    for (int32_t i = b; i < e; ++i) { out[i] = acc; acc += in[i]; }
-}
 __global__ void __launch_bounds__(64)
 encode_brick_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int32_t nz, int32_t nbx, int32_t nby, int32_t bsx, int32_t bsy,
-                    const uint32_t* __restrict__ range, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ slot_of,
+                    const uint32_t* __restrict__ range, const uint32_t* __restrict__ flag,
                     BrickRec* __restrict__ recs, uint8_t* __restrict__ atlas) {
     const int32_t brick = blockIdx.x, lane = threadIdx.x;
     const int32_t bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
     const uint32_t rg = range[brick];
     const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
-    const bool alloc = flag[brick] != 0u;
-    const uint32_t slot = alloc ? slot_of[brick] : 0u;       // bricks without a block point at slot 0 (indirection word 0)
-    if (lane == 0) { BrickRec r; r.slot = slot; r.rmin = lo; r.rdiff = hi - lo; r.range = rg; recs[((((size_t)bz << bsy) + by) << bsx) + bx] = r; }
+    const bool alloc = flag[brick] != 0u;                    // a brick whose range is one value keeps its zeroed block
+    const size_t idx = ((((size_t)bz << bsy) + by) << bsx) + bx;      // brick-linear atlas: block index = record index
+    if (lane == 0) { BrickRec r; r.slot = (uint32_t)idx; r.rmin = lo; r.rdiff = hi - lo; r.range = rg; recs[idx] = r; }
     if (!alloc) return;
     const float inv = 255.0f / (hi - lo);
-    uint8_t* dst = atlas + (size_t)slot * 512u;
+    uint8_t* dst = atlas + idx * 512u;
     for (int32_t i = lane; i < 512; i += 64) {
         const int32_t x = bx * 8 + (i & 7), y = by * 8 + ((i >> 3) & 7), z = bz * 8 + (i >> 6);
         float v = 0.0f;
@@ -309,15 +294,14 @@ range_mip_kernel(const uint32_t* __restrict__ src, int32_t sx, int32_t sy, int32
     dst[i] = hlo | (hhi << 16);
 }
 
-void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_t nb[3], uint32_t* range, uint32_t* flag, uint32_t* slot_of, hipStream_t stream) {
+void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_t nb[3], uint32_t* range, uint32_t* flag, hipStream_t stream) {
     const int32_t n = nb[0] * nb[1] * nb[2];
     hipLaunchKernelGGL(encode_range_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], nb[2], range, flag);
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, flag, slot_of, n);
 }
-void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const int32_t bshift[2], const uint32_t* range, const uint32_t* flag, const uint32_t* slot_of,
+void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const int32_t bshift[2], const uint32_t* range, const uint32_t* flag,
                           BrickRec* recs, uint8_t* atlas, hipStream_t stream) {
     const int32_t n = nb[0] * nb[1] * nb[2];
-    hipLaunchKernelGGL(encode_brick_kernel, dim3(n), dim3(64), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], bshift[0], bshift[1], range, flag, slot_of, recs, atlas);
+    hipLaunchKernelGGL(encode_brick_kernel, dim3(n), dim3(64), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], bshift[0], bshift[1], range, flag, recs, atlas);
 }
 void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream) {
     const int32_t n = ddim[0] * ddim[1] * ddim[2];

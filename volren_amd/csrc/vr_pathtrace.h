@@ -27,6 +27,7 @@ struct SchedParams {
 // blockIdx.x & 7 names the XCD): the waves of one XCD -- which share one L2 -- work on one band of tile rows; a wave whose
 // segment is empty takes units from the next one.
 constexpr uint32_t kQueueSegments = 8u;
+constexpr uint32_t kMaxIters = 1u << 27;      // watchdog: ~100x the scheduler iterations of the heaviest wavefront seen
 struct LaunchDesc {
     const int32_t* tiles;     // 16x16 tile ids (raster, row 0 = bottom) or nullptr = all tiles
     int32_t n_tiles, first_sample, n_samples, spu;
@@ -120,40 +121,58 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// The scene parameters are ~1 KiB of uniforms.  The hot pair (march / collide) reads its few fields from the by-value
-// kernel argument `P`, which the compiler keeps in SGPRs for the whole launch.  The event code (new sample, NEE, scatter,
-// escape) reads everything else -- camera, environment, transforms -- through event_params(): the same kernel-argument
-// bytes, addressed through a pointer the optimiser cannot see through, so that those ~150 dwords are fetched by scalar
-// loads where an event needs them instead of being hoisted out of the scheduler loop and spilled (round 1: 217 SGPR spills,
-// i.e. a v_readlane/v_writelane + s_nop on every use).  `P` MUST stay the kernel's first parameter: the kernarg segment
-// lays arguments out in order from offset 0 (AMDGPU ABI).
-typedef const __attribute__((address_space(4))) SceneParams* KernargParams;
-__device__ __forceinline__ const SceneParams& event_params() {
-    KernargParams p = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+// All kernel arguments travel as ONE struct so that the event code can address any of them through the kernarg pointer.
+// The scene parameters alone are ~1 KiB of uniforms.  The hot pair (march / collide) reads its few fields from the by-value
+// argument, which the compiler keeps in SGPRs; the event code (new sample, NEE, scatter, escape) reads everything else --
+// camera, environment, transforms, the work queue -- through event_args(): the same bytes, addressed through a pointer the
+// optimiser cannot see through, so that those ~200 dwords are fetched by scalar loads where an event needs them instead of
+// being hoisted out of the scheduler loop and spilled (round 1: 217 SGPR spills = a v_readlane/v_writelane + s_nop per use).
+struct KernelArgs {
+    SceneParams P;
+    LaunchDesc D;
+    SchedParams S;
+    float* sbuf;                 // sample pool
+    float* cold_ws;              // cold path state of all resident wavefronts
+    uint32_t* status;            // [0] bit 0: watchdog tripped, bit 1: a path ended in an impossible state
+    unsigned long long* stats;   // STATS kernels only
+};
+typedef const __attribute__((address_space(4))) KernelArgs* KernargPtr;
+__device__ __forceinline__ const KernelArgs& event_args() {
+    KernargPtr p = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();      // the struct is the only kernel parameter: offset 0
     asm volatile("" : "+s"(p));
-    return *(const SceneParams*)p;
+    return *(const KernelArgs*)p;
 }
 
 template <class K, bool STATS>
 __global__ void __launch_bounds__(256, VR_WAVES_PER_SIMD)
-pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restrict__ cold_ws, const LaunchDesc D, const SchedParams S,
-                 uint32_t* __restrict__ status, unsigned long long* __restrict__ stats) {
+pathtrace_kernel(const KernelArgs A) {
+    const SceneParams& P = A.P;           // hot pair only; events use event_args()
     const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
     __shared__ uint8_t lds_q[4 * Q_COUNT * NSLOT];
     uint8_t* const q = lds_q + wave * (Q_COUNT * NSLOT);
     // per-wavefront slice of the workspace: the cold fields of its NSLOT paths
-    float* const cold_base = cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)(C_STRIDE * NSLOT);
+    float* const cold_base = A.cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)(C_STRIDE * NSLOT);
     __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NSLOT];
     const HotStore hs{ lds_hot + wave * (HOT_STRIDE * NSLOT) };
 
-    const int32_t pool = (S.thr[ST_BEGIN] > 0 && S.thr[ST_BEGIN] < NSLOT) ? S.thr[ST_BEGIN] : NSLOT;     // slots in use (diagnostic cap)
+    // scheduler thresholds, one byte each in two scalars: batch sizes that trigger NEW / NEE / POSTNEE / ESCAPE, the low-water
+    // mark of live paths ("hungry"), the slots in use (diagnostic cap)
+    const int32_t pool = (A.S.thr[ST_BEGIN] > 0 && A.S.thr[ST_BEGIN] < NSLOT) ? A.S.thr[ST_BEGIN] : NSLOT;
+    const uint32_t thr_a = (uint32_t)(A.S.thr[ST_NEW] & 255) | ((uint32_t)(A.S.thr[ST_NEE] & 255) << 8) | ((uint32_t)(A.S.thr[ST_POSTNEE] & 255) << 16) | ((uint32_t)(A.S.thr[ST_ESCAPE] & 255) << 24);
+    const uint32_t thr_b = (uint32_t)(A.S.thr[ST_MARCH] & 255) | ((uint32_t)pool << 8);
+#define VR_THR_NEW ((int32_t)(thr_a & 255u))
+#define VR_THR_NEE ((int32_t)((thr_a >> 8) & 255u))
+#define VR_THR_POST ((int32_t)((thr_a >> 16) & 255u))
+#define VR_THR_ESC ((int32_t)(thr_a >> 24))
+#define VR_THR_HUNGRY ((int32_t)(thr_b & 255u))
+#define VR_POOL ((int32_t)(thr_b >> 8))
     int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = pool;     // stack heights (wave-uniform)
     for (int32_t i = lane; i < pool; i += 64) q[Q_FREE * NSLOT + i] = (uint8_t)i;
     __builtin_amdgcn_wave_barrier();
 
-    WorkUnit wu;
-    wu.px0 = wu.py0 = 0; wu.first_sample = 1; wu.n_items = 0; wu.base = 0u; wu.out = sbuf;
+    WorkUnit wu;                      // current unit; .out is filled in where a sample is written (event_args().sbuf)
+    wu.px0 = wu.py0 = 0; wu.first_sample = 1; wu.n_items = 0; wu.base = 0u; wu.out = nullptr;
     uint32_t cursor = 0u;             // next item of the current unit (wave-uniform)
     bool exhausted = false;           // the global queue has no more units
     uint32_t seg_tries = 0u;          // queue segments this wavefront has found empty (wave-uniform)
@@ -163,7 +182,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
     int32_t slot = -1;                // path held in this lane's registers (-1: none)
 
     uint32_t iters = 0u;
-    unsigned long long t_last = __builtin_readcyclecounter(), t_elapsed = 0ull;
+    uint32_t t_last = (uint32_t)__builtin_readcyclecounter(), t_elapsed = 0u;
     uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
     unsigned long long occ[6] = { 0, 0, 0, 0, 0, 0 };      // summed per iteration: marching lanes, READY, NEE, POSTNEE, ESCAPE, FREE
@@ -184,27 +203,28 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
         VR_PUSH(Q_POST, cnt_post, v_ && s_ == ST_POSTNEE, BS); \
         VR_PUSH(Q_ESC, cnt_esc, v_ && s_ == ST_ESCAPE, BS); \
         const bool lost_ = v_ && (s_ < ST_NEW || s_ > ST_ESCAPE || s_ == ST_BEGIN); \
-        if (__ballot(lost_)) { if (lost_) atomicOr(status, 2u); } \
+        if (__ballot(lost_)) { if (lost_) atomicOr(event_args().status, 2u); } \
         VR_PUSH(Q_FREE, cnt_free, v_ && (s_ == ST_NEW || lost_), BS); \
     } while (0)
 #define VR_ROUTE(BS) VR_ROUTE_ST(BS, l.state)
 #define VR_ROUTE_B(BS) VR_ROUTE_ST(BS, b.state)
 
     for (;;) {
-        // watchdog: a wavefront's share of a launch is tens of milliseconds; give up (and report) after S.max_iters
-        // scheduler iterations or ~8 s of shader clock, whichever comes first -- a kernel must never hang the GPU
-        bool give_up = ++iters > S.max_iters;
+        // watchdog: a wavefront's share of a launch is tens of milliseconds; give up (and report) after kMaxIters scheduler
+        // iterations or ~8 s of shader clock, whichever comes first -- a kernel must never hang the GPU
+        bool give_up = ++iters > kMaxIters;
         if ((iters & 1023u) == 0u) {
-            // elapsed shader-clock time, summed over 1024-iteration windows.  A window that appears to take more than 2^34 ticks (or
-            // a negative time) is a counter discontinuity -- a wavefront that was saved and restored on another XCD when several
-            // processes time-share the GPU reads a different counter -- and is not counted.
-            const unsigned long long now = __builtin_readcyclecounter(), d = now - t_last;
+            // elapsed shader-clock time in units of 1024 ticks, summed over 1024-iteration windows (low 32 bits of the counter:
+            // a window is a few million ticks).  A window that appears to take more than 2^31 ticks is a counter discontinuity
+            // -- a wavefront that was saved and restored on another XCD when several processes time-share the GPU reads a
+            // different counter -- and is not counted.
+            const uint32_t now = (uint32_t)__builtin_readcyclecounter(), d = now - t_last;
             t_last = now;
-            if (d < (1ull << 34)) t_elapsed += d;
-            give_up = give_up || t_elapsed > 20000000000ull;
+            if (d < (1u << 31)) t_elapsed += d >> 10;
+            give_up = give_up || t_elapsed > (20000000000ull >> 10);
         }
         if (give_up) {
-            if (lane == 0) atomicOr(status, 1u);
+            if (lane == 0) atomicOr(event_args().status, 1u);
             break;
         }
         // (1) idle lanes resume READY paths
@@ -220,23 +240,33 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
             }
         }
         if (STATS) { occ[0] += (unsigned)popc(__ballot(slot >= 0)); occ[1] += (unsigned)cnt_ready; occ[2] += (unsigned)cnt_nee; occ[3] += (unsigned)cnt_post; occ[4] += (unsigned)cnt_esc; occ[5] += (unsigned)cnt_free; }
-        // (2) the hot pair: up to thr[COLLIDE] march steps, then the collision code
-        int32_t n;
-        for (int32_t k = 0; k < S.thr[ST_COLLIDE]; ++k) {
-            n = popc(__ballot(slot >= 0 && l.state == ST_MARCH));
-            if (n == 0) break;
-            VR_STAT(ST_MARCH, n);
-            if (slot >= 0 && l.state == ST_MARCH) do_march(l, P);
-            VR_STAT_END(ST_MARCH);
-        }
-        n = popc(__ballot(slot >= 0 && l.state == ST_COLLIDE));
-        if (n > 0) {
-            VR_STAT(ST_COLLIDE, n);
-            if (slot >= 0 && l.state == ST_COLLIDE) {
+        // (2) the hot pair: two DDA steps for the marching lanes, then the collision code for every lane that now stands at a
+        // tentative collision (after two steps that is most of them, so both blocks run nearly full width).  Two memory round
+        // trips per pass instead of four: both majorants are loaded together (the second step is prepared speculatively,
+        // march_prep), and a tap's brick record and voxel are loaded together (brick-linear atlas, tap_load).  The loads
+        // themselves are unconditional straight-line code between the exec-masked blocks (march_load / collide_load).
+        {
+            if (STATS) t_blk = __builtin_readcyclecounter();
+            const bool is_m = slot >= 0 && l.state == ST_MARCH;
+            MarchIO mio;
+            march_idle(mio);
+            if (is_m) march_prep(l, P, mio);
+            march_load(P, mio);
+            if (is_m) march_finish(l, mio);
+            if (STATS) { const int32_t nm = popc(__ballot(is_m)); if (nm) { st_exec[ST_MARCH] += 1u; st_lanes[ST_MARCH] += (uint32_t)nm; } const unsigned long long t_now = __builtin_readcyclecounter(); st_cyc[ST_MARCH] += t_now - t_blk; t_blk = t_now; }
+            const bool is_c = slot >= 0 && l.state == ST_COLLIDE;
+            CollideIO<K> cio;
+            collide_idle<K>(cio);
+            if (is_c) collide_prep<K>(l, P, cio);
+            collide_load<K>(P, cio);
+            if (is_c) {
                 ColdGlobal c{ cold_base + slot * C_STRIDE };
-                if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) do_collide_global<K>(l, c, P); else do_collide<K>(l, c, P);
+                collide_finish<K>(l, c, P, cio);
             }
-            VR_STAT_END(ST_COLLIDE);
+            // every load of the pass has been consumed or belongs to a lane that left early: say so, or the compiler carries
+            // "possibly outstanding" around the loop and waits where nothing is pending
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0)
+            if (STATS) { const int32_t nc = popc(__ballot(is_c)); if (nc) { st_exec[ST_COLLIDE] += 1u; st_lanes[ST_COLLIDE] += (uint32_t)nc; } st_cyc[ST_COLLIDE] += __builtin_readcyclecounter() - t_blk; }
         }
         // (3) park paths that reached an event
         {
@@ -251,8 +281,9 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
             }
         }
         // (4) event batches
+        int32_t n;
         const int32_t n_live = popc(__ballot(slot >= 0)) + cnt_ready;
-        const bool hungry = n_live < S.thr[ST_MARCH];                    // the hot pair is about to run under-filled
+        const bool hungry = n_live < VR_THR_HUNGRY;                    // the hot pair is about to run under-filled
         // a batch runs when it is full enough; a hungry wave additionally runs its LARGEST batch (only that one, so that the
         // others keep filling up)
         const int32_t c_new = exhausted ? 0 : cnt_free;
@@ -260,10 +291,10 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
         if (cnt_nee > big) big = cnt_nee;
         if (cnt_post > big) big = cnt_post;
         if (cnt_esc > big) big = cnt_esc;
-        const bool want_new = c_new > 0 && (c_new >= S.thr[ST_NEW] || (hungry && c_new == big));
-        const bool want_nee = cnt_nee > 0 && (cnt_nee >= S.thr[ST_NEE] || (hungry && cnt_nee == big));
-        const bool want_post = cnt_post > 0 && (cnt_post >= S.thr[ST_POSTNEE] || (hungry && cnt_post == big));
-        const bool want_esc = cnt_esc > 0 && (cnt_esc >= S.thr[ST_ESCAPE] || (hungry && cnt_esc == big));
+        const bool want_new = c_new > 0 && (c_new >= VR_THR_NEW || (hungry && c_new == big));
+        const bool want_nee = cnt_nee > 0 && (cnt_nee >= VR_THR_NEE || (hungry && cnt_nee == big));
+        const bool want_post = cnt_post > 0 && (cnt_post >= VR_THR_POST || (hungry && cnt_post == big));
+        const bool want_esc = cnt_esc > 0 && (cnt_esc >= VR_THR_ESC || (hungry && cnt_esc == big));
         if (want_new || want_nee || want_post || want_esc) {
             // the lanes double as batch workers.  VR_BATCH_REGS=1: the batch path lives in its own register set `b` and the
             // marching path `l` stays put; =0: the marching path is saved to its LDS slot and `l` is reused (fewer VGPRs)
@@ -283,7 +314,9 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                     bs = q[Q_ESC * NSLOT + cnt_esc - 1 - lane];
                     hs.load(b, bs);
                     ColdGlobal c{ cold_base + bs * C_STRIDE };
-                    do_escape(b, c, event_params(), wu);                              // writes the sample; the slot becomes free
+                    const KernelArgs& E = event_args();
+                    WorkUnit w; w.out = E.sbuf;
+                    do_escape(b, c, E.P, w);                              // writes the sample; the slot becomes free
                 }
                 cnt_esc -= n;
                 VR_ROUTE_B(bs);                                            // ST_NEW: the slot is free again
@@ -297,7 +330,9 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                     bs = q[Q_POST * NSLOT + cnt_post - 1 - lane];
                     hs.load(b, bs);
                     ColdGlobal c{ cold_base + bs * C_STRIDE };
-                    do_postnee<K>(b, c, event_params(), wu);
+                    const KernelArgs& E = event_args();
+                    WorkUnit w; w.out = E.sbuf;
+                    do_postnee<K>(b, c, E.P, w);
                     hs.save(b, bs);
                 }
                 cnt_post -= n;
@@ -306,17 +341,18 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
             }
             if (want_new) {
                 if (cursor == (uint32_t)wu.n_items) {
+                    const KernelArgs& E = event_args();
                     uint32_t j = 0xFFFFFFFFu;
                     while (seg_tries < kQueueSegments) {                    // own segment first, then the following ones
                         const uint32_t k = ((blockIdx.x & (kQueueSegments - 1u)) + seg_tries) & (kQueueSegments - 1u);
-                        const uint32_t lo = k * D.seg_len, hi = min(lo + D.seg_len, D.n_units);
+                        const uint32_t lo = k * E.D.seg_len, hi = min(lo + E.D.seg_len, E.D.n_units);
                         uint32_t v = 0xFFFFFFFFu;
-                        if (lo < hi) { if (lane == 0) v = atomicAdd(D.unit_counter + k, 1u); v = __builtin_amdgcn_readfirstlane(v); }
+                        if (lo < hi) { if (lane == 0) v = atomicAdd(E.D.unit_counter + k, 1u); v = __builtin_amdgcn_readfirstlane(v); }
                         if (lo < hi && v < hi - lo) { j = lo + v; break; }
                         ++seg_tries;                                        // this segment is used up for good
                     }
                     if (j == 0xFFFFFFFFu) exhausted = true;
-                    else { wu = make_unit(D, event_params().u.resolution[0], j, sbuf); cursor = 0u; }
+                    else { wu = make_unit(E.D, E.P.u.resolution[0], j, nullptr); cursor = 0u; }
                 }
                 n = min(min(64, cnt_free), (int32_t)((uint32_t)wu.n_items - cursor));
                 if (n > 0) {
@@ -326,7 +362,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                         bs = q[Q_FREE * NSLOT + cnt_free - 1 - lane];
                         hot_init(b);
                         ColdGlobal c{ cold_base + bs * C_STRIDE };
-                        do_new<K>(b, c, event_params(), wu, cursor + (uint32_t)lane);
+                        do_new<K>(b, c, event_args().P, wu, cursor + (uint32_t)lane);
                         hs.save(b, bs);
                     }
                     cnt_free -= n;
@@ -343,7 +379,7 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
                     bs = q[Q_NEE * NSLOT + cnt_nee - 1 - lane];
                     hs.load(b, bs);
                     ColdGlobal c{ cold_base + bs * C_STRIDE };
-                    do_nee<K>(b, c, event_params());
+                    do_nee<K>(b, c, event_args().P);
                     hs.save(b, bs);
                 }
                 cnt_nee -= n;
@@ -355,8 +391,9 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
             if (my_slot >= 0) hs.load(l, my_slot);
 #endif
         }
-        if (exhausted && cnt_free == pool) break;                        // every path of the pool has finished
+        if (exhausted && cnt_free == VR_POOL) break;                        // every path of the pool has finished
     }
+    unsigned long long* const stats = A.stats;
     if (STATS && stats && lane == 0) {
 #pragma unroll
         for (int k = 0; k < ST_DONE; ++k) { atomicAdd(&stats[2 * k], (unsigned long long)st_exec[k]); atomicAdd(&stats[2 * k + 1], (unsigned long long)st_lanes[k]); }
@@ -369,6 +406,12 @@ pathtrace_kernel(const SceneParams P, float* __restrict__ sbuf, float* __restric
         for (int k = 0; k < 6; ++k) atomicAdd(&stats[26 + k], occ[k]);
     }
 #undef VR_STAT
+#undef VR_THR_NEW
+#undef VR_THR_NEE
+#undef VR_THR_POST
+#undef VR_THR_ESC
+#undef VR_THR_HUNGRY
+#undef VR_POOL
 #undef VR_STAT_END
 #undef VR_PUSH
 #undef VR_ROUTE

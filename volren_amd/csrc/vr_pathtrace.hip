@@ -26,7 +26,7 @@ template <bool TF> using Cfg = TraceCfg<TF, 1, 2, 2>;
 #define VR_PT_CAT2(a, b) a##b
 #define VR_PT_CAT(a, b) VR_PT_CAT2(a, b)
 
-typedef void (*PtKernel)(const SceneParams, float*, float*, const LaunchDesc, const SchedParams, uint32_t*, unsigned long long*);
+typedef void (*PtKernel)(const KernelArgs);
 static PtKernel pick(bool tf, bool stats) {
     return tf ? (stats ? pathtrace_kernel<Cfg<true>, true> : pathtrace_kernel<Cfg<true>, false>)
               : (stats ? pathtrace_kernel<Cfg<false>, true> : pathtrace_kernel<Cfg<false>, false>);
@@ -39,7 +39,9 @@ int VR_PT_CAT(pt_occupancy_variant_, VR_PT_VARIANT)(bool tf, bool stats) {
 }
 void VR_PT_CAT(pt_launch_variant_, VR_PT_VARIANT)(bool tf, bool stats, unsigned grid, hipStream_t stream, const SceneParams& P, float* sbuf, float* cold_ws,
                                                    const LaunchDesc& D, const SchedParams& S, uint32_t* status, unsigned long long* stats_buf) {
-    hipLaunchKernelGGL(pick(tf, stats), dim3(grid), dim3(256), 0, stream, P, sbuf, cold_ws, D, S, status, stats_buf);
+    KernelArgs A;
+    A.P = P; A.D = D; A.S = S; A.sbuf = sbuf; A.cold_ws = cold_ws; A.status = status; A.stats = stats_buf;
+    hipLaunchKernelGGL(pick(tf, stats), dim3(grid), dim3(256), 0, stream, A);
 }
 
 }  // namespace vr

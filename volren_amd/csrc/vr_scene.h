@@ -7,7 +7,8 @@
 namespace vr {
 
 // One brick of a voldata::BrickGrid, repacked for HBM (DESIGN.md "Data layout"):
-//   slot  : index of the brick's 8x8x8 u8 block in the brick-major atlas (512 contiguous bytes per slot)
+//   slot  : index of the brick's 8x8x8 u8 block in the atlas (512 contiguous bytes per block).  The atlas is brick-LINEAR:
+//           slot == the record's own index, so the hot path computes the voxel address without reading it
 //   rmin  : float(range.x); rdiff = float(range.y) - float(range.x)  (both exact/IEEE, done once at commit)
 //   range : the file's 2 x fp16 word, low = min, high = max (GL_RG16F in renderer.cpp:181-183), kept for reference
 // one 16-byte load per tap;
@@ -38,7 +39,7 @@ VR_SCENE_HD size_t dense_blocked_index(uint32_t x, uint32_t y, uint32_t z, uint3
 
 struct GridView {
     const BrickRec* bricks;      // nb[2] << (bshift[0] + bshift[1]) records, power-of-two pitches (see above)
-    const uint8_t* atlas;        // slots * 512 bytes, voxel (x&7) + 8*(y&7) + 64*(z&7)
+    const uint8_t* atlas;        // one 512-byte block per brick record (same index), voxel (x&7) + 8*(y&7) + 64*(z&7)
     const float* majorant;       // all mips, padded (see above): "effective" majorant = density_scale * range.y, TF-remapped when a LUT is bound
     int32_t nb[3];               // bricks per axis (mip 0); mip m has ceil(nb / 2^m) cells per axis
     int32_t bshift[2];           // log2 of the brick-record pitches (x, y)

@@ -106,34 +106,73 @@ VR_HD void rng_skip9(uint32_t& s) {
 
 // ---------------------------------------------------------------------------------------------------
 // grids  (common.glsl:268-297); out-of-range fetches read 0 (GL: undefined)
+//
+// Every fetch is split in three: where the voxel lives (tap_addr: arithmetic only) -> the loads (tap_load) -> the value
+// (tap_value).  The scheduler (vr_pathtrace.h) runs the first two for all lanes of a pass before anything waits, so that one
+// memory round trip serves the DDA steps and the collisions of the whole wavefront.  The brick atlas is brick-linear
+// (block of brick record i = bytes [512 i, 512 i + 512)): record and voxel are fetched together, no dependent pointer chase.
 template <int DENSE>
 VR_HD bool grid_is_dense(const GridView& g) { return DENSE == 2 ? g.dense != nullptr : DENSE == 1; }
+struct TapAddr { uint32_t cell, off; bool in; };      // bricks: record index, byte inside the 8^3 block; dense: 4x4x4 block index, voxel inside it
+struct TapData { float rmin, rdiff; uint32_t raw; };  // bricks: range of the brick + the u8; dense: the fp16 bits
+template <int DENSE = 2>
+VR_HD TapAddr tap_addr(const GridView& g, int32_t x, int32_t y, int32_t z) {
+    TapAddr a;
+    const bool nonneg = (x | y | z) >= 0;
+    if (grid_is_dense<DENSE>(g)) {          // dense fp16 grid: one 2-byte load, no indirection
+        a.in = nonneg && (uint32_t)x < (uint32_t)g.dim[0] && (uint32_t)y < (uint32_t)g.dim[1] && (uint32_t)z < (uint32_t)g.dim[2];
+        // 4x4x4 blocks (vr_scene.h): neighbouring rays and the +-2-voxel stochastic taps share 128-byte lines; block counts < 2^14 per axis
+        a.cell = (mul24((uint32_t)z >> 2, (uint32_t)g.dblk[1]) + ((uint32_t)y >> 2)) * (uint32_t)g.dblk[0] + ((uint32_t)x >> 2);
+        a.off = (((uint32_t)z & 3u) << 4) | (((uint32_t)y & 3u) << 2) | ((uint32_t)x & 3u);
+    } else {
+        const uint32_t bx = (uint32_t)x >> 3, by = (uint32_t)y >> 3, bz = (uint32_t)z >> 3;
+        a.in = nonneg && bx < (uint32_t)g.nb[0] && by < (uint32_t)g.nb[1] && bz < (uint32_t)g.nb[2];
+        a.cell = (((bz << g.bshift[1]) + by) << g.bshift[0]) + bx;
+        a.off = (((uint32_t)z & 7u) << 6) | (((uint32_t)y & 7u) << 3) | ((uint32_t)x & 7u);
+    }
+    if (!a.in) { a.cell = 0u; a.off = 0u; }       // the loads are unconditional: an outside tap reads cell 0 and is discarded
+    return a;
+}
+template <int DENSE = 2>
+VR_HD TapData tap_load(const GridView& g, TapAddr a) {
+    TapData d;
+    if (grid_is_dense<DENSE>(g)) {
+        d.rmin = 0.0f; d.rdiff = 0.0f;
+        d.raw = g.dense[(size_t)a.cell * 64u + a.off];
+    } else {
+        const BrickRec* rec = g.bricks + a.cell;
+        d.rmin = rec->rmin; d.rdiff = rec->rdiff;
+        d.raw = g.atlas[(size_t)a.cell * 512u + a.off];
+    }
+    return d;
+}
+template <int DENSE = 2>
+VR_HD float tap_value(const GridView& g, TapData d, bool in) {
+    const float v = grid_is_dense<DENSE>(g) ? half2float(d.raw) : d.rmin + unorm8(d.raw) * d.rdiff;
+    return in ? v : 0.0f;
+}
 template <int DENSE = 2>
 VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
-    if ((x | y | z) < 0) return 0.0f;
-    if (grid_is_dense<DENSE>(g)) {          // dense fp16 grid: one 2-byte load, no indirection
-        if ((uint32_t)x >= (uint32_t)g.dim[0] || (uint32_t)y >= (uint32_t)g.dim[1] || (uint32_t)z >= (uint32_t)g.dim[2]) return 0.0f;
-        // 4x4x4 blocks (vr_scene.h): neighbouring rays and the +-2-voxel stochastic taps share 128-byte lines; block counts < 2^14 per axis
-        const uint32_t blk = (mul24((uint32_t)z >> 2, (uint32_t)g.dblk[1]) + ((uint32_t)y >> 2)) * (uint32_t)g.dblk[0] + ((uint32_t)x >> 2);
-        return half2float(g.dense[(size_t)blk * 64u + ((((uint32_t)z & 3u) << 4) | (((uint32_t)y & 3u) << 2) | ((uint32_t)x & 3u))]);
-    }
-    const uint32_t bx = (uint32_t)x >> 3, by = (uint32_t)y >> 3, bz = (uint32_t)z >> 3;
-    if (bx >= (uint32_t)g.nb[0] || by >= (uint32_t)g.nb[1] || bz >= (uint32_t)g.nb[2]) return 0.0f;
-    const BrickRec rec = g.bricks[(((bz << g.bshift[1]) + by) << g.bshift[0]) + bx];
-    const uint32_t b = g.atlas[(size_t)rec.slot * 512u + ((((uint32_t)z & 7u) << 6) | (((uint32_t)y & 7u) << 3) | ((uint32_t)x & 7u))];
-    return rec.rmin + unorm8(b) * rec.rdiff;
+    const TapAddr a = tap_addr<DENSE>(g, x, y, z);
+    return tap_value<DENSE>(g, tap_load<DENSE>(g, a), a.in);
 }
-VR_HD float majorant_at(const GridView& g, v3 ipos, int32_t mip) {
-    // cell = floor(ipos) >> (3 + mip); outside the grid (or NaN) reads 0.  The padded layout (vr_scene.h) holds 0 in every
-    // cell beyond the real extent of a level, so only the padded extent -- the same for all levels -- is tested, on the
-    // floats (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails), after which truncation equals floor.
+// index of the majorant cell floor(ipos) >> (3 + mip) in the padded table, or -1 outside the grid (or NaN): reads 0 there.
+// The padded layout (vr_scene.h) holds 0 in every cell beyond the real extent of a level, so only the padded extent -- the
+// same for all levels -- is tested, on the floats (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails), after
+// which truncation equals floor.
+VR_HD int32_t majorant_index(const GridView& g, v3 ipos, int32_t mip) {
     const bool inside = (mip <= g.n_mips) & (ipos.x >= 0.0f) & (ipos.x < g.mlim[0]) & (ipos.y >= 0.0f) & (ipos.y < g.mlim[1]) & (ipos.z >= 0.0f) & (ipos.z < g.mlim[2]);
-    if (!inside) return 0.0f;        // one branch: the tests are evaluated together
     const uint32_t sh = 3u + (uint32_t)mip;
     const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
     const uint32_t sx = (uint32_t)g.mshift[0] - (uint32_t)mip, sy = (uint32_t)g.mshift[1] - (uint32_t)mip;
     const uint32_t off = majorant_level_offset((uint32_t)(g.mshift[0] + g.mshift[1] + g.mshift[2]), (uint32_t)mip);
-    return g.majorant[off + (((bz << sy) + by) << sx) + bx];
+    return inside ? (int32_t)(off + (((bz << sy) + by) << sx) + bx) : -1;
+}
+VR_HD float majorant_fetch(const GridView& g, int32_t idx) { return g.majorant[idx < 0 ? 0 : idx]; }      // unconditional load (cell 0 when outside); the caller discards it then
+VR_HD float majorant_at(const GridView& g, v3 ipos, int32_t mip) {
+    const int32_t idx = majorant_index(g, ipos, mip);
+    const float m = majorant_fetch(g, idx);
+    return idx < 0 ? 0.0f : m;
 }
 // a NaN coordinate must read "outside": on the device voxel_index turns NaN into index o, so one index is forced negative
 VR_HD int32_t nan_guard(int32_t ix, float fx, float fy, float fz) {
@@ -160,48 +199,63 @@ VR_HD AxisCells axis_cells(int32_t i0, int32_t i1, uint32_t extent_voxels, uint3
     }
     return a;
 }
+struct TriIO { TapAddr a[8]; TapData d[8]; float fx, fy, fz; uint32_t in_mask; };      // corners in [z][y][x] order
 template <int DENSE = 2>
-VR_HD float density_trilinear_raw(const GridView& g, v3 ipos) {
+VR_HD void trilinear_prep(const GridView& g, v3 ipos, TriIO& io) {
     const float qx = ipos.x - 0.5f, qy = ipos.y - 0.5f, qz = ipos.z - 0.5f;
     const float flx = floor_(qx), fly = floor_(qy), flz = floor_(qz);
-    const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+    io.fx = qx - flx; io.fy = qy - fly; io.fz = qz - flz;
     const int32_t ix = nan_guard(voxel_index(flx, 0), flx, fly, flz), iy = voxel_index(fly, 0), iz = voxel_index(flz, 0);
     const int32_t x1 = nan_guard(voxel_index(flx, 1), flx, fly, flz), y1 = voxel_index(fly, 1), z1 = voxel_index(flz, 1);
-    float v[2][2][2];      // [z][y][x]
-    if (grid_is_dense<DENSE>(g)) {
-        const AxisCells X = axis_cells(ix, x1, (uint32_t)g.dim[0], 2u), Y = axis_cells(iy, y1, (uint32_t)g.dim[1], 2u), Z = axis_cells(iz, z1, (uint32_t)g.dim[2], 2u);
+    const bool dense = grid_is_dense<DENSE>(g);
+    const uint32_t lg = dense ? 2u : 3u;
+    const AxisCells X = axis_cells(ix, x1, dense ? (uint32_t)g.dim[0] : (uint32_t)g.nb[0] << 3, lg);
+    const AxisCells Y = axis_cells(iy, y1, dense ? (uint32_t)g.dim[1] : (uint32_t)g.nb[1] << 3, lg);
+    const AxisCells Z = axis_cells(iz, z1, dense ? (uint32_t)g.dim[2] : (uint32_t)g.nb[2] << 3, lg);
+    io.in_mask = 0u;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t row = (mul24(Z.c[k], (uint32_t)g.dblk[1]) + Y.c[j]) * (uint32_t)g.dblk[0];
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t row = dense ? (mul24(Z.c[k], (uint32_t)g.dblk[1]) + Y.c[j]) * (uint32_t)g.dblk[0]
+                                       : ((Z.c[k] << g.bshift[1]) + Y.c[j]) << g.bshift[0];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float val = half2float(g.dense[(size_t)(row + X.c[i]) * 64u + ((Z.o[k] << 4) | (Y.o[j] << 2) | X.o[i])]);
-                    v[k][j][i] = (X.in[i] & Y.in[j] & Z.in[k]) ? val : 0.0f;
-                }
+            for (int i = 0; i < 2; ++i) {
+                TapAddr& a = io.a[4 * k + 2 * j + i];
+                a.cell = row + X.c[i];
+                a.off = dense ? ((Z.o[k] << 4) | (Y.o[j] << 2) | X.o[i]) : ((Z.o[k] << 6) | (Y.o[j] << 3) | X.o[i]);
+                a.in = true;
+                io.in_mask |= (X.in[i] & Y.in[j] & Z.in[k]) ? 1u << (4 * k + 2 * j + i) : 0u;
             }
-    } else {
-        const AxisCells X = axis_cells(ix, x1, (uint32_t)g.nb[0] << 3, 3u), Y = axis_cells(iy, y1, (uint32_t)g.nb[1] << 3, 3u), Z = axis_cells(iz, z1, (uint32_t)g.nb[2] << 3, 3u);
+        }
+}
+template <int DENSE = 2>
+VR_HD void trilinear_load(const GridView& g, TriIO& io) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+    for (int n = 0; n < 8; ++n) io.d[n] = tap_load<DENSE>(g, io.a[n]);
+}
+VR_HD void trilinear_idle(TriIO& io) {           // addresses of a lane without a lookup: cell 0
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t row = ((Z.c[k] << g.bshift[1]) + Y.c[j]) << g.bshift[0];
+    for (int n = 0; n < 8; ++n) { io.a[n].cell = 0u; io.a[n].off = 0u; io.a[n].in = false; }
+    io.fx = io.fy = io.fz = 0.0f; io.in_mask = 0u;
+}
+template <int DENSE = 2>
+VR_HD float trilinear_value(const GridView& g, const TriIO& io) {
+    float v[8];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const BrickRec rec = g.bricks[row + X.c[i]];
-                    const uint32_t b = g.atlas[(size_t)rec.slot * 512u + ((Z.o[k] << 6) | (Y.o[j] << 3) | X.o[i])];
-                    const float val = rec.rmin + unorm8(b) * rec.rdiff;
-                    v[k][j][i] = (X.in[i] & Y.in[j] & Z.in[k]) ? val : 0.0f;
-                }
-            }
-    }
-    const float lx0 = mix_(v[0][0][0], v[0][0][1], fx);
-    const float lx1 = mix_(v[0][1][0], v[0][1][1], fx);
-    const float hx0 = mix_(v[1][0][0], v[1][0][1], fx);
-    const float hx1 = mix_(v[1][1][0], v[1][1][1], fx);
-    return mix_(mix_(lx0, lx1, fy), mix_(hx0, hx1, fy), fz);
+    for (int n = 0; n < 8; ++n) v[n] = tap_value<DENSE>(g, io.d[n], (io.in_mask >> n) & 1u);
+    const float lx0 = mix_(v[0], v[1], io.fx);
+    const float lx1 = mix_(v[2], v[3], io.fx);
+    const float hx0 = mix_(v[4], v[5], io.fx);
+    const float hx1 = mix_(v[6], v[7], io.fx);
+    return mix_(mix_(lx0, lx1, io.fy), mix_(hx0, hx1, io.fy), io.fz);
+}
+template <int DENSE = 2>
+VR_HD float density_trilinear_raw(const GridView& g, v3 ipos) {
+    TriIO io;
+    trilinear_prep<DENSE>(g, ipos, io);
+    trilinear_load<DENSE>(g, io);
+    return trilinear_value<DENSE>(g, io);
 }
 
 // stochastic tricubic tap (common.glsl:221-244): 9 draws in the order tap2.xyz, tap3.xyz, tap4.xyz;
@@ -511,7 +565,53 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
     begin_segment<K>(h, P, pos, dir, 0);
 }
 
-// loop body of both DDA trackers up to the collision test (common.glsl:422-435, 469-482)
+// Loop body of both DDA trackers up to the collision test (common.glsl:422-435, 469-482), TWO iterations at a time and in
+// two phases.  march_prep does everything that needs no memory -- positions, DDA levels, step lengths of this iteration AND
+// of the next one, taken as if this one neither collides nor leaves the box (step lengths do not depend on the majorant) --
+// and loads both majorants; march_finish replays the reference's loop on those values.  A second step that the first one
+// cancels costs one unused load; the arithmetic of a step that does run is the reference's, operation for operation.
+struct MarchIO { float dt1, dt2, t1, maj1, maj2; int32_t i1, i2; bool go1, go2; };     // i*: majorant cell or -1 (outside: majorant 0); maj*: as loaded
+VR_HD void march_idle(MarchIO& io) { io.i1 = io.i2 = -1; io.dt1 = io.dt2 = io.t1 = 0.0f; io.go1 = io.go2 = false; }      // a lane that is not marching
+VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
+    io.go1 = h.t < h.far;
+    const v3 c1 = axpy(h.ipos, h.t, h.idir);
+    const int32_t m1 = round_mip_q(h.mipq);
+    io.i1 = majorant_index(P.density, c1, m1);
+    io.dt1 = step_dda(c1, h.ri, m1);
+    io.t1 = h.t + io.dt1;
+    const int32_t q2 = h.mipq < 12 ? h.mipq + 1 : 12;              // mip = min(mip + 0.25, 3)
+    const int32_t m2 = round_mip_q(q2);
+    io.go2 = io.t1 < h.far;
+    const v3 c2 = axpy(h.ipos, io.t1, h.idir);
+    io.i2 = majorant_index(P.density, c2, m2);
+    io.dt2 = step_dda(c2, h.ri, m2);
+}
+// the loads: unconditional and for every lane of the wavefront (an idle lane reads cell 0), so that they sit in straight-line
+// code and the compiler's wait counts are exact
+VR_HD void march_load(const SceneParams& P, MarchIO& io) {
+    io.maj1 = majorant_fetch(P.density, io.i1);
+    io.maj2 = majorant_fetch(P.density, io.i2);
+}
+VR_HD void march_finish(Hot& h, const MarchIO& io) {
+    if (!io.go1) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    float t = io.t1, maj = io.i1 >= 0 ? io.maj1 : 0.0f;
+    float tau = h.tau - maj * io.dt1;
+    int32_t q = h.mipq < 12 ? h.mipq + 1 : 12;
+    if (tau > 0.0f) {                                              // no tentative collision in the first cell: second step
+        if (!io.go2) { h.t = t; h.tau = tau; h.mipq = q; h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+        maj = io.i2 >= 0 ? io.maj2 : 0.0f;
+        t = io.t1 + io.dt2;
+        tau = tau - maj * io.dt2;
+        q = q < 12 ? q + 1 : 12;
+        if (tau > 0.0f) { h.t = t; h.tau = tau; h.mipq = q; return; }
+    }
+    t += tau / maj;
+    h.t = t; h.tau = tau; h.mipq = q;
+    if (t >= h.far) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    h.majorant = maj;
+    h.state = ST_COLLIDE;
+}
+// one iteration (sequential form; the scheduler uses the two-phase form above)
 VR_HD void do_march(Hot& h, const SceneParams& P) {
     if (!(h.t < h.far)) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
     const v3 curr = axpy(h.ipos, h.t, h.idir);
@@ -528,42 +628,88 @@ VR_HD void do_march(Hot& h, const SceneParams& P) {
     h.state = ST_COLLIDE;
 }
 
-// tentative collision (common.glsl:436-452, 483-498)
-template <class K, class Cold>
-VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
-    constexpr bool USE_TF = K::tf;
-    const Uniforms& u = P.u;
+// Tentative collision (common.glsl:436-452, 483-498; global-majorant trackers :342-359, 372-392), in two phases like the
+// march: collide_prep draws the filter taps (the RNG draws of lookup_density / lookup_emission, in the reference's order),
+// computes the voxel addresses and issues the loads; collide_finish evaluates density (and emission), makes the real / null
+// decision and draws the next free-flight distance.
+template <class K> struct CollideIO {
+    TapAddr a; TapData d;        // no transfer function: the one stochastic-tricubic tap
+    TriIO tri;                   // transfer function: the 8 trilinear corners
+    TapAddr ea; TapData ed;      // emission tap (camera/scatter segments with an emission grid)
+};
+template <class K>
+VR_HD void collide_prep(Hot& h, const SceneParams& P, CollideIO<K>& io) {
     const v3 ip = axpy(h.ipos, h.t, h.idir);
-    float d;
-    float rgba[4] = { 0, 0, 0, 0 };
-    if (USE_TF) {
-        tf_lookup(P, (u.vol_density_scale * density_trilinear_raw<K::dense>(P.density, ip)) * u.vol_inv_majorant, rgba);
-        d = u.vol_majorant * rgba[3];
+    if (K::tf) {
+        trilinear_prep<K::dense>(P.density, ip, io.tri);
     } else {
         int32_t tx, ty, tz;
         tricubic_tap(ip, h.seed, tx, ty, tz);
-        d = u.vol_density_scale * brick_value<K::dense>(P.density, tx, ty, tz);
+        io.a = tap_addr<K::dense>(P.density, tx, ty, tz);
     }
+    io.ea.cell = io.ea.off = 0u; io.ea.in = false;
     if (!h.shadow) {
-        // Le += throughput * (1 - albedo) * lookup_emission(...) * d * vol_inv_majorant  (9 draws, always)
-        if (K::emission == 2 ? u.has_emission != 0 : K::emission == 1) {
+        // lookup_emission's filter draws its 9 numbers whether or not an emission grid is bound
+        if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) {
             const v3 ie = mat4_point(P.emission_from_density, ip);
             int32_t ex, ey, ez;
             tricubic_tap(ie, h.seed, ex, ey, ez);
-            const float tt = brick_value(P.emission, ex, ey, ez) * u.vol_emission_norm;
-            const v3 e3 = v3{ tt, sqr(tt), sqr(sqr(tt)) };
-            const v3 em = v3{ u.vol_emission_scale * sqr(e3.x), u.vol_emission_scale * sqr(e3.y), u.vol_emission_scale * sqr(e3.z) };
-            const v3 oma = v3{ 1.0f - u.vol_albedo[0], 1.0f - u.vol_albedo[1], 1.0f - u.vol_albedo[2] };
-            st3(c, C_L, ld3(c, C_L) + (((ld3(c, C_THR) * oma) * em) * d) * u.vol_inv_majorant);
+            io.ea = tap_addr<2>(P.emission, ex, ey, ez);
         } else {
             rng_skip9(h.seed);
         }
-        if (rng(h.seed) * h.majorant < d) {
-            v3 thr = ld3(c, C_THR) * v3{ u.vol_albedo[0], u.vol_albedo[1], u.vol_albedo[2] };
-            if (USE_TF) thr = thr * v3{ rgba[0], rgba[1], rgba[2] };
-            st3(c, C_THR, thr);
+    }
+}
+template <class K>
+VR_HD void collide_idle(CollideIO<K>& io) {      // a lane that is not colliding: its loads read cell 0
+    io.a.cell = io.a.off = 0u; io.a.in = false;
+    io.ea.cell = io.ea.off = 0u; io.ea.in = false;
+    if (K::tf) trilinear_idle(io.tri);
+}
+template <class K>
+VR_HD void collide_load(const SceneParams& P, CollideIO<K>& io) {      // unconditional, like march_load
+    if (K::tf) trilinear_load<K::dense>(P.density, io.tri);
+    else io.d = tap_load<K::dense>(P.density, io.a);
+    if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) io.ed = tap_load<2>(P.emission, io.ea);
+}
+template <class K, class Cold>
+VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO<K>& io) {
+    constexpr bool USE_TF = K::tf;
+    const Uniforms& u = P.u;
+    const bool global = K::global == 2 ? u.integrator != 0 : K::global == 1;
+    float d;
+    float rgba[4] = { 0, 0, 0, 0 };
+    if (USE_TF) {
+        tf_lookup(P, (u.vol_density_scale * trilinear_value<K::dense>(P.density, io.tri)) * u.vol_inv_majorant, rgba);
+        d = u.vol_majorant * rgba[3];
+    } else {
+        d = u.vol_density_scale * tap_value<K::dense>(P.density, io.d, io.a.in);
+    }
+    if (!h.shadow) {
+        const float P_real = d * u.vol_inv_majorant;                 // global trackers only
+        if (K::emission == 2 ? u.has_emission != 0 : K::emission == 1) {
+            // Le += throughput * (1 - albedo) * lookup_emission(...) * d * vol_inv_majorant
+            const float tt = tap_value<2>(P.emission, io.ed, io.ea.in) * u.vol_emission_norm;
+            const v3 e3 = v3{ tt, sqr(tt), sqr(sqr(tt)) };
+            const v3 em = v3{ u.vol_emission_scale * sqr(e3.x), u.vol_emission_scale * sqr(e3.y), u.vol_emission_scale * sqr(e3.z) };
+            const v3 oma = v3{ 1.0f - u.vol_albedo[0], 1.0f - u.vol_albedo[1], 1.0f - u.vol_albedo[2] };
+            const v3 thr = ld3(c, C_THR);
+            if (global) st3(c, C_L, ld3(c, C_L) + ((thr * oma) * em) * P_real);
+            else st3(c, C_L, ld3(c, C_L) + (((thr * oma) * em) * d) * u.vol_inv_majorant);
+        }
+        if (global ? rng(h.seed) < P_real : rng(h.seed) * h.majorant < d) {
+            // real collision.  "throughput *= albedo [* rgba.rgb]" is applied by do_nee (the one event that follows): the
+            // hot pair then never touches the path's cold state; a transfer-function colour travels there in C_SHLE
+            if (USE_TF) st3(c, C_SHLE, v3{ rgba[0], rgba[1], rgba[2] });
             h.state = ST_NEE;
             return;
+        }
+    } else if (global) {
+        h.Tr *= 1.0f - d * u.vol_inv_majorant;
+        if (h.Tr < 0.1f) {
+            const float prob = 1.0f - h.Tr;
+            if (rng(h.seed) < prob) { h.Tr = 0.0f; h.state = ST_POSTNEE; return; }
+            h.Tr /= 1.0f - prob;
         }
     } else {
         if (rng(h.seed) * h.majorant < d) {
@@ -575,60 +721,22 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
             }
         }
     }
+    if (global) {
+        // stays in ST_COLLIDE while the ray is inside the box
+        h.t = h.t + neg_log_1m(rng(h.seed)) * u.vol_inv_majorant;
+        if (!(h.t < h.far)) h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE;
+        return;
+    }
     h.tau = neg_log_1m(rng(h.seed));
     h.mipq = h.mipq > 8 ? h.mipq - 8 : 0;                  // mip = max(0, mip - 2)
     h.state = ST_MARCH;
 }
-
-// tentative collision of the global-majorant trackers (common.glsl:342-359, 372-392): stays in ST_COLLIDE while the
-// ray is inside the box
 template <class K, class Cold>
-VR_HD void do_collide_global(Hot& h, Cold& c, const SceneParams& P) {
-    constexpr bool USE_TF = K::tf;
-    const Uniforms& u = P.u;
-    const v3 ip = axpy(h.ipos, h.t, h.idir);
-    float d;
-    float rgba[4] = { 0, 0, 0, 0 };
-    if (USE_TF) {
-        tf_lookup(P, (u.vol_density_scale * density_trilinear_raw<K::dense>(P.density, ip)) * u.vol_inv_majorant, rgba);
-        d = u.vol_majorant * rgba[3];
-    } else {
-        int32_t tx, ty, tz;
-        tricubic_tap(ip, h.seed, tx, ty, tz);
-        d = u.vol_density_scale * brick_value<K::dense>(P.density, tx, ty, tz);
-    }
-    if (!h.shadow) {
-        const float P_real = d * u.vol_inv_majorant;
-        if (K::emission == 2 ? u.has_emission != 0 : K::emission == 1) {
-            const v3 ie = mat4_point(P.emission_from_density, ip);
-            int32_t ex, ey, ez;
-            tricubic_tap(ie, h.seed, ex, ey, ez);
-            const float tt = brick_value(P.emission, ex, ey, ez) * u.vol_emission_norm;
-            const v3 e3 = v3{ tt, sqr(tt), sqr(sqr(tt)) };
-            const v3 em = v3{ u.vol_emission_scale * sqr(e3.x), u.vol_emission_scale * sqr(e3.y), u.vol_emission_scale * sqr(e3.z) };
-            const v3 oma = v3{ 1.0f - u.vol_albedo[0], 1.0f - u.vol_albedo[1], 1.0f - u.vol_albedo[2] };
-            st3(c, C_L, ld3(c, C_L) + ((ld3(c, C_THR) * oma) * em) * P_real);
-        } else {
-            rng_skip9(h.seed);
-        }
-        if (rng(h.seed) < P_real) {
-            v3 thr = ld3(c, C_THR);
-            if (USE_TF) thr = thr * v3{ rgba[0] * u.vol_albedo[0], rgba[1] * u.vol_albedo[1], rgba[2] * u.vol_albedo[2] };
-            else thr = thr * v3{ u.vol_albedo[0], u.vol_albedo[1], u.vol_albedo[2] };
-            st3(c, C_THR, thr);
-            h.state = ST_NEE;
-            return;
-        }
-    } else {
-        h.Tr *= 1.0f - d * u.vol_inv_majorant;
-        if (h.Tr < 0.1f) {
-            const float prob = 1.0f - h.Tr;
-            if (rng(h.seed) < prob) { h.Tr = 0.0f; h.state = ST_POSTNEE; return; }
-            h.Tr /= 1.0f - prob;
-        }
-    }
-    h.t = h.t + neg_log_1m(rng(h.seed)) * u.vol_inv_majorant;
-    if (!(h.t < h.far)) h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE;
+VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
+    CollideIO<K> io;
+    collide_prep<K>(h, P, io);
+    collide_load<K>(P, io);
+    collide_finish<K>(h, c, P, io);
 }
 
 // real collision: common.glsl:611-626 up to (and including the set-up of) the transmittance call
@@ -637,6 +745,14 @@ VR_HD void do_nee(Hot& h, Cold& c, const SceneParams& P) {
     const v3 dir = ld3(c, C_DIR);
     const v3 pos = axpy(ld3(c, C_POS), h.t, dir);
     st3(c, C_POS, pos);
+    // the real collision that led here: throughput *= albedo [* rgba.rgb] (common.glsl:383-388, 491-495; see collide_finish)
+    {
+        const v3 alb = v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };
+        v3 thr = ld3(c, C_THR);
+        if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) thr = K::tf ? thr * (ld3(c, C_SHLE) * alb) : thr * alb;
+        else { thr = thr * alb; if (K::tf) thr = thr * ld3(c, C_SHLE); }
+        st3(c, C_THR, thr);
+    }
     const float r0 = rng(h.seed), r1 = rng(h.seed);
     float pdf;
     v3 w_i, Le;
@@ -750,8 +866,8 @@ VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, 
         if (next_item >= (uint32_t)wu.n_items) { h.state = ST_DONE; break; }
         do_new<K>(h, c, P, wu, next_item++);
         break;
-    case ST_MARCH: do_march(h, P); break;
-    case ST_COLLIDE: if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) do_collide_global<K>(h, c, P); else do_collide<K>(h, c, P); break;
+    case ST_MARCH: { MarchIO io; march_prep(h, P, io); march_load(P, io); march_finish(h, io); break; }     // two DDA steps, as on the device
+    case ST_COLLIDE: do_collide<K>(h, c, P); break;
     case ST_NEE: do_nee<K>(h, c, P); break;
     case ST_POSTNEE: do_postnee<K>(h, c, P, wu); break;
     case ST_ESCAPE: do_escape(h, c, P, wu); break;
