@@ -10,7 +10,9 @@ HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 OBJDIR   := build
 SRCS_CPP := grids.cpp imageio.cpp environment.cpp transferfunc.cpp renderer.cpp capi.cpp
 PT_VARIANTS := 0 1 2 3
-OBJS     := $(OBJDIR)/vr_kernels.o $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_%.o) $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
+OBJS     := $(OBJDIR)/vr_kernels.o $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_%.o) $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_fast_%.o) $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
+# tolerance-mode kernels (opt-in, vr_math.h VR_FAST_MATH): hardware transcendentals, reciprocal division, contraction allowed
+FASTFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result -Iinclude -DVR_FAST_MATH=1
 HDRS     := $(wildcard $(CSRC)/*.h) include/volren_amd.h
 
 all: volren_amd/libvolren_amd.so volren_amd/volren oracle
@@ -23,6 +25,10 @@ $(OBJDIR)/vr_kernels.o: $(CSRC)/vr_kernels.hip $(HDRS)
 $(OBJDIR)/vr_pathtrace_%.o: $(CSRC)/vr_pathtrace.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_pathtrace_$*.resources.txt || (cat $(OBJDIR)/vr_pathtrace_$*.resources.txt; false)
+
+$(OBJDIR)/vr_pathtrace_fast_%.o: $(CSRC)/vr_pathtrace.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FASTFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_pathtrace_fast_$*.resources.txt || (cat $(OBJDIR)/vr_pathtrace_fast_$*.resources.txt; false)
 
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)

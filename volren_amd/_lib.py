@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvolren_amd.so")
+LIB_PATH = os.environ.get("VOLREN_AMD_LIB") or os.path.join(_HERE, "libvolren_amd.so")      # override: tuning builds (tests/tools_build_variant.sh)
 
 # every symbol include/volren_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

@@ -8,6 +8,7 @@
 #include <iostream>
 
 #include "vr_device.h"
+#include "vr_math.h"
 
 namespace vr {
 
@@ -228,6 +229,16 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
     }
     out.bricks = make_device_buffer(recs.size() * sizeof(BrickRec));
     out.bricks->upload(recs.data(), recs.size() * sizeof(BrickRec));
+#if defined(VR_ATLAS_F32) && VR_ATLAS_F32
+    {   // experiment: decoded float voxels (rmin + unorm8(b) * rdiff, the decode of common.glsl:268-275 done once)
+        std::vector<float> decoded(atlas.size());
+        for (size_t i = 0; i < recs.size(); ++i)
+            for (size_t v = 0; v < 512; ++v) decoded[i * 512 + v] = recs[i].rmin + unorm8(atlas[i * 512 + v]) * recs[i].rdiff;
+        out.atlas = make_device_buffer(decoded.size() * sizeof(float));
+        out.atlas->upload(decoded.data(), decoded.size() * sizeof(float));
+        return out;
+    }
+#endif
     out.atlas = make_device_buffer(atlas.size());
     out.atlas->upload(atlas.data(), atlas.size());
     return out;
@@ -404,7 +415,7 @@ void RendererHIP::launch(int n) {
     for (int done = 0; done < n; done += per_launch) {
         ++last_launches;
         const int m = std::min(per_launch, n - done);
-        launch_pathtrace(P, color->as<float>(), pool_->as<float>(), workspace_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, sample + 1 + done, m, status_->as<uint32_t>(), stream);
+        launch_pathtrace(P, color->as<float>(), pool_->as<float>(), workspace_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, sample + 1 + done, m, status_->as<uint32_t>(), stream, fast_math);
         VR_HIP(hipGetLastError());
     }
     VR_HIP(hipEventRecord(ev1_, stream));

@@ -108,6 +108,8 @@ struct RendererHIP {
     ivec2 resolution{ 0, 0 };
     hipStream_t stream = nullptr;
     int integrator = 0;                               // 0: DDA tracking (both reference kernels)
+    bool fast_math = false;                           // opt-in tolerance mode: hardware log/sin/cos/rcp instead of the specified arithmetic
+                                                      // (within 1e-3 relative L2 of the default, not bit-reproducible)
     int last_launches = 0;                            // path-tracing sub-launches of the last trace()/render()
     size_t sample_pool_bytes = (size_t)16 << 30;      // HBM budget of the per-sample radiance pool (16 B per pixel-sample; sized for 288 GB HBM3E, allocated on demand)
 

@@ -16,7 +16,9 @@ namespace vr {
 size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples);
 size_t pathtrace_workspace_floats();      // cold path state of all resident wavefronts
 void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
-                      int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream);
+                      int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math = false);
+// fast_math: the opt-in tolerance-mode kernels (hardware transcendentals, reciprocal division; vr_math.h VR_FAST_MATH); the default
+// kernels are bit-identical to the CPU oracle
 
 // env_setup.glsl:18-34 + glGenerateMipmap (environment.cpp:27-31): importance pyramid of a dim x dim map
 void launch_build_impmap(const float* envmap_rgba, int32_t env_w, int32_t env_h, int32_t dim, float* pyramid, hipStream_t stream);

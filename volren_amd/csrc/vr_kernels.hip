@@ -91,17 +91,20 @@ size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples) {
     return (size_t)chunks * (size_t)n_tiles * 4u * (size_t)spu * 64u * 4u;
 }
 
-// the kernel variants live in vr_pathtrace.hip, one compilation each
+// the kernel variants live in vr_pathtrace.hip, one compilation each, in two arithmetic modes (bit-exact / tolerance)
+extern "C" {
 #define VR_PT_DECL(N) \
-    int pt_occupancy_variant_##N(bool tf, bool stats); \
-    void pt_launch_variant_##N(bool tf, bool stats, unsigned grid, hipStream_t stream, const SceneParams& P, float* sbuf, float* cold_ws, \
-                               const LaunchDesc& D, const SchedParams& S, uint32_t* status, unsigned long long* stats_buf);
-VR_PT_DECL(0) VR_PT_DECL(1) VR_PT_DECL(2) VR_PT_DECL(3)
+    int vr_pt_occupancy_##N(int tf, int stats); \
+    void vr_pt_launch_##N(int tf, int stats, unsigned grid, hipStream_t stream, const void* P, float* sbuf, float* cold_ws, const void* D, const void* S, uint32_t* status, unsigned long long* stats_buf);
+VR_PT_DECL(0) VR_PT_DECL(1) VR_PT_DECL(2) VR_PT_DECL(3) VR_PT_DECL(0_fast) VR_PT_DECL(1_fast) VR_PT_DECL(2_fast) VR_PT_DECL(3_fast)
 #undef VR_PT_DECL
-typedef int (*PtOccupancy)(bool, bool);
-typedef void (*PtLaunch)(bool, bool, unsigned, hipStream_t, const SceneParams&, float*, float*, const LaunchDesc&, const SchedParams&, uint32_t*, unsigned long long*);
-static const PtOccupancy kPtOccupancy[4] = { pt_occupancy_variant_0, pt_occupancy_variant_1, pt_occupancy_variant_2, pt_occupancy_variant_3 };
-static const PtLaunch kPtLaunch[4] = { pt_launch_variant_0, pt_launch_variant_1, pt_launch_variant_2, pt_launch_variant_3 };
+}
+typedef int (*PtOccupancy)(int, int);
+typedef void (*PtLaunch)(int, int, unsigned, hipStream_t, const void*, float*, float*, const void*, const void*, uint32_t*, unsigned long long*);
+static const PtOccupancy kPtOccupancy[2][4] = { { vr_pt_occupancy_0, vr_pt_occupancy_1, vr_pt_occupancy_2, vr_pt_occupancy_3 },
+                                                { vr_pt_occupancy_0_fast, vr_pt_occupancy_1_fast, vr_pt_occupancy_2_fast, vr_pt_occupancy_3_fast } };
+static const PtLaunch kPtLaunch[2][4] = { { vr_pt_launch_0, vr_pt_launch_1, vr_pt_launch_2, vr_pt_launch_3 },
+                                          { vr_pt_launch_0_fast, vr_pt_launch_1_fast, vr_pt_launch_2_fast, vr_pt_launch_3_fast } };
 
 // which compiled variant serves a scene (see vr_pathtrace.hip)
 static int pathtrace_variant(const SceneParams& P) {
@@ -111,18 +114,18 @@ static int pathtrace_variant(const SceneParams& P) {
 }
 
 constexpr int kMaxWorkgroups = 2048;                // the cold-state workspace is sized for this many resident workgroups
-static int resident_blocks(int variant, bool tf, bool stats) {
+static int resident_blocks(int mode, int variant, bool tf, bool stats) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    per_cu = g_blocks_per_cu > 0 ? g_blocks_per_cu : kPtOccupancy[variant](tf, stats);
+    per_cu = g_blocks_per_cu > 0 ? g_blocks_per_cu : kPtOccupancy[mode][variant](tf, stats);
     return std::min(cus * per_cu, kMaxWorkgroups);
 }
 
-size_t pathtrace_workspace_floats() { return (size_t)kMaxWorkgroups * 4u * C_STRIDE * NSLOT; }      // cold state of 4 wavefronts per resident workgroup
+size_t pathtrace_workspace_floats() { return (size_t)kMaxWorkgroups * 4u * kColdWaveFloats; }      // cold state of 4 wavefronts per resident workgroup
 
 void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
-                      int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream) {
+                      int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math) {
     if (n_tiles <= 0 || n_samples <= 0) return;
     tuning_from_env();
     SchedParams S = g_sched;
@@ -137,9 +140,10 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     S.max_iters = kMaxIters;
     const int variant = pathtrace_variant(P);
     const bool tf = P.u.use_tf != 0, stats = g_stats != nullptr;
-    static int blocks_cache[4][4] = {};
-    int& blocks = blocks_cache[variant][(tf ? 2 : 0) + (stats ? 1 : 0)];
-    if (blocks == 0 || g_blocks_per_cu > 0) blocks = resident_blocks(variant, tf, stats);
+    const int mode = fast_math ? 1 : 0;
+    static int blocks_cache[2][4][4] = {};
+    int& blocks = blocks_cache[mode][variant][(tf ? 2 : 0) + (stats ? 1 : 0)];
+    if (blocks == 0 || g_blocks_per_cu > 0) blocks = resident_blocks(mode, variant, tf, stats);
     const uint32_t waves_needed = (D.n_units + 3u) / 4u;
     const dim3 grid((unsigned)std::min<uint32_t>((uint32_t)blocks, waves_needed > 0 ? waves_needed : 1u)), block(256);
     if (P.u.integrator == 2 && P.u.use_tf) {
@@ -147,7 +151,7 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
         hipLaunchKernelGGL(dvr_kernel, dim3((unsigned)((items + 255) / 256)), block, 0, stream, P, sample_pool, D);
     } else {
         (void)hipMemsetAsync(unit_counter, 0, kQueueSegments * sizeof(uint32_t), stream);
-        kPtLaunch[variant](tf, stats, grid.x, stream, P, sample_pool, workspace, D, S, status, g_stats);
+        kPtLaunch[mode][variant](tf, stats, grid.x, stream, &P, sample_pool, workspace, &D, &S, status, g_stats);
     }
     hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)n_tiles), block, 0, stream, sample_pool, fb, tiles, n_tiles,
                        P.u.resolution[0], P.u.resolution[1], first_sample, n_samples, D.spu);

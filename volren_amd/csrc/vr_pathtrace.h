@@ -55,6 +55,9 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #ifndef VR_WAVES_PER_SIMD
 #define VR_WAVES_PER_SIMD 4
 #endif
+#ifndef VR_MARCH_SPECULATIVE
+#define VR_MARCH_SPECULATIVE 1
+#endif
 #ifndef VR_BATCH_REGS
 #define VR_BATCH_REGS 1
 #endif
@@ -110,11 +113,37 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         h.majorant = 0.0f;
     }
 };
-struct ColdGlobal {                    // one 128-byte line per path slot in this wavefront's slice of the workspace
-    float* base;
-    __device__ __forceinline__ float ld(int32_t f) const { return static_cast<const float*>(__builtin_assume_aligned(base, 128))[f]; }
-    __device__ __forceinline__ void st(int32_t f, float v) { static_cast<float*>(__builtin_assume_aligned(base, 128))[f] = v; }
+// Cold path state of one wavefront in global memory, group-major: the six 16-byte field groups (vr_trace.h ColdField) are six
+// arrays of NSLOT entries, [group][slot][4].  An event reads or writes a few groups for up to 64 arbitrary slots: with this
+// layout one such access touches the <= 19 cache lines that hold a group's 152 entries, instead of 64 lines (one per slot) in
+// a slot-major layout -- the kernel is bound by L1 (TCP) accesses, profiles/r2i_pmc_c2_tcp.txt -- and successive groups go
+// to different lines, so their misses overlap instead of queueing on one pending line.
+#ifndef VR_COLD_SOA
+#define VR_COLD_SOA 1
+#endif
+constexpr int32_t kColdGroups = C_COUNT / 4;          // 6
+struct ColdGlobal {
+    float* base;                       // the wavefront's slice + this slot's offset inside a group
+    __device__ __forceinline__ float ld(int32_t f) const {
+#if VR_COLD_SOA
+        return static_cast<const float*>(__builtin_assume_aligned(base, 16))[(f >> 2) * (NSLOT * 4) + (f & 3)];
+#else
+        return static_cast<const float*>(__builtin_assume_aligned(base, 128))[f];
+#endif
+    }
+    __device__ __forceinline__ void st(int32_t f, float v) {
+#if VR_COLD_SOA
+        static_cast<float*>(__builtin_assume_aligned(base, 16))[(f >> 2) * (NSLOT * 4) + (f & 3)] = v;
+#else
+        static_cast<float*>(__builtin_assume_aligned(base, 128))[f] = v;
+#endif
+    }
 };
+#if VR_COLD_SOA
+constexpr int32_t kColdWaveFloats = kColdGroups * NSLOT * 4, kColdSlotStride = 4;
+#else
+constexpr int32_t kColdWaveFloats = C_STRIDE * NSLOT, kColdSlotStride = C_STRIDE;
+#endif
 
 __device__ __forceinline__ int32_t popc(uint64_t mask) { return (int32_t)__popcll(mask); }     // int: min(long long, int) would go through double
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
@@ -152,7 +181,7 @@ pathtrace_kernel(const KernelArgs A) {
     __shared__ uint8_t lds_q[4 * Q_COUNT * NSLOT];
     uint8_t* const q = lds_q + wave * (Q_COUNT * NSLOT);
     // per-wavefront slice of the workspace: the cold fields of its NSLOT paths
-    float* const cold_base = A.cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)(C_STRIDE * NSLOT);
+    float* const cold_base = A.cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)kColdWaveFloats;
     __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NSLOT];
     const HotStore hs{ lds_hot + wave * (HOT_STRIDE * NSLOT) };
 
@@ -248,11 +277,16 @@ pathtrace_kernel(const KernelArgs A) {
         {
             if (STATS) t_blk = __builtin_readcyclecounter();
             const bool is_m = slot >= 0 && l.state == ST_MARCH;
+#if VR_MARCH_SPECULATIVE
             MarchIO mio;
             march_idle(mio);
             if (is_m) march_prep(l, P, mio);
             march_load(P, mio);
             if (is_m) march_finish(l, mio);
+#else
+            for (int32_t k = 0; k < 2; ++k)            // diagnostic: two plain steps, one majorant load each, only where a step runs
+                if (slot >= 0 && l.state == ST_MARCH) do_march(l, P);
+#endif
             if (STATS) { const int32_t nm = popc(__ballot(is_m)); if (nm) { st_exec[ST_MARCH] += 1u; st_lanes[ST_MARCH] += (uint32_t)nm; } const unsigned long long t_now = __builtin_readcyclecounter(); st_cyc[ST_MARCH] += t_now - t_blk; t_blk = t_now; }
             const bool is_c = slot >= 0 && l.state == ST_COLLIDE;
             CollideIO<K> cio;
@@ -260,7 +294,7 @@ pathtrace_kernel(const KernelArgs A) {
             if (is_c) collide_prep<K>(l, P, cio);
             collide_load<K>(P, cio);
             if (is_c) {
-                ColdGlobal c{ cold_base + slot * C_STRIDE };
+                ColdGlobal c{ cold_base + slot * kColdSlotStride };
                 collide_finish<K>(l, c, P, cio);
             }
             // every load of the pass has been consumed or belongs to a lane that left early: say so, or the compiler carries
@@ -313,7 +347,7 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_ESC * NSLOT + cnt_esc - 1 - lane];
                     hs.load(b, bs);
-                    ColdGlobal c{ cold_base + bs * C_STRIDE };
+                    ColdGlobal c{ cold_base + bs * kColdSlotStride };
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
                     do_escape(b, c, E.P, w);                              // writes the sample; the slot becomes free
@@ -329,7 +363,7 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_POST * NSLOT + cnt_post - 1 - lane];
                     hs.load(b, bs);
-                    ColdGlobal c{ cold_base + bs * C_STRIDE };
+                    ColdGlobal c{ cold_base + bs * kColdSlotStride };
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
                     do_postnee<K>(b, c, E.P, w);
@@ -361,7 +395,7 @@ pathtrace_kernel(const KernelArgs A) {
                     if (lane < n) {
                         bs = q[Q_FREE * NSLOT + cnt_free - 1 - lane];
                         hot_init(b);
-                        ColdGlobal c{ cold_base + bs * C_STRIDE };
+                        ColdGlobal c{ cold_base + bs * kColdSlotStride };
                         do_new<K>(b, c, event_args().P, wu, cursor + (uint32_t)lane);
                         hs.save(b, bs);
                     }
@@ -378,7 +412,7 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_NEE * NSLOT + cnt_nee - 1 - lane];
                     hs.load(b, bs);
-                    ColdGlobal c{ cold_base + bs * C_STRIDE };
+                    ColdGlobal c{ cold_base + bs * kColdSlotStride };
                     do_nee<K>(b, c, event_args().P);
                     hs.save(b, bs);
                 }

@@ -4,12 +4,23 @@
 //   1  DDA trackers, dense fp16 density grid, no emission grid (c4)
 //   2  DDA trackers, emission grid bound                       (c5; density bricks or dense, decided at run time)
 //   3  global-majorant trackers (common.glsl:333-394, the code the reference compiles out with USE_DDA); everything else at run time
-// Each exports pt_variant_<n>: launch + resident-block query for {no TF, TF} x {plain, STATS}.
-#include "vr_pathtrace.h"
+// Each is built twice: bit-exact arithmetic (the default and the parity target) and, with -DVR_FAST_MATH=1, the opt-in
+// tolerance mode (hardware transcendentals, reciprocal division, contraction; vr_math.h).  A compilation exports two C symbols,
+// vr_pt_occupancy_<variant>[_fast] and vr_pt_launch_<variant>[_fast], for {no TF, TF} x {plain, STATS}.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #ifndef VR_PT_VARIANT
 #error "compile with -DVR_PT_VARIANT=0..3"
 #endif
+#ifdef VR_FAST_MATH
+#define vr vr_fastmath            // the inline lane code differs from the exact build's: keep the two apart for the linker
+#define VR_PT_SUFFIX _fast
+#else
+#define VR_PT_SUFFIX
+#endif
+
+#include "vr_pathtrace.h"
 
 namespace vr {
 
@@ -23,25 +34,29 @@ template <bool TF> using Cfg = TraceCfg<TF, 0, 1, 2>;
 template <bool TF> using Cfg = TraceCfg<TF, 1, 2, 2>;
 #endif
 
-#define VR_PT_CAT2(a, b) a##b
-#define VR_PT_CAT(a, b) VR_PT_CAT2(a, b)
-
 typedef void (*PtKernel)(const KernelArgs);
 static PtKernel pick(bool tf, bool stats) {
     return tf ? (stats ? pathtrace_kernel<Cfg<true>, true> : pathtrace_kernel<Cfg<true>, false>)
               : (stats ? pathtrace_kernel<Cfg<false>, true> : pathtrace_kernel<Cfg<false>, false>);
 }
 
-int VR_PT_CAT(pt_occupancy_variant_, VR_PT_VARIANT)(bool tf, bool stats) {
+}  // namespace vr
+
+#define VR_PT_CAT3(a, b, c) a##b##c
+#define VR_PT_CAT(a, b, c) VR_PT_CAT3(a, b, c)
+
+extern "C" int VR_PT_CAT(vr_pt_occupancy_, VR_PT_VARIANT, VR_PT_SUFFIX)(int tf, int stats) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick(tf, stats), 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vr::pick(tf != 0, stats != 0), 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
     return per_cu;
 }
-void VR_PT_CAT(pt_launch_variant_, VR_PT_VARIANT)(bool tf, bool stats, unsigned grid, hipStream_t stream, const SceneParams& P, float* sbuf, float* cold_ws,
-                                                   const LaunchDesc& D, const SchedParams& S, uint32_t* status, unsigned long long* stats_buf) {
-    KernelArgs A;
-    A.P = P; A.D = D; A.S = S; A.sbuf = sbuf; A.cold_ws = cold_ws; A.status = status; A.stats = stats_buf;
-    hipLaunchKernelGGL(pick(tf, stats), dim3(grid), dim3(256), 0, stream, A);
+// P, D, S: SceneParams, LaunchDesc, SchedParams (plain data, same layout in both builds)
+extern "C" void VR_PT_CAT(vr_pt_launch_, VR_PT_VARIANT, VR_PT_SUFFIX)(int tf, int stats, unsigned grid, hipStream_t stream, const void* P, float* sbuf, float* cold_ws,
+                                                                       const void* D, const void* S, uint32_t* status, unsigned long long* stats_buf) {
+    vr::KernelArgs A;
+    A.P = *static_cast<const vr::SceneParams*>(P);
+    A.D = *static_cast<const vr::LaunchDesc*>(D);
+    A.S = *static_cast<const vr::SchedParams*>(S);
+    A.sbuf = sbuf; A.cold_ws = cold_ws; A.status = status; A.stats = stats_buf;
+    hipLaunchKernelGGL(vr::pick(tf != 0, stats != 0), dim3(grid), dim3(256), 0, stream, A);
 }
-
-}  // namespace vr

@@ -111,6 +111,9 @@ VR_HD void rng_skip9(uint32_t& s) {
 // (tap_value).  The scheduler (vr_pathtrace.h) runs the first two for all lanes of a pass before anything waits, so that one
 // memory round trip serves the DDA steps and the collisions of the whole wavefront.  The brick atlas is brick-linear
 // (block of brick record i = bytes [512 i, 512 i + 512)): record and voxel are fetched together, no dependent pointer chase.
+#ifndef VR_ATLAS_F32
+#define VR_ATLAS_F32 0
+#endif
 template <int DENSE>
 VR_HD bool grid_is_dense(const GridView& g) { return DENSE == 2 ? g.dense != nullptr : DENSE == 1; }
 struct TapAddr { uint32_t cell, off; bool in; };      // bricks: record index, byte inside the 8^3 block; dense: 4x4x4 block index, voxel inside it
@@ -140,15 +143,24 @@ VR_HD TapData tap_load(const GridView& g, TapAddr a) {
         d.rmin = 0.0f; d.rdiff = 0.0f;
         d.raw = g.dense[(size_t)a.cell * 64u + a.off];
     } else {
+#if VR_ATLAS_F32
+        d.rmin = 0.0f; d.rdiff = 0.0f;       // experiment: decoded voxels, one 4-byte load per tap
+        d.raw = f2u(reinterpret_cast<const float*>(g.atlas)[(size_t)a.cell * 512u + a.off]);
+#else
         const BrickRec* rec = g.bricks + a.cell;
         d.rmin = rec->rmin; d.rdiff = rec->rdiff;
         d.raw = g.atlas[(size_t)a.cell * 512u + a.off];
+#endif
     }
     return d;
 }
 template <int DENSE = 2>
 VR_HD float tap_value(const GridView& g, TapData d, bool in) {
+#if VR_ATLAS_F32
+    const float v = grid_is_dense<DENSE>(g) ? half2float(d.raw) : u2f(d.raw);
+#else
     const float v = grid_is_dense<DENSE>(g) ? half2float(d.raw) : d.rmin + unorm8(d.raw) * d.rdiff;
+#endif
     return in ? v : 0.0f;
 }
 template <int DENSE = 2>
@@ -288,7 +300,23 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
     const AxisWeights ay = tricubic_axis_weights(ipos.y - 0.5f);
     const AxisWeights az = tricubic_axis_weights(ipos.z - 0.5f);
     int32_t jx = 0, jy = 0, jz = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if VR_FAST_DEVICE
+    // tolerance mode: draw j is k_j * 2^-24 and "r_j < w / s" is taken as k_j * s < w * 2^24, unguarded (one rounding apart
+    // from the reference's quotient; a decision flips only when the draw lands within that rounding of the threshold)
+    {
+        const uint32_t lo24 = seed & 0x00FFFFFFu;
+#define VR_TAPF(J, V, W, S, N) do { \
+            constexpr LcgJump g_ = lcg_jump(N); \
+            const float k_ = (float)((mul24(lo24, g_.A & 0x00FFFFFFu) + g_.C) & 0x00FFFFFFu); \
+            J = k_ * (S) < (W) * 16777216.0f ? V : J; \
+        } while (0)
+        VR_TAPF(jx, 1, ax.w2, ax.s2, 1); VR_TAPF(jy, 1, ay.w2, ay.s2, 2); VR_TAPF(jz, 1, az.w2, az.s2, 3);
+        VR_TAPF(jx, 2, ax.w3, ax.s3, 4); VR_TAPF(jy, 2, ay.w3, ay.s3, 5); VR_TAPF(jz, 2, az.w3, az.s3, 6);
+        VR_TAPF(jx, 3, ax.w4, ax.s4, 7); VR_TAPF(jy, 3, ay.w4, ay.s4, 8); VR_TAPF(jz, 3, az.w4, az.s4, 9);
+#undef VR_TAPF
+        rng_skip9(seed);
+    }
+#elif defined(__HIP_DEVICE_COMPILE__)
     // Device fast path, no division and no 32-bit multiply per test.
     //  * draw j is r_j = k_j * 2^-24 with k_j = state_j & 0xFFFFFF, and the low 24 bits of state_j = A_j * seed + C_j only
     //    need the low 24 bits of seed and A_j: one 24-bit multiply-add (full rate) instead of a chained 32-bit multiply;
@@ -315,6 +343,7 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
     if (unsure) {
         seed = seed0; jx = jy = jz = 0;
 #endif
+#if !VR_FAST_DEVICE
         float r;
         r = rng(seed); if (r < ax.w2 / ax.s2) jx = 1;
         r = rng(seed); if (r < ay.w2 / ay.s2) jy = 1;
@@ -327,6 +356,7 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
         r = rng(seed); if (r < az.w4 / az.s4) jz = 3;
 #if defined(__HIP_DEVICE_COMPILE__)
     }
+#endif
 #endif
     tx = nan_guard(voxel_index(ax.fl, jx - 1), ax.fl, ay.fl, az.fl); ty = voxel_index(ay.fl, jy - 1); tz = voxel_index(az.fl, jz - 1);
 }

@@ -7,7 +7,7 @@ import numpy as np
 from . import _lib
 
 _INT_FIELDS = ("sample", "sppx", "seed", "bounces", "show_environment", "tonemapping", "integrator", "grid_frame_counter",
-               "sample_pool_mb", "gpu_encoder")
+               "sample_pool_mb", "gpu_encoder", "fast_math")
 _FLOAT_FIELDS = {"tonemap_exposure": 1, "tonemap_gamma": 1, "albedo": 3, "phase": 1, "density_scale": 1,
                  "emission_scale": 1, "vol_clip_min": 3, "vol_clip_max": 3, "env_strength": 1, "env_transform": 9,
                  "tf_window_left": 1, "tf_window_width": 1, "cam_pos": 3, "cam_dir": 3, "cam_up": 3, "cam_fov": 1,
@@ -63,6 +63,10 @@ class Renderer:
             _lib.check(self._L.vr_set_float(self._h, name.encode(), v.ctypes.data_as(C.POINTER(C.c_float)), v.size))
         else:
             object.__setattr__(self, name, value)
+
+    def has_fast_math(self):
+        """The library carries the opt-in tolerance-mode kernels (`fast_math = 1`); the default kernels are bit-exact."""
+        return True
 
     # ---- scene ----
     def load_volume(self, path):
