@@ -140,6 +140,45 @@ def main():
         same_rng += r; exact += (r and t == b[i, 0]); close += (r and abs(t - b[i, 0]) <= 1e-5 * max(abs(b[i, 0]), 1e-3))
     n = a.shape[0]
     P["transmittanceDDA"] = dict(same_rng_state=same_rng / n, identical=exact / n, within_1e5=close / n)
+    # 4: view_dir (camera ray)
+    a, b = G["probe4_in"], G["probe4_out"]
+    L.orc_view_dir.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    o3 = np.zeros(3, np.float32)
+    e = []
+    for i in range(a.shape[0]):
+        L.orc_view_dir(C.byref(p), int(a[i, 0]), int(a[i, 1]), int(a[i, 2]), int(a[i, 3]), float(a[i, 4]), float(a[i, 5]), o3.ctypes.data)
+        e.append(np.abs(o3 - b[i, :3]).max())
+    P["view_dir_max_abs"] = float(max(e))
+    # 5: intersect_box
+    a, b = G["probe5_in"], G["probe5_out"]
+    L.orc_intersect_box.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    nf = np.zeros(2, np.float32)
+    flag_bad, e = 0, []
+    for i in range(a.shape[0]):
+        pos = np.ascontiguousarray(a[i, :3]); dr = np.ascontiguousarray(a[i, 4:7])
+        hit = L.orc_intersect_box(C.byref(p), pos.ctypes.data, dr.ctypes.data, nf.ctypes.data)
+        flag_bad += int(bool(hit) != bool(b[i, 0] > 0.5))
+        if hit and b[i, 0] > 0.5:
+            e.append(float(np.max(np.abs(nf - b[i, 1:3]) / np.maximum(np.abs(b[i, 1:3]), 1e-3))))
+    P["intersect_box"] = dict(flag_mismatches=flag_bad, near_far_max_rel=float(max(e)), hits=len(e))
+    # 9: sample_volumeDDA (one camera segment) with its RNG stream
+    a, b = G["probe9_in"], G["probe9_out"]
+    L.orc_sample_volume.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    o4 = np.zeros(4, np.float32)
+    same_rng = same_flag = exact = close = 0
+    for i in range(a.shape[0]):
+        sd = C.c_uint32(int(a.view(np.uint32)[i, 3]))
+        pos = np.ascontiguousarray(a[i, :3]); dr = np.ascontiguousarray(a[i, 4:7])
+        real = L.orc_sample_volume(C.byref(p), C.byref(s), pos.ctypes.data, dr.ctypes.data, C.byref(sd), o4.ctypes.data)
+        r = sd.value == b.view(np.uint32)[i, 2]
+        f = bool(real) == bool(b[i, 0] > 0.5)
+        same_rng += r; same_flag += f
+        if r and f:
+            tt = o4[0] == b[i, 1] or not real                    # t is only meaningful after a real collision
+            exact += bool(tt and np.array_equal(o4[1:], b[i, 4:7]))
+            close += bool((not real or abs(o4[0] - b[i, 1]) <= 1e-5 * max(abs(b[i, 1]), 1e-3)) and np.abs(o4[1:] - b[i, 4:7]).max() <= 1e-6)
+    n = a.shape[0]
+    P["sample_volumeDDA"] = dict(same_rng_state=same_rng / n, same_flag=same_flag / n, identical=exact / n, within_1e5=close / n)
     # 7: the driver's built-ins against the specification
     a, b = G["probe7_in"], G["probe7_out"]
     spec = [("log", 0, 0, None, 0), ("sin", 1, 1, None, 1), ("cos", 2, 1, None, 2), ("acos", 4, 2, None, 3), ("atan2", 5, 3, 4, 4), ("exp", 6, 5, None, 5), ("pow", 7, 6, 7, 6)]
@@ -157,6 +196,19 @@ def main():
         L.orc_env_texture(o.env_tex.ctypes.data, o.env_tex.shape[1], o.env_tex.shape[0], float(a[i, 0]), float(a[i, 1]), rgb.ctypes.data)
         e.append(np.abs(rgb - b[i, :3]).max() / max(np.abs(b[i, :3]).max(), 1e-9))
     P["env_texture"] = dict(max_rel=float(max(e)), median_rel=float(np.median(e)))
+    # round-2 goldens: the same images at 1024 spp (north star: 1e-3 relative L2), and the ray-marching trackers (integrator 3)
+    G2 = np.load(os.path.join(HERE, "golden", "glsl_golden_r2.npz"))
+    M2 = json.load(open(os.path.join(HERE, "golden", "glsl_golden_r2.json")))
+    res["r2"] = {}
+    for name, m in M2["images"].items():
+        if m["config"] == "emission":
+            o = emission_scene(W, H)
+        else:
+            o = scenes.oracle_scene(m["config"], W, H)
+            if m["white_env"]:
+                o.set_envmap(np.ones((1, 1, 3), np.float32))
+        o.integrator = m.get("integrator", 0)
+        res["r2"][name] = image_metrics(G2[name], o.render(m["spp"]))
     print(json.dumps(res))
 
 

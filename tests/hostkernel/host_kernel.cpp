@@ -140,6 +140,13 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
         }
         return steps;
     }
+    if (u.integrator == 3) {                   // trace_path with the ray-marching trackers: one call per (pixel, sample)
+        for (int y = y0; y < y1; ++y) for (int x = x0; x < x1; ++x) {
+            float* px = fb + 4 * ((size_t)y * W + x);
+            for (int k = 0; k < n_samples; ++k) { float L[4]; raymarch_path_sample(P, x, y, first_sample + k, L); accumulate_sample(px, L, first_sample + k); ++steps; }
+        }
+        return steps;
+    }
     // wave-sized work units exactly like the HIP kernel: 8x8 tile x chunk of samples -> sample buffer -> running mean
     const int spu = n_samples < 32 ? n_samples : 32;
     std::vector<float> sbuf((size_t)spu * 64 * 4);

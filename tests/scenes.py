@@ -104,6 +104,8 @@ def configure_sparse(r, is_oracle, n=512):
 
 
 def configure(r, name, is_oracle):
+    if name.startswith("c5full"):
+        return configure_sparse_full(r, is_oracle, int(name[7:]) if len(name) > 7 else 1024)
     if name.startswith("c5"):
         return configure_sparse(r, is_oracle, int(name[3:]) if len(name) > 3 else 512)
     if name.startswith("c4"):
@@ -164,3 +166,109 @@ def synthetic_density(n, seed=1234, blobs=24):
     thr = np.quantile(f, 0.75)
     f = np.maximum(f - thr, 0)
     return (f * (5.0 / f.max())).astype(np.float32)
+
+
+def _range_mips(lo, hi):
+    """Three (min of mins, max of maxes) levels over 2x2x2 children, as encoder_ref.encode_arrays builds them."""
+    mips = []
+    for _ in range(3):
+        z, y, x = lo.shape
+        z2, y2, x2 = (z + 1) // 2, (y + 1) // 2, (x + 1) // 2
+        plo = np.full((z2 * 2, y2 * 2, x2 * 2), np.inf, np.float32)
+        phi = np.full((z2 * 2, y2 * 2, x2 * 2), -np.inf, np.float32)
+        plo[:z, :y, :x] = lo
+        phi[:z, :y, :x] = hi
+        lo = plo.reshape(z2, 2, y2, 2, x2, 2).min((1, 3, 5))
+        hi = phi.reshape(z2, 2, y2, 2, x2, 2).max((1, 3, 5))
+        w = lo.astype(np.float16).view(np.uint16).astype(np.uint32) | (hi.astype(np.float16).view(np.uint16).astype(np.uint32) << 16)
+        mips.append(((x2, y2, z2), w.reshape(-1)))
+    return mips
+
+
+_SPARSE_FULL = {}
+
+
+def sparse_brick_arrays_full(n=1024, chunks=160, seed=777):
+    """BASELINE configs[4]'s grid SIZE (n^3 voxels, (n/8)^3 bricks, a few per cent of them allocated) built directly in brick
+    form -- the dense n^3 array is never materialised, so the scene takes seconds, not minutes: `chunks` cells of a 64-voxel
+    lattice each hold one smooth blob that vanishes 4 voxels inside the cell border (so the +-2-voxel range dilation never
+    crosses cells and every cell can be encoded on its own by the numpy reference encoder), everything else is empty.
+    Returns (density, temperature) as encode_arrays()-style dicts: the exact input of vr_set_volume_brick / oracle Grid.set."""
+    key = (n, chunks, seed)
+    if key in _SPARSE_FULL:
+        return _SPARSE_FULL[key]
+    import encoder_ref
+    c = 64
+    cells = n // c
+    nb = n // 8
+    rs = np.random.RandomState(seed)
+    # blobs cluster around the centre so that a camera looking at the origin sees overlapping ones
+    pick = set()
+    while len(pick) < chunks:
+        p = tuple(np.clip(np.round(rs.normal(cells / 2 - 0.5, cells / 6, 3)), 0, cells - 1).astype(int))
+        pick.add(p)
+    zz, yy, xx = np.meshgrid(*(np.arange(c, dtype=np.float32) - (c - 1) / 2,) * 3, indexing="ij")
+    r2 = xx * xx + yy * yy + zz * zz
+    out = []
+    for which in ("density", "temperature"):
+        rng_w = np.zeros((nb, nb, nb), np.uint32)
+        ind = np.zeros((nb, nb, nb), np.uint32)
+        blocks = []
+        for (cz, cy, cx) in sorted(pick):
+            rr = np.random.RandomState(hash((cz, cy, cx, seed)) & 0x7FFFFFFF)
+            sigma = np.float32(rr.uniform(8.0, 13.0))
+            amp = np.float32(rr.uniform(1.0, 5.0))
+            f = np.exp(-r2 / (2 * sigma * sigma)) - np.float32(np.exp(-28.0 * 28.0 / (2 * sigma * sigma)))
+            wob = 1 + np.float32(0.25) * np.sin(xx * np.float32(rr.uniform(0.2, 0.5))) * np.cos(yy * np.float32(rr.uniform(0.2, 0.5)) + zz * np.float32(0.3))
+            f = (np.maximum(f, 0) * wob * amp).astype(np.float32)
+            if which == "temperature":
+                f = (np.clip(f / amp, 0, 1) ** 2 * np.float32(rr.uniform(0.3, 1.0))).astype(np.float32)
+            a = encoder_ref.encode_arrays(f)
+            lb = c // 8
+            l_ind = a["indirection"].reshape(lb, lb, lb)
+            l_rng = a["rng"].reshape(lb, lb, lb)
+            l_atlas = a["atlas"].reshape(a["atlas_dim"][2], a["atlas_dim"][1], a["atlas_dim"][0])
+            rng_w[cz * lb:(cz + 1) * lb, cy * lb:(cy + 1) * lb, cx * lb:(cx + 1) * lb] = l_rng
+            lo = (l_rng & 0xFFFF).astype(np.uint16).view(np.float16)
+            hi = (l_rng >> 16).astype(np.uint16).view(np.float16)
+            for bz, by, bx in zip(*np.nonzero(lo != hi)):
+                v = int(l_ind[bz, by, bx])
+                px, py, pz = v >> 22, (v >> 12) & 1023, (v >> 2) & 1023
+                blocks.append(((cz * lb + bz, cy * lb + by, cx * lb + bx), l_atlas[pz * 8:pz * 8 + 8, py * 8:py * 8 + 8, px * 8:px * 8 + 8]))
+        per_layer = nb * nb
+        layers = max(1, (len(blocks) + per_layer - 1) // per_layer)
+        atlas = np.zeros((layers * 8, nb * 8, nb * 8), np.uint8)
+        for k, ((bz, by, bx), blk) in enumerate(blocks):
+            px, py, pz = k % nb, (k // nb) % nb, k // per_layer
+            ind[bz, by, bx] = (px << 22) | (py << 12) | (pz << 2)
+            atlas[pz * 8:pz * 8 + 8, py * 8:py * 8 + 8, px * 8:px * 8 + 8] = blk
+        lo_f = (rng_w & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)
+        hi_f = (rng_w >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+        out.append(dict(transform=np.eye(4, dtype=np.float32).reshape(16), n_bricks=(nb, nb, nb), min_maj=(float(lo_f.min()), float(hi_f.max())),
+                        brick_counter=len(blocks), indirection=ind.reshape(-1), rng=rng_w.reshape(-1),
+                        atlas_dim=(nb * 8, nb * 8, layers * 8), atlas=atlas.reshape(-1), mips=_range_mips(lo_f, hi_f)))
+    _SPARSE_FULL[key] = tuple(out)
+    return _SPARSE_FULL[key]
+
+
+def configure_sparse_full(r, is_oracle, n=1024):
+    """The c5 settings (configure_sparse) on the brick-form full-size grid of sparse_brick_arrays_full()."""
+    ad, at = sparse_brick_arrays_full(n)
+    if is_oracle:
+        from oracle import binding as ob
+
+        def grid(a):
+            g = ob.Grid()
+            g.set(a["transform"], a["n_bricks"], a["min_maj"], a["brick_counter"], a["indirection"], a["rng"], a["atlas_dim"], a["atlas"], a["mips"])
+            return g
+        r.set_volume(grid(ad), emission=grid(at), majorant_emission=at["min_maj"][1])
+    else:
+        r.set_volume_brick(ad["transform"], ad["n_bricks"], ad["min_maj"], ad["indirection"], ad["rng"], ad["atlas_dim"], ad["atlas"], ad["mips"], commit=False)
+        r.set_volume_brick(at["transform"], at["n_bricks"], at["min_maj"], at["indirection"], at["rng"], at["atlas_dim"], at["atlas"], at["mips"], name="temperature", commit=True)
+    r.load_envmap(HDR)
+    r.bounces, r.cam_fov = 128, 40.0
+    r.albedo = (0.9, 0.9, 0.9)
+    r.phase = 0.3
+    r.density_scale = 100.0
+    r.emission_scale = 100.0
+    return r

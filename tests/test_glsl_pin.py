@@ -88,6 +88,36 @@ def test_functions_of_common_glsl(standard):
         assert v < 2e-6, (k, v)                                               # tonemap.glsl (pow is the driver's: a few ulp)
 
 
+def test_more_functions_of_common_glsl(standard, unfused):
+    """Probes 4, 5 and 9 of the golden file: view_dir, intersect_box and a complete sample_volumeDDA camera segment."""
+    for res in (standard, unfused):
+        p = res["probes"]
+        assert p["view_dir_max_abs"] < 3e-7, p["view_dir_max_abs"]
+        b = p["intersect_box"]
+        assert b["flag_mismatches"] == 0 and b["hits"] >= 5 and b["near_far_max_rel"] < 2e-6, b
+    d = standard["probes"]["sample_volumeDDA"]
+    # decisions and RNG end state of every segment identical; t / throughput to 1e-5 (the probes run with the driver's log, 86 ulp)
+    assert d["same_flag"] == 1.0 and d["same_rng_state"] == 1.0 and d["within_1e5"] >= 0.99, d
+    assert unfused["probes"]["sample_volumeDDA"]["same_rng_state"] >= 0.99, unfused["probes"]["sample_volumeDDA"]
+
+
+def test_north_star_tolerance_at_1024_spp(standard, unfused):
+    """"Output within 1e-3 relative L2 of the GLSL reference", at 1024 samples per pixel (glsl_golden_r2.npz): the standard
+    oracle -- which the HIP kernels reproduce bit for bit -- and the unfused build."""
+    for name in ("hi_c2_white_driver", "hi_c2_hdr_spec", "hi_c3_tf_spec", "hi_readme_hdr_spec", "hi_c1_hdr_spec", "hi_emission_spec"):
+        assert standard["r2"][name]["rel_l2"] <= 1e-3, (name, standard["r2"][name])
+        assert unfused["r2"][name]["rel_l2"] <= 1e-3, (name, unfused["r2"][name])
+    assert standard["r2"]["hi_c2_hdr_driver"]["rel_l2"] <= 2e-3, standard["r2"]["hi_c2_hdr_driver"]      # the driver's own acos/atan: 2e-4 relative
+
+
+def test_raymarch_trackers_reproduce_reference_text(standard, unfused):
+    """trace_path with sample_volume_raymarch / transmittance_raymarch (common.glsl:506-566, integrator 3) against the
+    reference's text run on llvmpipe."""
+    for name in ("rm_c2_spec", "rm_c3_spec"):
+        assert unfused["r2"][name]["rel_l2"] < 5e-5 and unfused["r2"][name]["within_1e5"] > 0.995, (name, unfused["r2"][name])
+        assert standard["r2"][name]["within_1e5"] > 0.99 and standard["r2"][name]["rel_l2"] < 5e-2, (name, standard["r2"][name])
+
+
 def test_recorded_precision_of_driver_builtins(standard):
     """What "the reference" is, in the last digits, depends on the GL driver: llvmpipe's sin/cos equal the specification's
     (both Cephes), its log/acos/atan are short polynomials.  Recorded so that the tolerances above can be read."""

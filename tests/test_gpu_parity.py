@@ -518,6 +518,66 @@ def test_synthetic_baseline_configs_small(name):
     _assert_same(fb, o.render(4), name)
 
 
+def _full_resolution_properties(name, w, h, spp=2):
+    """Size-independent checks at a BASELINE frame size (the oracle is too slow there): finite, alpha in [0, 1], something hit,
+    the same image twice, and the tile-shard property of the multi-GPU path -- a renderer restricted to a subset of the 16x16
+    tiles produces exactly the pixels the full-frame render has there (seed depends on pixel and sample only)."""
+    from volren_amd.shard import TileShard
+    r = scenes.hip_scene(name, w, h)
+    r.render(spp)
+    a = r.framebuffer().copy()
+    assert np.isfinite(a).all() and a[..., 3].min() >= 0.0 and a[..., 3].max() <= 1.0 and a[..., 3].max() > 0 and a[..., :3].max() > 0
+    r.reset()
+    r.render(spp)
+    assert np.array_equal(_bits(a), _bits(r.framebuffer())), "%s: two renders of the same frame differ" % name
+    sh = TileShard(w, h, 8, 3)
+    r.set_tiles(sh.mine)
+    r.reset()
+    r.render(spp)
+    b = r.framebuffer()
+    tx = (w + 15) // 16
+    for t in list(sh.mine)[::max(1, len(sh.mine) // 64)]:
+        y0, x0 = (t // tx) * 16, (t % tx) * 16
+        assert np.array_equal(_bits(a[y0:y0 + 16, x0:x0 + 16]), _bits(b[y0:y0 + 16, x0:x0 + 16])), "%s: tile %d differs between full frame and shard" % (name, t)
+
+
+def test_c4_full_size_dense_512():
+    """BASELINE configs[3] at its real grid size: synthetic 512^3 dense fp16 grid (256 MiB of voxels: beyond L2 and the
+    Infinity Cache's comfort), README parameters, 128 bounces.  Bit for bit against the oracle ON THE SAME 512^3 GRID at a
+    frame size the oracle finishes in seconds (its cost scales with pixels, not voxels), then the properties at 1920x1080."""
+    o = scenes.oracle_scene("c4:512", 96, 64)
+    r = scenes.hip_scene("c4:512", 96, 64)
+    r.render(4)
+    fb = r.framebuffer()
+    assert fb[..., :3].max() > 0 and fb[..., 3].mean() > 0.2
+    _assert_same(fb, o.render(4), "c4 512^3 dense fp16")
+    del r, o
+    _full_resolution_properties("c4:512", 1920, 1080)
+
+
+def test_c5_full_size_sparse_1024():
+    """BASELINE configs[4] at its real grid size: a 1024^3-voxel sparse brick grid (128^3 = 2 M bricks, 65 k allocated) plus a
+    temperature grid of the same size, emission on, handed to both sides in brick form (scenes.sparse_brick_arrays_full):
+    exercises the 2^21-entry brick tables, the 1 GiB brick-linear atlas addressing and the padded majorant levels that a 64^3
+    miniature cannot.  Bit for bit against the oracle, then the properties at 2048x2048."""
+    o = scenes.oracle_scene("c5full", 96, 64)
+    r = scenes.hip_scene("c5full", 96, 64)
+    r.render(4)
+    fb = r.framebuffer()
+    assert fb[..., :3].max() > 0 and fb[..., 3].max() > 0
+    _assert_same(fb, o.render(4), "c5 1024^3 sparse + emission")
+    # a second view from inside the grid's corner region: large brick indices on every axis
+    for x in (r, o):
+        x.cam_pos = (0.45, 0.4, 0.48)
+        x.cam_dir = (-0.6, -0.5, -0.62)
+    r.reset()
+    o.sample = 0
+    r.render(4)
+    _assert_same(r.framebuffer(), o.render(4), "c5 1024^3, corner view")
+    del r, o
+    _full_resolution_properties("c5full", 2048, 2048)
+
+
 def test_hip_against_reference_glsl_golden():
     """The north star's check itself: the HIP renderer against images of the reference's GLSL kernels (rendered on Mesa llvmpipe in
     the build container, tests/golden/glsl_golden.npz), same seed, same spp.  HIP == standard oracle bit for bit, so the
@@ -543,6 +603,44 @@ def test_hip_against_reference_glsl_golden():
         tol = 1e-3 if name == "c3_tf_spec" or name.endswith("global_spec") else 1e-5
         assert (rel <= tol).mean() > 0.995, (name, float((rel <= tol).mean()))
         assert rl2 < 5e-2 and abs(hip[..., :3].mean() / ref[..., :3].mean() - 1.0) < 1e-3, (name, rl2)
+
+
+def test_hip_within_1e3_of_reference_glsl_at_1024_spp():
+    """BASELINE north_star: "output within 1e-3 relative L2 of the GLSL reference" -- asserted at a sample count where the
+    statement is about the renderer and not about one flipped path: tests/golden/glsl_golden_r2.npz holds the reference's
+    kernels run for 1024 dispatches per image (make_golden_glsl.py --r2).  Measured: 1e-4 ... 8e-4 (tests/test_glsl_pin.py
+    asserts the same for the oracle, which the HIP kernels equal bit for bit).  Also in the opt-in tolerance mode."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "glsl_golden_r2.npz"))
+    meta = json.load(open(os.path.join(here, "golden", "glsl_golden_r2.json")))
+    w, h, spp = meta["width"], meta["height"], meta["hi_spp"]
+    for name in ("hi_c2_white_driver", "hi_c2_hdr_spec", "hi_c3_tf_spec", "hi_readme_hdr_spec", "hi_c1_hdr_spec"):
+        m = meta["images"][name]
+        r = scenes.hip_scene(m["config"], w, h)
+        if m["white_env"]:
+            r.set_envmap(np.ones((1, 1, 3), np.float32))
+        for fast in (0, 1):
+            r.fast_math = fast
+            r.reset()
+            r.render(spp)
+            rl2 = scenes.rel_l2(r.framebuffer()[..., :3], g[name][..., :3])
+            assert rl2 <= 1e-3, (name, "fast_math" if fast else "bit-exact", rl2)
+
+
+def test_raymarch_integrator_matches_oracle_and_reference():
+    """integrator = 3: trace_path with the 64-step ray-marching trackers (common.glsl:506-566; code the reference contains but
+    calls from no kernel).  Bit for bit against the oracle; the oracle itself is pinned against the reference's text run on
+    llvmpipe (tests/test_glsl_pin.py, rm_* images)."""
+    for name in ("c2", "c3", "c5:64"):
+        o = scenes.oracle_scene(name, 64, 48)
+        r = scenes.hip_scene(name, 64, 48)
+        o.integrator = 3
+        r.integrator = 3
+        r.render(8)
+        fb = r.framebuffer()
+        assert fb[..., :3].max() > 0
+        _assert_same(fb, o.render(8), "raymarch integrator, " + name)
 
 
 @pytest.mark.parametrize("case", ["fov0", "fov180", "cam_inside", "axis_aligned", "huge_density", "zero_albedo"])

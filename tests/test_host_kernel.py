@@ -48,6 +48,18 @@ def test_direct_volume_rendering_integrator():
     assert _same(got, want)
 
 
+@pytest.mark.parametrize("name", ["c2", "c3"])
+def test_raymarch_trackers_integrator(name):
+    """common.glsl:506-566 (transmittance_raymarch / sample_volume_raymarch inside trace_path; dead code in the reference):
+    integrator = 3, the device's raymarch_path_sample compiled for the host against the oracle."""
+    r = scenes.oracle_scene(name, 32, 32)
+    r.integrator = 3
+    want = r.render(4).copy()
+    got, _ = hk.render(r, 4)
+    assert want[..., :3].max() > 0
+    assert _same(got, want)
+
+
 def test_sample_chunks_and_progressive_accumulation():
     """40 spp spans two 32-sample chunks of a wave's item pool; rendering 3 + 5 more samples continues the running mean."""
     r = scenes.oracle_scene("c1", 24, 24)

@@ -77,3 +77,36 @@ def test_two_rank_render_equals_single_process():
     ref = scenes.oracle_scene("c1", W, H).render(SPP)
     for rk in (0, 1):
         assert np.array_equal(frames[rk].view(np.uint32), ref.view(np.uint32)), "rank %d frame differs" % rk
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` must start its ranks itself (no external torchrun), before anything touches a GPU, and
+    exit with their status.  --launch-check runs the launcher path only (spawn, rendezvous on 127.0.0.1, one all_gather of a
+    per-rank tile buffer) with the gloo backend, so it works in the GPU-less build container."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["VOLREN_DIST_BACKEND"] = "gloo"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--width", "256", "--height", "192"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["launch_check"] is True and j["n_gpus"] == 2 and j["backend"] == "gloo" and j["tiles_per_rank"] == 96
+    # a rank that fails makes the launcher exit non-zero: without --launch-check the ranks need a HIP device
+    if not _have_gpu():
+        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-budget", "0"],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert bad.returncode != 0
+
+
+def _have_gpu():
+    try:
+        import volren_amd
+        return volren_amd.load().vr_device_count() > 0
+    except Exception:
+        return False

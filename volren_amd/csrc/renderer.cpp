@@ -383,7 +383,7 @@ void RendererHIP::launch(int n) {
     if (n <= 0) return;
     if (!color) throw std::runtime_error("RendererHIP::trace: no framebuffer (call resize first)");
     if (integrator == 2 && !transferfunc) throw std::runtime_error("RendererHIP::trace: integrator 2 (direct volume rendering) needs a transfer function");
-    if (integrator < 0 || integrator > 2) throw std::runtime_error("RendererHIP::trace: unknown integrator");
+    if (integrator < 0 || integrator > 3) throw std::runtime_error("RendererHIP::trace: unknown integrator");
     SceneParams P;
     fill_params(P);
     update_majorants(P, density_grids[volume->grid_frame_counter]);

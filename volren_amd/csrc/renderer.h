@@ -107,7 +107,8 @@ struct RendererHIP {
     Camera camera;
     ivec2 resolution{ 0, 0 };
     hipStream_t stream = nullptr;
-    int integrator = 0;                               // 0: DDA tracking (both reference kernels)
+    int integrator = 0;                               // 0: DDA tracking (both reference kernels), 1: global-majorant tracking (common.glsl:333-394),
+                                                      // 2: direct volume rendering (:571-591, needs a LUT), 3: 64-step ray-marching trackers (:506-566)
     bool fast_math = false;                           // opt-in tolerance mode: hardware log/sin/cos/rcp instead of the specified arithmetic
                                                       // (within 1e-3 relative L2 of the default, not bit-reproducible)
     int last_launches = 0;                            // path-tracing sub-launches of the last trace()/render()

@@ -38,6 +38,22 @@ dvr_kernel(const SceneParams P, float* __restrict__ sbuf, const LaunchDesc D) {
     reinterpret_cast<float4*>(sbuf)[wu.base + item] = make_float4(L[0], L[1], L[2], L[3]);
 }
 
+// integrator = 3: trace_path with the ray-marching trackers, one thread per (pixel, sample) item like dvr_kernel
+__global__ void __launch_bounds__(256)
+raymarch_kernel(const SceneParams P, float* __restrict__ sbuf, const LaunchDesc D) {
+    const uint32_t per_unit = (uint32_t)(D.spu * 64);
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t u = g / per_unit, item = g - u * per_unit;
+    if (u >= D.n_units) return;
+    const WorkUnit wu = make_unit(D, P.u.resolution[0], u, sbuf);
+    if ((int32_t)item >= wu.n_items) return;
+    const int32_t px = wu.px0 + (int32_t)(item & 7u), py = wu.py0 + (int32_t)((item >> 3) & 7u);
+    if (px >= P.u.resolution[0] || py >= P.u.resolution[1]) return;
+    float L[4];
+    raymarch_path_sample(P, px, py, wu.first_sample + (int32_t)(item >> 6), L);
+    reinterpret_cast<float4*>(sbuf)[wu.base + item] = make_float4(L[0], L[1], L[2], L[3]);
+}
+
 // Running mean over the samples of one launch, in sample order (pathtracer_brick.glsl:36): one thread per pixel.
 __global__ void __launch_bounds__(256)
 accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const int32_t* __restrict__ tiles, int32_t n_tiles,
@@ -122,7 +138,7 @@ static int resident_blocks(int mode, int variant, bool tf, bool stats) {
     return std::min(cus * per_cu, kMaxWorkgroups);
 }
 
-size_t pathtrace_workspace_floats() { return (size_t)kMaxWorkgroups * 4u * kColdWaveFloats; }      // cold state of 4 wavefronts per resident workgroup
+size_t pathtrace_workspace_floats() { return (size_t)kMaxWorkgroups * 4u * (kColdWaveFloats > 0 ? kColdWaveFloats : 4); }      // cold state of 4 wavefronts per resident workgroup
 
 void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math) {
@@ -149,6 +165,9 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     if (P.u.integrator == 2 && P.u.use_tf) {
         const uint64_t items = (uint64_t)D.n_units * (uint64_t)(D.spu * 64);
         hipLaunchKernelGGL(dvr_kernel, dim3((unsigned)((items + 255) / 256)), block, 0, stream, P, sample_pool, D);
+    } else if (P.u.integrator == 3) {
+        const uint64_t items = (uint64_t)D.n_units * (uint64_t)(D.spu * 64);
+        hipLaunchKernelGGL(raymarch_kernel, dim3((unsigned)((items + 255) / 256)), block, 0, stream, P, sample_pool, D);
     } else {
         (void)hipMemsetAsync(unit_counter, 0, kQueueSegments * sizeof(uint32_t), stream);
         kPtLaunch[mode][variant](tf, stats, grid.x, stream, &P, sample_pool, workspace, &D, &S, status, g_stats);

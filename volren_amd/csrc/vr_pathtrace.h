@@ -121,26 +121,54 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
 #ifndef VR_COLD_SOA
 #define VR_COLD_SOA 1
 #endif
+#ifndef VR_COLD_NT
+#define VR_COLD_NT 0               // experiment: non-temporal cold-state accesses
+#endif
+#ifndef VR_WHATIF_COLD_ALIAS
+#define VR_WHATIF_COLD_ALIAS 0     // diagnostic (wrong images): all slots of a wavefront share one cold entry -> what the cold traffic costs
+#endif
 constexpr int32_t kColdGroups = C_COUNT / 4;          // 6
 struct ColdGlobal {
     float* base;                       // the wavefront's slice + this slot's offset inside a group
     __device__ __forceinline__ float ld(int32_t f) const {
-#if VR_COLD_SOA
+#if VR_COLD_NT
+        return __builtin_nontemporal_load(static_cast<const float*>(__builtin_assume_aligned(base, 16)) + ((f >> 2) * (NSLOT * 4) + (f & 3)));
+#elif VR_COLD_SOA
         return static_cast<const float*>(__builtin_assume_aligned(base, 16))[(f >> 2) * (NSLOT * 4) + (f & 3)];
 #else
         return static_cast<const float*>(__builtin_assume_aligned(base, 128))[f];
 #endif
     }
     __device__ __forceinline__ void st(int32_t f, float v) {
-#if VR_COLD_SOA
+#if VR_COLD_NT
+        __builtin_nontemporal_store(v, static_cast<float*>(__builtin_assume_aligned(base, 16)) + ((f >> 2) * (NSLOT * 4) + (f & 3)));
+#elif VR_COLD_SOA
         static_cast<float*>(__builtin_assume_aligned(base, 16))[(f >> 2) * (NSLOT * 4) + (f & 3)] = v;
 #else
         static_cast<float*>(__builtin_assume_aligned(base, 128))[f] = v;
 #endif
     }
 };
-#if VR_COLD_SOA
-constexpr int32_t kColdWaveFloats = kColdGroups * NSLOT * 4, kColdSlotStride = 4;
+// VR_COLD_LDS: the cold state lives in LDS next to the parked hot state ([slot][field], odd stride).  Nothing of a path is in
+// global memory then; the price is LDS capacity, i.e. fewer path slots per wavefront and / or fewer wavefronts per CU.
+#ifndef VR_COLD_LDS
+#define VR_COLD_LDS 0
+#endif
+constexpr int32_t COLD_LDS_STRIDE = 23;          // C_SHLE + 3 = 23 dwords are used; odd: conflict-free for lanes with different slots
+struct ColdLDS {
+    float* base;
+    __device__ __forceinline__ float ld(int32_t f) const { return base[f]; }
+    __device__ __forceinline__ void st(int32_t f, float v) { base[f] = v; }
+};
+#if VR_COLD_LDS
+typedef ColdLDS ColdT;
+#else
+typedef ColdGlobal ColdT;
+#endif
+#if VR_COLD_LDS
+constexpr int32_t kColdWaveFloats = 0, kColdSlotStride = COLD_LDS_STRIDE;
+#elif VR_COLD_SOA
+constexpr int32_t kColdWaveFloats = kColdGroups * NSLOT * 4, kColdSlotStride = VR_WHATIF_COLD_ALIAS ? 0 : 4;
 #else
 constexpr int32_t kColdWaveFloats = C_STRIDE * NSLOT, kColdSlotStride = C_STRIDE;
 #endif
@@ -181,7 +209,12 @@ pathtrace_kernel(const KernelArgs A) {
     __shared__ uint8_t lds_q[4 * Q_COUNT * NSLOT];
     uint8_t* const q = lds_q + wave * (Q_COUNT * NSLOT);
     // per-wavefront slice of the workspace: the cold fields of its NSLOT paths
+#if VR_COLD_LDS
+    __shared__ float lds_cold[4 * COLD_LDS_STRIDE * NSLOT];
+    float* const cold_base = lds_cold + wave * (COLD_LDS_STRIDE * NSLOT);
+#else
     float* const cold_base = A.cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)kColdWaveFloats;
+#endif
     __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NSLOT];
     const HotStore hs{ lds_hot + wave * (HOT_STRIDE * NSLOT) };
 
@@ -294,7 +327,7 @@ pathtrace_kernel(const KernelArgs A) {
             if (is_c) collide_prep<K>(l, P, cio);
             collide_load<K>(P, cio);
             if (is_c) {
-                ColdGlobal c{ cold_base + slot * kColdSlotStride };
+                ColdT c{ cold_base + slot * kColdSlotStride };
                 collide_finish<K>(l, c, P, cio);
             }
             // every load of the pass has been consumed or belongs to a lane that left early: say so, or the compiler carries
@@ -347,7 +380,7 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_ESC * NSLOT + cnt_esc - 1 - lane];
                     hs.load(b, bs);
-                    ColdGlobal c{ cold_base + bs * kColdSlotStride };
+                    ColdT c{ cold_base + bs * kColdSlotStride };
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
                     do_escape(b, c, E.P, w);                              // writes the sample; the slot becomes free
@@ -363,7 +396,7 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_POST * NSLOT + cnt_post - 1 - lane];
                     hs.load(b, bs);
-                    ColdGlobal c{ cold_base + bs * kColdSlotStride };
+                    ColdT c{ cold_base + bs * kColdSlotStride };
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
                     do_postnee<K>(b, c, E.P, w);
@@ -395,7 +428,7 @@ pathtrace_kernel(const KernelArgs A) {
                     if (lane < n) {
                         bs = q[Q_FREE * NSLOT + cnt_free - 1 - lane];
                         hot_init(b);
-                        ColdGlobal c{ cold_base + bs * kColdSlotStride };
+                        ColdT c{ cold_base + bs * kColdSlotStride };
                         do_new<K>(b, c, event_args().P, wu, cursor + (uint32_t)lane);
                         hs.save(b, bs);
                     }
@@ -412,7 +445,7 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_NEE * NSLOT + cnt_nee - 1 - lane];
                     hs.load(b, bs);
-                    ColdGlobal c{ cold_base + bs * kColdSlotStride };
+                    ColdT c{ cold_base + bs * kColdSlotStride };
                     do_nee<K>(b, c, event_args().P);
                     hs.save(b, bs);
                 }

@@ -888,6 +888,117 @@ VR_HD void dvr_sample(const SceneParams& P, int32_t px, int32_t py, int32_t smp,
     out[0] = L.x; out[1] = L.y; out[2] = L.z; out[3] = 1.0f - Tr;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// trace_path with the 64-step ray-marching trackers (common.glsl:506-566: transmittance_raymarch, sample_volume_raymarch;
+// RAYMARCH_STEPS 64).  Dead code in the reference -- no kernel calls them; trace_path only switches between the DDA and the
+// global-majorant pair -- offered as integrator = 3.  Every step costs a stochastic-tricubic tap (9 draws), also with a
+// transfer function.  One call per (pixel, sample), sequential: no path state, no scheduler (like dvr_sample).
+VR_HD float raymarch_density(const SceneParams& P, v3 ip, uint32_t& seed) {
+    int32_t tx, ty, tz;
+    tricubic_tap(ip, seed, tx, ty, tz);
+    return P.u.vol_density_scale * brick_value<2>(P.density, tx, ty, tz);
+}
+VR_HD float transmittance_raymarch(const SceneParams& P, v3 wpos, v3 wdir, uint32_t& seed) {
+    const Uniforms& u = P.u;
+    float tnear, tfar;
+    if (!intersect_box(wpos, wdir, u.vol_bb_min, u.vol_bb_max, tnear, tfar)) return 1.0f;
+    const v3 ipos = mat4_point(u.vol_density_inv_transform, wpos);
+    const v3 idir = mat4_dir(u.vol_density_inv_transform, wdir);
+    const float dt = (tfar - tnear) / 64.0f;
+    tnear += rng(seed) * dt;
+    float tau = 0.0f;
+    for (int32_t i = 0; i < 64; ++i) {
+        const float d = raymarch_density(P, axpy(ipos, min_(tnear + (float)i * dt, tfar), idir), seed);
+        if (u.use_tf) {
+            float rgba[4];
+            tf_lookup(P, d * u.vol_inv_majorant, rgba);
+            tau += rgba[3] * u.vol_majorant * dt;
+        } else {
+            tau += d * dt;
+        }
+    }
+    return exp_(-tau);
+}
+VR_HD bool sample_volume_raymarch(const SceneParams& P, v3 wpos, v3 wdir, float& t, v3& throughput, uint32_t& seed) {
+    const Uniforms& u = P.u;
+    float tnear, tfar;
+    if (!intersect_box(wpos, wdir, u.vol_bb_min, u.vol_bb_max, tnear, tfar)) return false;
+    const v3 ipos = mat4_point(u.vol_density_inv_transform, wpos);
+    const v3 idir = mat4_dir(u.vol_density_inv_transform, wdir);
+    const float tau_target = neg_log_1m(rng(seed));
+    const float dt = (tfar - tnear) / 64.0f;
+    tnear += rng(seed) * dt;
+    float tau = 0.0f;
+    for (int32_t i = 0; i < 64; ++i) {
+        t = min_(tnear + (float)i * dt, tfar);
+        const float d = raymarch_density(P, axpy(ipos, t, idir), seed);
+        float rgba[4] = { 0, 0, 0, 0 };
+        if (u.use_tf) {
+            tf_lookup(P, d * u.vol_inv_majorant, rgba);
+            tau += rgba[3] * u.vol_majorant * dt;
+        } else {
+            tau += d * dt;
+        }
+        if (tau >= tau_target) {
+            // throughput *= albedo (the `pdf` output of the reference function has no consumer in trace_path)
+            const v3 alb = u.use_tf ? v3{ rgba[0] * u.vol_albedo[0], rgba[1] * u.vol_albedo[1], rgba[2] * u.vol_albedo[2] }
+                                    : v3{ u.vol_albedo[0], u.vol_albedo[1], u.vol_albedo[2] };
+            throughput = throughput * alb;
+            return true;
+        }
+    }
+    return false;
+}
+// pathtracer_brick*.glsl main + trace_path (common.glsl:599-652) around the two trackers above
+VR_HD void raymarch_path_sample(const SceneParams& P, int32_t px, int32_t py, int32_t smp, float out[4]) {
+    const Uniforms& u = P.u;
+    const int32_t W = u.resolution[0], H = u.resolution[1];
+    uint32_t seed = tea32((uint32_t)u.seed * (uint32_t)(py * W + px), (uint32_t)smp);
+    const float jx = rng(seed), jy = rng(seed);
+    const float fx = (((float)px + jx) - (float)W * 0.5f) / (float)H;
+    const float fy = (((float)py + jy) - (float)H * 0.5f) / (float)H;
+    v3 dir = normalize(mat3_mul(u.cam_transform, normalize(v3{ fx, fy, P.cam_z })));
+    v3 pos = v3{ u.cam_pos[0], u.cam_pos[1], u.cam_pos[2] };
+    v3 L = v3{ 0, 0, 0 }, thr = v3{ 1, 1, 1 };
+    bool free_path = true;
+    uint32_t n_paths = 0u;
+    float t = 0.0f, f_p = 0.0f;
+    while (sample_volume_raymarch(P, pos, dir, t, thr, seed)) {
+        pos = axpy(pos, t, dir);
+        const float r0 = rng(seed), r1 = rng(seed);
+        float pdf;
+        v3 w_i, Le;
+        sample_environment(P, r0, r1, w_i, Le, pdf);
+        if (pdf > 0.0f) {
+            f_p = phase_hg(dot(-dir, w_i), u.vol_phase_g);
+            const float mis = u.show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
+            const float Tr = transmittance_raymarch(P, pos, w_i, seed);
+            L = L + ((((thr * mis) * f_p) * Tr) * Le) / pdf;
+        }
+        if (++n_paths >= (uint32_t)u.bounces) { free_path = false; break; }
+        const float rr = luma(thr);
+        if (rr < 0.1f) {
+            const float prob = 1.0f - rr;
+            if (rng(seed) < prob) { free_path = false; break; }
+            thr = thr / (1.0f - prob);
+        }
+        const float s0 = rng(seed), s1 = rng(seed);
+        const v3 sd = sample_phase_hg(dir, u.vol_phase_g, s0, s1);
+        f_p = phase_hg(dot(-dir, sd), u.vol_phase_g);
+        dir = sd;
+    }
+    if (free_path && u.show_environment > 0) {
+        const v3 Le = lookup_environment(P, dir);
+        float mis = 1.0f;
+        if (n_paths > 0u) {
+            const float avg_w = imp_fetch(P, 0, 0, u.env_imp_base_mip);
+            mis = power_heuristic(f_p, (luma(Le) / avg_w) * kInv4Pi);
+        }
+        L = L + (thr * mis) * Le;
+    }
+    out[0] = L.x; out[1] = L.y; out[2] = L.z; out[3] = n_paths > 0u ? 1.0f : 0.0f;
+}
+
 // sequential driver (host harness / reference order): one state transition of one lane
 template <class K, class Cold>
 VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uint32_t& next_item) {
