@@ -137,32 +137,50 @@ class Bench:
         from volren_amd.shard import TileShard
         self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
         self.config, self.w, self.h, self.spp = config, w, h, spp
-        self.r = scenes.hip_scene(config, w, h, device=local_rank)
-        if fast_math:
-            self.r.fast_math = 1
-        self.r.set_stream(torch.cuda.current_stream().cuda_stream)
         self.shard = TileShard(w, h, world, rank)
         self.staged = world > 1 and os.environ.get("VOLREN_DIST_BACKEND", "nccl") != "nccl"
+        # Multi-GPU: a rank's share of a frame is short (tens of ms), so the fixed drain of the persistent wavefronts' path pools at
+        # the end of a launch (4-5 ms, set by the deepest paths) is what bounds strong scaling.  Consecutive frames are independent:
+        # two renderers on two streams let frame i+1's wavefronts move onto the CUs that frame i's draining workgroups free
+        # (profiles/r2_launch_overhead.txt).  Each has its own framebuffer, sample pool and tile buffers; one GPU needs neither.
+        self.pipelined = world > 1 and os.environ.get("VOLREN_PIPELINE", "1") != "0"
+        self.slots = []
+        for k in range(2 if self.pipelined else 1):
+            r = scenes.hip_scene(config, w, h, device=local_rank)
+            if fast_math:
+                r.fast_math = 1
+            stream = torch.cuda.Stream() if self.pipelined else torch.cuda.current_stream()
+            r.set_stream(stream.cuda_stream)
+            slot = dict(r=r, stream=stream)
+            if world > 1:
+                r.set_tiles(self.shard.mine)
+                slot["packed"] = torch.empty(self.shard.packed_floats, dtype=torch.float32, device="cuda")
+                slot["gathered"] = torch.empty(self.shard.gathered_floats, dtype=torch.float32, device="cuda")
+            self.slots.append(slot)
+        self.r = self.slots[0]["r"]
+        self.frame = 0
         if world > 1:
-            self.r.set_tiles(self.shard.mine)
             self.tiles_dev = torch.from_numpy(self.shard.pack_ids).cuda()
             self.all_tiles_dev = torch.from_numpy(self.shard.unpack_ids).cuda()
-            self.packed = torch.empty(self.shard.packed_floats, dtype=torch.float32, device="cuda")
-            self.gathered = torch.empty(self.shard.gathered_floats, dtype=torch.float32, device="cuda")
 
     def step(self):
-        r, torch = self.r, self.torch
-        r.reset()
-        r.render(self.spp, sync=False)                                          # ONE fused launch: all spp of all owned tiles
-        if self.world > 1:
-            r.pack_tiles(self.tiles_dev.data_ptr(), self.shard.n_max, self.packed.data_ptr())
-            if self.staged:
-                hg = torch.empty(self.gathered.shape, dtype=self.gathered.dtype)
-                self.shard.all_gather(self.dist, hg, self.packed.cpu())
-                self.gathered.copy_(hg)
-            else:
-                self.shard.all_gather(self.dist, self.gathered, self.packed)    # RCCL over xGMI, once per frame
-            r.unpack_tiles(self.all_tiles_dev.data_ptr(), self.world * self.shard.n_max, self.gathered.data_ptr())
+        torch = self.torch
+        slot = self.slots[self.frame % len(self.slots)]
+        self.frame += 1
+        r = slot["r"]
+        with torch.cuda.stream(slot["stream"]):
+            r.reset()
+            r.render(self.spp, sync=False)                                      # ONE fused launch: all spp of all owned tiles
+            if self.world > 1:
+                r.pack_tiles(self.tiles_dev.data_ptr(), self.shard.n_max, slot["packed"].data_ptr())
+                if self.staged:
+                    r.synchronize()
+                    hg = torch.empty(slot["gathered"].shape, dtype=slot["gathered"].dtype)
+                    self.shard.all_gather(self.dist, hg, slot["packed"].cpu())
+                    slot["gathered"].copy_(hg)
+                else:
+                    self.shard.all_gather(self.dist, slot["gathered"], slot["packed"])   # RCCL over xGMI, once per frame
+                r.unpack_tiles(self.all_tiles_dev.data_ptr(), self.world * self.shard.n_max, slot["gathered"].data_ptr())
 
     def barrier(self):
         if self.world > 1:
@@ -174,20 +192,26 @@ class Bench:
         for _ in range(warmup):
             self.step()
         self.barrier()
-        self.r.synchronize()
+        for slot in self.slots:
+            slot["r"].synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
         self.barrier()
         elapsed = time.perf_counter() - t0
-        self.r.synchronize()                                                    # also raises if the kernel watchdog tripped
-        last_ms = self.r.last_kernel_ms()                                       # HIP events on the renderer's stream around the last frame's launches
+        for slot in self.slots:
+            slot["r"].synchronize()                                             # also raises if the kernel watchdog tripped
+        if self.pipelined:                                                      # the kernel's own duration: one more frame with nothing beside it
+            self.frame = 0
+            self.step()
+            self.barrier()
+        last_ms = self.slots[(self.frame - 1) % len(self.slots)]["r"].last_kernel_ms()                                       # HIP events on the renderer's stream around the last frame's launches
         if self.world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if not self.staged else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         samples = float(self.w) * self.h * self.spp
-        launches = max(1, self.r.last_launches)                                 # a frame is split so that a sub-launch fits the sample pool
+        launches = max(1, self.slots[(self.frame - 1) % len(self.slots)]["r"].last_launches)                                 # a frame is split so that a sub-launch fits the sample pool
         my_samples = len(self.shard.mine) * 256.0 * self.spp if self.world > 1 else samples
         return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=last_ms / launches,
                     launches=launches, samples_per_launch=my_samples / launches)
@@ -297,7 +321,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else
                                       "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
             "config": {"workload": workload_name(args.config, w, h, spp),
-                       "parallelism": "tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame" % world if world > 1 else "1 GPU, 1 fused launch/frame"},
+                       "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, ", consecutive frames pipelined over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, 1 fused launch/frame"},
             "roofline": b.roofline(m, counters),
         }
         if cpu is not None:

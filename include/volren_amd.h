@@ -48,8 +48,16 @@ int vr_resize(vr_renderer* r, int width, int height);
 /* --- scene loading: load_volume / load_envmap / load_transferfunc of src/main.cpp:37-81 (same side effects:
  *     load_volume sets density_scale=1, scale_and_move_to_unit_cube(), commit(), sample=0; load_envmap resets
  *     transform/strength; load_transferfunc sets show_environment=false) */
-int vr_load_volume(vr_renderer* r, const char* path);              /* .brick file, or a folder of .brick frames */
+int vr_load_volume(vr_renderer* r, const char* path);              /* .brick / .dense / .raw file, or a folder of such frames */
 int vr_load_envmap(vr_renderer* r, const char* path);              /* Radiance .hdr */
+/* `renderer.volume = Volume(path)` of the pybind11 module (src/bindings.cpp:82,176): replaces the volume and nothing else --
+ * no density_scale reset, no unit cube, no commit; the caller runs vr_scale_and_move_to_unit_cube() / vr_commit() in the
+ * reference's order (scripts/datagen_colmap.py:57-63, datagen_denoise.py:85-86) */
+int vr_set_volume_path(vr_renderer* r, const char* path);
+/* voldata::Volume::AABB(name) / minorant_majorant(name) (src/bindings.cpp:91,93; used by scripts/datagen_*.py to place the
+ * camera): world-space box, out = min xyz, max xyz */
+int vr_volume_aabb(vr_renderer* r, const char* name, float out[6]);
+int vr_volume_minorant_majorant(vr_renderer* r, const char* name, float out[2]);
 int vr_load_transferfunc(vr_renderer* r, const char* path);        /* "%f, %f, %f, %f" rows */
 
 /* --- scene from memory: voldata::DenseGrid(w,h,d,float*) + Volume(grid) (src/main.cpp:470-472, bindings.cpp Volume ctors);
@@ -131,6 +139,9 @@ int vr_math_probe(int fn, const float* a, const float* b, float* out, int n);
 /* voldata::Volume::to_brick_grid + BrickGrid serialisation: encode a dense float grid (x fastest) and write it as a .brick
  * container (SURVEY.md 2.3 layout); transform may be NULL (identity).  Host only, needs no device. */
 int vr_write_brick_from_dense(const float* voxels, int nx, int ny, int nz, const float* transform, const char* path);
+/* writes this build's ".dense" container (the serialized dense grid main.cpp:44 can load; voldata's own layout is not
+ * vendored): u8 voxels, x fastest, value = lo + u8 / 255 * (hi - lo) */
+int vr_write_dense(const uint8_t* voxels, int nx, int ny, int nz, float lo, float hi, const float* transform, const char* path);
 /* host-side helpers exposed for tests: dense->brick encoder statistics */
 int vr_encode_dense_stats(const float* voxels, int nx, int ny, int nz, uint32_t n_bricks_out[3], uint64_t* brick_counter, float min_maj_out[2]);
 

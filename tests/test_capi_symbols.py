@@ -109,3 +109,38 @@ def test_host_encoder_matches_reference_encoder_bitwise(tmp_path):
     dec = g.decode_dense()[:40, :36, :44]
     assert np.abs(dec - dens).max() <= (dens.max() - dens.min()) / 255.0 * 0.51 + 1e-3      # u8 quantisation inside each brick range
     assert float(g.decode_dense().max()) <= g.min_maj[1] + 1e-6
+
+
+def test_public_cpp_header_compiles_against_the_reference_names(tmp_path):
+    """include/volren_amd.hpp: a translation unit written against the reference's object API (RendererOpenGL, Environment,
+    TransferFunction, voldata::Volume; src/renderer.h:16-63) compiles against this library's headers."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "caller.cpp"
+    src.write_text('''
+#include <volren_amd.hpp>
+#include <memory>
+int drive(const char* vol, const char* env, const char* lut) {
+    auto renderer = std::make_shared<RendererOpenGL>();
+    renderer->resolution = { 64, 48 };
+    renderer->init();
+    renderer->volume = std::make_shared<voldata::Volume>(std::string(vol));
+    renderer->density_scale = 1.f;
+    renderer->scale_and_move_to_unit_cube();
+    renderer->commit();
+    renderer->environment = std::make_shared<Environment>(std::string(env));
+    renderer->environment->strength = 2.f;
+    renderer->transferfunc = std::make_shared<TransferFunction>(std::string(lut));
+    renderer->transferfunc->window_width = 0.5f;
+    renderer->albedo = vr::vec3(0.8f); renderer->phase = 0.3f; renderer->bounces = 16; renderer->seed = 42; renderer->sppx = 8;
+    renderer->reset();
+    while (renderer->sample < renderer->sppx) renderer->trace();
+    renderer->draw();
+    return renderer->sample;
+}
+''')
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-x", "hip", "-I", os.path.join(root, "include"), str(src)])

@@ -13,12 +13,12 @@ LIB_PATH = os.environ.get("VOLREN_AMD_LIB") or os.path.join(_HERE, "libvolren_am
 # every symbol include/volren_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "vr_last_error", "vr_version", "vr_device_count", "vr_create", "vr_destroy", "vr_resize",
-    "vr_load_volume", "vr_load_envmap", "vr_load_transferfunc", "vr_set_volume_dense", "vr_set_volume_dense_f16", "vr_set_volume_brick",
+    "vr_load_volume", "vr_set_volume_path", "vr_volume_aabb", "vr_volume_minorant_majorant", "vr_load_envmap", "vr_load_transferfunc", "vr_set_volume_dense", "vr_set_volume_dense_f16", "vr_set_volume_brick",
     "vr_set_envmap", "vr_set_transferfunc", "vr_set_int", "vr_get_int", "vr_set_float", "vr_get_float",
     "vr_commit", "vr_reset", "vr_scale_and_move_to_unit_cube", "vr_trace", "vr_render", "vr_synchronize",
     "vr_last_kernel_ms", "vr_framebuffer", "vr_framebuffer_device", "vr_draw", "vr_display", "vr_save_png",
     "vr_set_tiles", "vr_set_stream", "vr_pack_tiles", "vr_unpack_tiles", "vr_get_uniforms", "vr_uniforms_size",
-    "vr_impmap_floats", "vr_get_impmap", "vr_set_sched", "vr_sched_stats", "vr_grid_checksums", "vr_math_probe", "vr_encode_dense_stats", "vr_write_brick_from_dense",
+    "vr_impmap_floats", "vr_get_impmap", "vr_set_sched", "vr_sched_stats", "vr_grid_checksums", "vr_math_probe", "vr_encode_dense_stats", "vr_write_brick_from_dense", "vr_write_dense",
 ]
 
 _lib = None
@@ -49,7 +49,9 @@ def load():
     L.vr_destroy.argtypes = [vp]
     L.vr_destroy.restype = None
     L.vr_resize.argtypes = [vp, ci, ci]
-    for n in ("vr_load_volume", "vr_load_envmap", "vr_load_transferfunc", "vr_save_png"):
+    L.vr_volume_aabb.argtypes = [vp, C.c_char_p, C.POINTER(cf)]
+    L.vr_volume_minorant_majorant.argtypes = [vp, C.c_char_p, C.POINTER(cf)]
+    for n in ("vr_load_volume", "vr_set_volume_path", "vr_load_envmap", "vr_load_transferfunc", "vr_save_png"):
         getattr(L, n).argtypes = [vp, C.c_char_p]
     L.vr_set_volume_dense.argtypes = [vp, C.c_char_p, vp, ci, ci, ci, vp, ci]
     L.vr_set_volume_dense_f16.argtypes = [vp, C.c_char_p, vp, ci, ci, ci, vp, ci]
@@ -80,6 +82,7 @@ def load():
     L.vr_grid_checksums.argtypes = [vp, vp]
     L.vr_math_probe.argtypes = [ci, vp, vp, vp, ci]
     L.vr_write_brick_from_dense.argtypes = [vp, ci, ci, ci, vp, C.c_char_p]
+    L.vr_write_dense.argtypes = [vp, ci, ci, ci, cf, cf, vp, C.c_char_p]
     L.vr_encode_dense_stats.argtypes = [vp, ci, ci, ci, vp, vp, vp]
     _lib = L
     return L

@@ -95,6 +95,39 @@ int vr_load_volume(vr_renderer* r, const char* path) {
     });
 }
 
+// renderer.volume = std::make_shared<voldata::Volume>(path) as the Python scripts do it (bindings.cpp:82,176;
+// datagen_colmap.py:57, datagen_denoise.py:85): ONLY replaces the volume -- density_scale, the unit-cube transform and the
+// device grids are untouched until the caller runs scale_and_move_to_unit_cube() / commit() itself
+int vr_set_volume_path(vr_renderer* r, const char* path) {
+    NEED(r);
+    if (!path) return fail(VR_ERR_ARG, "null path");
+    return guard([&] {
+        if (std::filesystem::is_directory(path)) r->impl.volume = vr::Volume::load_folder(path);
+        else r->impl.volume = std::make_shared<vr::Volume>(std::string(path));
+    });
+}
+
+// voldata::Volume::AABB(name) / minorant_majorant(name) of the renderer's volume (bindings.cpp:91,93): world-space box of the
+// current frame's grid under the volume transform, out = min xyz, max xyz
+int vr_volume_aabb(vr_renderer* r, const char* name, float out[6]) {
+    NEED(r);
+    if (!out) return fail(VR_ERR_ARG, "null output");
+    return guard([&] {
+        if (!r->impl.volume || r->impl.volume->grids.empty()) throw std::runtime_error("vr_volume_aabb: no volume");
+        const auto bb = r->impl.volume->AABB(name ? name : "density");
+        out[0] = bb.first.x; out[1] = bb.first.y; out[2] = bb.first.z; out[3] = bb.second.x; out[4] = bb.second.y; out[5] = bb.second.z;
+    });
+}
+int vr_volume_minorant_majorant(vr_renderer* r, const char* name, float out[2]) {
+    NEED(r);
+    if (!out) return fail(VR_ERR_ARG, "null output");
+    return guard([&] {
+        if (!r->impl.volume || r->impl.volume->grids.empty()) throw std::runtime_error("vr_volume_minorant_majorant: no volume");
+        const auto mm = r->impl.volume->minorant_majorant(name ? name : "density");
+        out[0] = mm.first; out[1] = mm.second;
+    });
+}
+
 // main.cpp:64-71
 int vr_load_envmap(vr_renderer* r, const char* path) {
     NEED(r);
@@ -452,6 +485,16 @@ int vr_write_brick_from_dense(const float* voxels, int nx, int ny, int nz, const
         auto d = std::make_shared<vr::DenseGrid>((uint32_t)nx, (uint32_t)ny, (uint32_t)nz, voxels);
         if (transform) memcpy(d->transform.m, transform, 64);
         vr::Volume::to_brick_grid(d)->write(path);
+    });
+}
+
+// writes this build's ".dense" container (grids.cpp): u8 voxels with value = lo + u8 / 255 * (hi - lo)
+int vr_write_dense(const uint8_t* voxels, int nx, int ny, int nz, float lo, float hi, const float* transform, const char* path) {
+    if (!voxels || !path || nx <= 0 || ny <= 0 || nz <= 0) return fail(VR_ERR_ARG, "bad dense grid arguments");
+    return guard([&] {
+        vr::mat4 t;
+        if (transform) memcpy(t.m, transform, 64);
+        vr::write_dense_file(path, t, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, lo, hi, voxels);
     });
 }
 

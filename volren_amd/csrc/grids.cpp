@@ -169,21 +169,94 @@ float BrickGrid::lookup(uint32_t x, uint32_t y, uint32_t z) const {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Serialized dense grid, ".dense".  voldata's own serialisation is not vendored, so this build defines the
+// container by analogy with the .brick one it could pin: little endian,
+//   u8 endian_flag = 1; f32[16] transform (column-major); u32[3] n_voxels; f32[2] min_maj;
+//   Buf3D<u8> voxels: u32[3] stride = n_voxels, u64 count, u8 data[count]  (x fastest; value = min + u8/255 * (maj - min))
+// "parity unpinned" for files written by the reference's voldata; files written by write_dense_file() round-trip exactly.
+static std::shared_ptr<DenseGrid> load_dense_file(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Unable to read file: " + path);
+    Reader r{ f, path };
+    try {
+        uint8_t endian;
+        r.read(&endian, 1);
+        if (endian != 1) throw std::runtime_error("Unable to read dense grid (not a little-endian .dense): " + path);
+        mat4 transform;
+        r.read(transform.m, 64);
+        uint32_t n[3]; r.read(n, 12);
+        float mm[2]; r.read(mm, 8);
+        Buf3D<uint8_t> vox;
+        r.buf3d(vox);
+        if (vox.stride.x != n[0] || vox.stride.y != n[1] || vox.stride.z != n[2]) throw std::runtime_error("Unable to read dense grid (extent mismatch): " + path);
+        std::vector<float> v(vox.data.size());
+        for (size_t i = 0; i < v.size(); ++i) v[i] = mm[0] + ((float)vox.data[i] / 255.f) * (mm[1] - mm[0]);
+        fclose(f);
+        auto g = std::make_shared<DenseGrid>(n[0], n[1], n[2], v.data());
+        g->transform = transform;
+        return g;
+    } catch (...) { fclose(f); throw; }
+}
+void write_dense_file(const std::string& path, const mat4& transform, uint32_t nx, uint32_t ny, uint32_t nz, float lo, float hi, const uint8_t* voxels) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("Unable to write file: " + path);
+    Writer w{ f };
+    try {
+        const uint8_t endian = 1; w.write(&endian, 1);
+        w.write(transform.m, 64);
+        const uint32_t n[3] = { nx, ny, nz }; w.write(n, 12);
+        const float mm[2] = { lo, hi }; w.write(mm, 8);
+        Buf3D<uint8_t> b(nx, ny, nz);
+        memcpy(b.data.data(), voxels, b.data.size());
+        w.buf3d(b);
+        fclose(f);
+    } catch (...) { fclose(f); throw; }
+}
+// Headerless raw volume, "<name>_<nx>x<ny>x<nz>_<uint8|uint16|float32>.raw" (the Open SciVis naming convention): x fastest,
+// little endian; integer types are normalised to [0, 1].  Identity transform (index space = model space).
+static std::shared_ptr<DenseGrid> load_raw_file(const std::string& path) {
+    const std::string stem = std::filesystem::path(path).stem().string();
+    unsigned nx = 0, ny = 0, nz = 0;
+    char type[16] = { 0 };
+    const size_t us = stem.rfind('_');
+    const size_t ds = us == std::string::npos ? std::string::npos : stem.rfind('_', us - 1);
+    if (us == std::string::npos || ds == std::string::npos || sscanf(stem.c_str() + ds + 1, "%ux%ux%u_%15s", &nx, &ny, &nz, type) != 4 || !nx || !ny || !nz)
+        throw std::runtime_error("Unable to load raw volume (expected <name>_<nx>x<ny>x<nz>_<uint8|uint16|float32>.raw): " + path);
+    const std::string t = type;
+    const size_t bpv = t == "uint8" ? 1 : (t == "uint16" ? 2 : (t == "float32" ? 4 : 0));
+    if (!bpv) throw std::runtime_error("Unable to load raw volume (voxel type " + t + "): " + path);
+    const size_t n = (size_t)nx * ny * nz;
+    std::vector<uint8_t> raw(n * bpv);
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Unable to read file: " + path);
+    const size_t got = fread(raw.data(), 1, raw.size(), f);
+    fclose(f);
+    if (got != raw.size()) throw std::runtime_error("Unable to load raw volume (file shorter than its name says): " + path);
+    std::vector<float> v(n);
+    if (bpv == 1) for (size_t i = 0; i < n; ++i) v[i] = (float)raw[i] / 255.f;
+    else if (bpv == 2) for (size_t i = 0; i < n; ++i) { uint16_t u; memcpy(&u, &raw[2 * i], 2); v[i] = (float)u / 65535.f; }
+    else memcpy(v.data(), raw.data(), n * 4);
+    return std::make_shared<DenseGrid>(nx, ny, nz, v.data());
+}
+
+// voldata::Volume(path) (main.cpp:44): grid "density" of frame 0 from a file.  This build reads the serialized sparse (.brick)
+// and dense (.dense) grids and headerless .raw volumes; OpenVDB / NanoVDB / DICOM need libraries the image does not have.
 Volume::Volume(const std::string& path) {
     const std::string ext = std::filesystem::path(path).extension().string();
-    if (ext != ".brick")
-        throw std::runtime_error("Unable to load volume (only .brick grids are supported by this build): " + path);
-    add_grid_frame(std::make_shared<BrickGrid>(path), "density");
+    if (ext == ".brick") add_grid_frame(std::make_shared<BrickGrid>(path), "density");
+    else if (ext == ".dense") add_grid_frame(load_dense_file(path), "density");
+    else if (ext == ".raw") add_grid_frame(load_raw_file(path), "density");
+    else throw std::runtime_error("Unable to load volume (this build reads .brick, .dense and .raw grids): " + path);
 }
 
 std::shared_ptr<Volume> Volume::load_folder(const std::string& path) {
     std::vector<std::string> files;
     for (const auto& e : std::filesystem::directory_iterator(path))
-        if (e.is_regular_file() && e.path().extension() == ".brick") files.push_back(e.path().string());
+        if (e.is_regular_file() && (e.path().extension() == ".brick" || e.path().extension() == ".dense" || e.path().extension() == ".raw")) files.push_back(e.path().string());
     std::sort(files.begin(), files.end());
-    if (files.empty()) throw std::runtime_error("Unable to load volume (no .brick files in folder): " + path);
+    if (files.empty()) throw std::runtime_error("Unable to load volume (no .brick / .dense / .raw files in folder): " + path);
     auto vol = std::make_shared<Volume>();
-    for (const auto& f : files) vol->add_grid_frame(std::make_shared<BrickGrid>(f), "density");
+    for (const auto& f : files) vol->add_grid_frame(Volume(f).current_grid(), "density");
     return vol;
 }
 

@@ -86,7 +86,7 @@ struct Volume {
     size_t grid_frame_counter = 0;
 
     Volume() = default;
-    explicit Volume(const std::string& path);                 // single .brick file as frame 0, grid "density"
+    explicit Volume(const std::string& path);                 // single .brick / .dense / .raw file as frame 0, grid "density"
     explicit Volume(const GridPtr& density) { add_grid_frame(density, "density"); }
 
     void clear() { grids.clear(); grid_frame_counter = 0; }
@@ -104,6 +104,9 @@ struct Volume {
     // dense -> brick encoder (a BrickGrid passes through unchanged)
     static std::shared_ptr<BrickGrid> to_brick_grid(const GridPtr& grid);
 };
+
+// this build's ".dense" container (see grids.cpp): u8 voxels, value = lo + u8 / 255 * (hi - lo)
+void write_dense_file(const std::string& path, const mat4& transform, uint32_t nx, uint32_t ny, uint32_t nz, float lo, float hi, const uint8_t* voxels);
 
 uint16_t float_to_half_round_down(float f);   // largest fp16 <= f
 uint16_t float_to_half_round_up(float f);     // smallest fp16 >= f

@@ -82,6 +82,13 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #define VR_NSLOT 152
 #endif
 constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
+// The transfer-function kernels stage the LUT (up to kLutLdsEntries vec4 = 4 KiB) in LDS and give up 16 path slots for it:
+// 4 workgroups x (136 slots x 65 B x 4 wavefronts + 4 KiB) = 154.1 KiB of the CU's 160 KiB.
+#ifndef VR_NSLOT_TF
+#define VR_NSLOT_TF (VR_NSLOT >= 152 ? VR_NSLOT - 16 : VR_NSLOT)
+#endif
+constexpr int32_t kLutLdsEntries = 256;
+template <class K> constexpr int32_t pool_slots() { return K::tf ? VR_NSLOT_TF : VR_NSLOT; }
 
 enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
 
@@ -205,22 +212,32 @@ __global__ void __launch_bounds__(256, VR_WAVES_PER_SIMD)
 pathtrace_kernel(const KernelArgs A) {
     const SceneParams& P = A.P;           // hot pair only; events use event_args()
     const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    constexpr int32_t NS = pool_slots<K>();           // path slots of this kernel's wavefronts (shadows the global maximum below)
 
-    __shared__ uint8_t lds_q[4 * Q_COUNT * NSLOT];
-    uint8_t* const q = lds_q + wave * (Q_COUNT * NSLOT);
+    __shared__ uint8_t lds_q[4 * Q_COUNT * NS];
+    uint8_t* const q = lds_q + wave * (Q_COUNT * NS);
     // per-wavefront slice of the workspace: the cold fields of its NSLOT paths
 #if VR_COLD_LDS
-    __shared__ float lds_cold[4 * COLD_LDS_STRIDE * NSLOT];
-    float* const cold_base = lds_cold + wave * (COLD_LDS_STRIDE * NSLOT);
+    __shared__ float lds_cold[4 * COLD_LDS_STRIDE * NS];
+    float* const cold_base = lds_cold + wave * (COLD_LDS_STRIDE * NS);
 #else
     float* const cold_base = A.cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)kColdWaveFloats;
 #endif
-    __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NSLOT];
-    const HotStore hs{ lds_hot + wave * (HOT_STRIDE * NSLOT) };
+    __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NS];
+    const HotStore hs{ lds_hot + wave * (HOT_STRIDE * NS) };
+    // transfer function: the LUT (tf_size x vec4, 128 B for lut.txt, 4 KiB for a 256-entry colour map) is read twice per
+    // tentative collision; one copy per workgroup in LDS replaces those global gathers.  Larger LUTs stay in global memory.
+    __shared__ float lds_lut[K::tf ? 4 * kLutLdsEntries : 4];
+    const bool lut_in_lds = K::tf && P.u.tf_size <= (uint32_t)kLutLdsEntries;
+    if (K::tf) {
+        if (lut_in_lds)
+            for (uint32_t i = threadIdx.x; i < 4u * P.u.tf_size; i += 256u) lds_lut[i] = P.tf_lut[i];
+        __syncthreads();                              // the only workgroup barrier of the kernel: before the persistent loop
+    }
 
     // scheduler thresholds, one byte each in two scalars: batch sizes that trigger NEW / NEE / POSTNEE / ESCAPE, the low-water
     // mark of live paths ("hungry"), the slots in use (diagnostic cap)
-    const int32_t pool = (A.S.thr[ST_BEGIN] > 0 && A.S.thr[ST_BEGIN] < NSLOT) ? A.S.thr[ST_BEGIN] : NSLOT;
+    const int32_t pool = (A.S.thr[ST_BEGIN] > 0 && A.S.thr[ST_BEGIN] < NS) ? A.S.thr[ST_BEGIN] : NS;
     const uint32_t thr_a = (uint32_t)(A.S.thr[ST_NEW] & 255) | ((uint32_t)(A.S.thr[ST_NEE] & 255) << 8) | ((uint32_t)(A.S.thr[ST_POSTNEE] & 255) << 16) | ((uint32_t)(A.S.thr[ST_ESCAPE] & 255) << 24);
     const uint32_t thr_b = (uint32_t)(A.S.thr[ST_MARCH] & 255) | ((uint32_t)pool << 8);
 #define VR_THR_NEW ((int32_t)(thr_a & 255u))
@@ -230,7 +247,7 @@ pathtrace_kernel(const KernelArgs A) {
 #define VR_THR_HUNGRY ((int32_t)(thr_b & 255u))
 #define VR_POOL ((int32_t)(thr_b >> 8))
     int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = pool;     // stack heights (wave-uniform)
-    for (int32_t i = lane; i < pool; i += 64) q[Q_FREE * NSLOT + i] = (uint8_t)i;
+    for (int32_t i = lane; i < pool; i += 64) q[Q_FREE * NS + i] = (uint8_t)i;
     __builtin_amdgcn_wave_barrier();
 
     WorkUnit wu;                      // current unit; .out is filled in where a sample is written (event_args().sbuf)
@@ -253,7 +270,7 @@ pathtrace_kernel(const KernelArgs A) {
 // push the slots of all lanes where COND holds onto stack QI (wave-synchronous)
 #define VR_PUSH(QI, CNT, COND, SLOTV) do { \
         const uint64_t m_ = __ballot(COND); \
-        if (m_) { if (COND) q[(QI) * NSLOT + (CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(SLOTV); (CNT) += popc(m_); } \
+        if (m_) { if (COND) q[(QI) * NS + (CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(SLOTV); (CNT) += popc(m_); } \
     } while (0)
 
 // route the batch paths to the stack of their new state; an impossible state is reported and the slot recycled
@@ -296,7 +313,7 @@ pathtrace_kernel(const KernelArgs A) {
             if (take > 0) {
                 if (slot < 0) {
                     const int32_t r = (int32_t)lane_rank(idle);
-                    if (r < take) { slot = q[Q_READY * NSLOT + cnt_ready - 1 - r]; hs.load(l, slot); }
+                    if (r < take) { slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load(l, slot); }
                 }
                 cnt_ready -= take;
             }
@@ -328,7 +345,8 @@ pathtrace_kernel(const KernelArgs A) {
             collide_load<K>(P, cio);
             if (is_c) {
                 ColdT c{ cold_base + slot * kColdSlotStride };
-                collide_finish<K>(l, c, P, cio);
+                if (lut_in_lds) collide_finish<K>(l, c, P, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
+                else collide_finish<K>(l, c, P, cio, P.tf_lut);
             }
             // every load of the pass has been consumed or belongs to a lane that left early: say so, or the compiler carries
             // "possibly outstanding" around the loop and waits where nothing is pending
@@ -378,7 +396,7 @@ pathtrace_kernel(const KernelArgs A) {
                 VR_STAT(ST_ESCAPE, n);
                 int32_t bs = -1;
                 if (lane < n) {
-                    bs = q[Q_ESC * NSLOT + cnt_esc - 1 - lane];
+                    bs = q[Q_ESC * NS + cnt_esc - 1 - lane];
                     hs.load(b, bs);
                     ColdT c{ cold_base + bs * kColdSlotStride };
                     const KernelArgs& E = event_args();
@@ -394,7 +412,7 @@ pathtrace_kernel(const KernelArgs A) {
                 VR_STAT(ST_POSTNEE, n);
                 int32_t bs = -1;
                 if (lane < n) {
-                    bs = q[Q_POST * NSLOT + cnt_post - 1 - lane];
+                    bs = q[Q_POST * NS + cnt_post - 1 - lane];
                     hs.load(b, bs);
                     ColdT c{ cold_base + bs * kColdSlotStride };
                     const KernelArgs& E = event_args();
@@ -426,7 +444,7 @@ pathtrace_kernel(const KernelArgs A) {
                     VR_STAT(ST_NEW, n);
                     int32_t bs = -1;
                     if (lane < n) {
-                        bs = q[Q_FREE * NSLOT + cnt_free - 1 - lane];
+                        bs = q[Q_FREE * NS + cnt_free - 1 - lane];
                         hot_init(b);
                         ColdT c{ cold_base + bs * kColdSlotStride };
                         do_new<K>(b, c, event_args().P, wu, cursor + (uint32_t)lane);
@@ -443,7 +461,7 @@ pathtrace_kernel(const KernelArgs A) {
                 VR_STAT(ST_NEE, n);
                 int32_t bs = -1;
                 if (lane < n) {
-                    bs = q[Q_NEE * NSLOT + cnt_nee - 1 - lane];
+                    bs = q[Q_NEE * NS + cnt_nee - 1 - lane];
                     hs.load(b, bs);
                     ColdT c{ cold_base + bs * kColdSlotStride };
                     do_nee<K>(b, c, event_args().P);

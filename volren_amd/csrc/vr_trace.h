@@ -362,8 +362,8 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
 }
 
 // transfer function (common.glsl:203-212)
-VR_HD void tf_lookup(const SceneParams& P, float d, float rgba[4]) {
-    const Uniforms& u = P.u;
+// `lut`: tf_size x vec4 -- the SSBO in global memory, or the copy the path-tracing kernel stages in LDS (vr_pathtrace.h)
+VR_HD void tf_lookup_at(const Uniforms& u, const float* lut, float d, float rgba[4]) {
     const float tc = clamp_((d - u.tf_window_left) / u.tf_window_width, 0.0f, 1.0f - 1e-6f);
     const float tcs = tc * (float)u.tf_size;
     int32_t idx = floor2i(tcs);
@@ -372,11 +372,12 @@ VR_HD void tf_lookup(const SceneParams& P, float d, float rgba[4]) {
     if (idx == kIntMin) idx = 0;
     idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
     const int32_t idx1 = idx + 1 < n - 1 ? idx + 1 : n - 1;
-    const float* a = P.tf_lut + 4 * idx;
-    const float* b = P.tf_lut + 4 * idx1;
+    const float* a = lut + 4 * idx;
+    const float* b = lut + 4 * idx1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) rgba[k] = mix_(a[k], b[k], f);
 }
+VR_HD void tf_lookup(const SceneParams& P, float d, float rgba[4]) { tf_lookup_at(P.u, P.tf_lut, d, rgba); }
 
 // ---------------------------------------------------------------------------------------------------
 // environment (common.glsl:93-152)
@@ -703,14 +704,14 @@ VR_HD void collide_load(const SceneParams& P, CollideIO<K>& io) {      // uncond
     if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) io.ed = tap_load<2>(P.emission, io.ea);
 }
 template <class K, class Cold>
-VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO<K>& io) {
+VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO<K>& io, const float* tf_lut) {
     constexpr bool USE_TF = K::tf;
     const Uniforms& u = P.u;
     const bool global = K::global == 2 ? u.integrator != 0 : K::global == 1;
     float d;
     float rgba[4] = { 0, 0, 0, 0 };
     if (USE_TF) {
-        tf_lookup(P, (u.vol_density_scale * trilinear_value<K::dense>(P.density, io.tri)) * u.vol_inv_majorant, rgba);
+        tf_lookup_at(u, tf_lut, (u.vol_density_scale * trilinear_value<K::dense>(P.density, io.tri)) * u.vol_inv_majorant, rgba);
         d = u.vol_majorant * rgba[3];
     } else {
         d = u.vol_density_scale * tap_value<K::dense>(P.density, io.d, io.a.in);
@@ -766,7 +767,7 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
     CollideIO<K> io;
     collide_prep<K>(h, P, io);
     collide_load<K>(P, io);
-    collide_finish<K>(h, c, P, io);
+    collide_finish<K>(h, c, P, io, P.tf_lut);
 }
 
 // real collision: common.glsl:611-626 up to (and including the set-up of) the transmittance call

@@ -72,6 +72,20 @@ class Renderer:
     def load_volume(self, path):
         _lib.check(self._L.vr_load_volume(self._h, str(path).encode()))
 
+    def set_volume_path(self, path):
+        """`renderer.volume = Volume(path)` of the reference's Python module: replaces the volume only (no commit)."""
+        _lib.check(self._L.vr_set_volume_path(self._h, str(path).encode()))
+
+    def volume_aabb(self, name="density"):
+        out = (C.c_float * 6)()
+        _lib.check(self._L.vr_volume_aabb(self._h, name.encode(), out))
+        return np.array(out[:3], np.float32), np.array(out[3:], np.float32)
+
+    def volume_minorant_majorant(self, name="density"):
+        out = (C.c_float * 2)()
+        _lib.check(self._L.vr_volume_minorant_majorant(self._h, name.encode(), out))
+        return float(out[0]), float(out[1])
+
     def load_envmap(self, path):
         _lib.check(self._L.vr_load_envmap(self._h, str(path).encode()))
 

@@ -1,43 +1,157 @@
-"""volpy -- the reference's embedded Python module (src/bindings.cpp:64-209) on top of libvolren_amd.so.
+"""volpy -- the reference's embedded Python module (src/bindings.cpp:64-417) on top of libvolren_amd.so.
 
 `import volren_amd.volpy as volpy` gives scripts written against the reference (`scripts/datagen_colmap.py`,
-`scripts/datagen_denoise.py`) the same classes and members: `Renderer`, `Volume`, `Environment`, `TransferFunction`,
-`vec3/vec4`.  Differences, all forced by running without a GL window:
-  * the resolution is a constructor argument (`Renderer(w, h)`, default 1024x1024) instead of the GL context's size
-    (`-w/-h` of the embedding executable); `Renderer.resolution()` returns it,
+`scripts/datagen_denoise.py`) the same classes, members and CALL PROTOCOL: assigning `renderer.volume` only replaces the
+volume; `scale_and_move_to_unit_cube()` multiplies the density scale the caller has set (renderer.cpp:227-242); `commit()`
+uploads the grids.  `vec2/vec3/vec4/quat` are small glm-like value types (`.x .y .z`, arithmetic, `.length()`,
+`.normalize()`, buffer access through `np.array(v)`), `Volume.AABB(name)` returns two of them, `resolution()` has `.x/.y`.
+Differences, all forced by running without a GL window:
+  * the resolution is a constructor argument (`Renderer(w, h)`, default 1024x1024; the reference takes the GL context's,
+    i.e. `-w/-h` of the embedding executable),
   * the camera members are per renderer (the reference exposes the global cppgl camera as class statics),
   * `draw()` tonemaps into an off-screen buffer; `save()` / `save_with_alpha()` write that buffer (they read the window in
     the reference, so call `draw()` first exactly like the reference scripts do: datagen_colmap.py:90-94),
-  * `shutdown()` does not `exit(0)`.
+  * `shutdown()` does not `exit(0)`,
+  * `TransferFunction.randomize()` draws from Python's `random` (the reference from C `rand()`): seedable from the script.
 """
 import math
 import os
+import random as _random
 
 import numpy as np
 
 from .renderer import Renderer as _Renderer
 
 
-def vec3(x=0.0, y=None, z=None):
-    if y is None:
-        y = z = x
-    return np.array([x, y, z], np.float32)
+# ---- glm-like value types (bindings.cpp:13-62, 215-416) ------------------------------------------------------------------
+class _Vec:
+    """float32 vector with glm's operator set: component-wise + - * / with a vector of the same size or a scalar."""
+    __slots__ = ("v",)
+    _n = 0
+    _dtype = np.float32
+
+    def __init__(self, *args):
+        n = self._n
+        if len(args) == 0:
+            self.v = np.zeros(n, self._dtype)
+        elif len(args) == 1 and np.ndim(args[0]) == 0 and not isinstance(args[0], _Vec):
+            self.v = np.full(n, args[0], self._dtype)
+        elif len(args) == 1:
+            a = np.asarray(args[0].v if isinstance(args[0], _Vec) else args[0], self._dtype).reshape(-1)
+            if a.size != n:
+                raise TypeError("%s from %d components" % (type(self).__name__, a.size))
+            self.v = a.copy()
+        elif len(args) == n:
+            self.v = np.array(args, self._dtype)
+        else:
+            raise TypeError("%s(): %d arguments" % (type(self).__name__, len(args)))
+
+    def _other(self, o):
+        if isinstance(o, _Vec):
+            if o._n != self._n:
+                raise TypeError("vector sizes differ")
+            return o.v
+        if np.ndim(o) == 0:
+            return self._dtype(o)
+        a = np.asarray(o, self._dtype).reshape(-1)
+        if a.size != self._n:
+            raise TypeError("vector sizes differ")
+        return a
+
+    def _new(self, a):
+        r = type(self).__new__(type(self))
+        r.v = np.asarray(a, self._dtype)
+        return r
+
+    def __add__(self, o): return self._new(self.v + self._other(o))
+    def __radd__(self, o): return self._new(self._other(o) + self.v)
+    def __sub__(self, o): return self._new(self.v - self._other(o))
+    def __rsub__(self, o): return self._new(self._other(o) - self.v)
+    def __mul__(self, o): return self._new(self.v * self._other(o))
+    def __rmul__(self, o): return self._new(self._other(o) * self.v)
+    def __truediv__(self, o): return self._new(self.v / self._other(o))
+    def __rtruediv__(self, o): return self._new(self._other(o) / self.v)
+    def __neg__(self): return self._new(-self.v)
+
+    def __iadd__(self, o): self.v = (self.v + self._other(o)).astype(self._dtype); return self
+    def __isub__(self, o): self.v = (self.v - self._other(o)).astype(self._dtype); return self
+    def __imul__(self, o): self.v = (self.v * self._other(o)).astype(self._dtype); return self
+    def __itruediv__(self, o): self.v = (self.v / self._other(o)).astype(self._dtype); return self
+
+    def length(self):
+        return float(np.sqrt(np.float32((self.v * self.v).sum(dtype=np.float32))))
+
+    def normalize(self):
+        return self._new(self.v / np.float32(self.length()))
+
+    def __array__(self, dtype=None, copy=None):
+        return self.v.astype(dtype) if dtype is not None else self.v.copy()
+
+    def __len__(self): return self._n
+    def __iter__(self): return iter(self.v.tolist())
+    def __getitem__(self, i): return self.v[i].item() if np.ndim(self.v[i]) == 0 else self.v[i]
+    def __setitem__(self, i, x): self.v[i] = x
+    def __eq__(self, o): return isinstance(o, _Vec) and o._n == self._n and bool(np.array_equal(self.v, o.v))
+    def __hash__(self): return hash(self.v.tobytes())
+    def __repr__(self): return "%s(%s)" % (type(self).__name__, ", ".join("%f" % c for c in self.v))
 
 
-def vec4(x=0.0, y=None, z=None, w=None):
-    if y is None:
-        y = z = w = x
-    return np.array([x, y, z, w], np.float32)
+def _component(i):
+    return property(lambda s: s.v[i].item(), lambda s, x: s.v.__setitem__(i, x))
 
 
+class vec2(_Vec):
+    __slots__ = ()
+    _n = 2
+    x, y = _component(0), _component(1)
+
+
+class vec3(_Vec):
+    __slots__ = ()
+    _n = 3
+    x, y, z = _component(0), _component(1), _component(2)
+
+
+class vec4(_Vec):
+    __slots__ = ()
+    _n = 4
+    x, y, z, w = _component(0), _component(1), _component(2), _component(3)
+
+
+class ivec2(_Vec):
+    __slots__ = ()
+    _n = 2
+    _dtype = np.int32
+    x, y = _component(0), _component(1)
+
+
+class quat(_Vec):
+    """glm::quat; memory order (x, y, z, w) like glm's default, so `np.array(q)[[3, 0, 1, 2]]` is (w, x, y, z)
+    (datagen_colmap.py:94).  Constructor order (w, x, y, z) as in glm."""
+    __slots__ = ()
+    _n = 4
+    x, y, z, w = _component(0), _component(1), _component(2), _component(3)
+
+    def __init__(self, *args):
+        if len(args) == 4:
+            w, x, y, z = args
+            _Vec.__init__(self, x, y, z, w)
+        elif len(args) == 0:
+            _Vec.__init__(self, 0.0, 0.0, 0.0, 1.0)
+        else:
+            _Vec.__init__(self, *args)
+
+
+# ---- scene objects -------------------------------------------------------------------------------------------------------
 class Volume:
-    """voldata::Volume: `Volume(path)` (a .brick file or a folder of frames) or `Volume(w, h, d, data)` (dense float32 or
-    uint8 voxels, x fastest)."""
+    """voldata::Volume as bound by bindings.cpp:82-95: `Volume()`, `Volume(path)` (a .brick file or a folder of frames) or
+    `Volume(w, h, d, data)` (dense float32 or uint8 voxels, x fastest)."""
 
     def __init__(self, *args):
         self.path = None
         self.dense = None
-        self.grid_frame_counter = 0
+        self._owner = None
+        self._frame = 0
         if len(args) == 1:
             self.path = os.fspath(args[0])
         elif len(args) == 4:
@@ -47,6 +161,38 @@ class Volume:
             self.dense = np.ascontiguousarray(a).reshape(int(d), int(h), int(w))
         elif args:
             raise TypeError("Volume(), Volume(path) or Volume(w, h, d, data)")
+
+    def _need_owner(self, what):
+        if self._owner is None:
+            raise RuntimeError("Volume.%s: assign the volume to a Renderer first (the grids live in the HIP library)" % what)
+        return self._owner._r
+
+    def AABB(self, name="density"):
+        """World-space bounding box (bb_min, bb_max) of the current frame's grid `name` under the volume transform."""
+        lo, hi = self._need_owner("AABB").volume_aabb(name)
+        return vec3(lo), vec3(hi)
+
+    def minorant_majorant(self, name="density"):
+        return self._need_owner("minorant_majorant").volume_minorant_majorant(name)
+
+    def clear(self):
+        self.path, self.dense = None, None
+
+    def load_grid(self, path):
+        """Replaces the volume by the grid file `path` (takes effect at the next assignment / commit)."""
+        self.path, self.dense = os.fspath(path), None
+        if self._owner is not None:
+            self._owner._attach_volume(self)
+
+    @property
+    def grid_frame_counter(self):
+        return self._frame
+
+    @grid_frame_counter.setter
+    def grid_frame_counter(self, v):
+        self._frame = int(v)
+        if self._owner is not None and self._owner._committed:
+            self._owner._r.grid_frame_counter = self._frame
 
     def __repr__(self):
         return "Volume(%s)" % (self.path if self.path else ("dense %s" % (self.dense.shape,) if self.dense is not None else "empty"))
@@ -70,17 +216,28 @@ class Environment:
 
 
 class TransferFunction:
+    """TransferFunction(), (path) or (list of vec4) -- transferfunc.h:9-42 as bound by bindings.cpp:104-112."""
+
     def __init__(self, arg=None):
         self.path = None
         self.lut = None
         self._owner = None
         self._left, self._width = 0.0, 1.0
         if arg is None:
-            self.lut = np.stack([np.linspace(0, 1, 8, dtype=np.float32)] * 4, 1)   # deterministic ramp (reference: random)
+            self.randomize()                              # the reference's default constructor randomizes too (transferfunc.cpp:7-9)
         elif isinstance(arg, (str, os.PathLike)):
             self.path = os.fspath(arg)
         else:
-            self.lut = np.asarray(arg, np.float32).reshape(-1, 4)
+            self.lut = np.asarray([np.asarray(v, np.float32) for v in arg], np.float32).reshape(-1, 4)
+
+    def randomize(self, n_bins=8):
+        """transferfunc.cpp:62-67: bin 0 is all zero, the others uniform random RGBA."""
+        lut = np.zeros((int(n_bins), 4), np.float32)
+        for i in range(1, int(n_bins)):
+            lut[i] = [_random.random() for _ in range(4)]
+        self.lut, self.path = lut, None
+        if self._owner is not None:
+            self._owner._upload_transferfunc(self)
 
     def _apply(self, which, v):
         setattr(self, which, float(v))
@@ -91,9 +248,9 @@ class TransferFunction:
     window_width = property(lambda s: s._width, lambda s, v: s._apply("_width", v))
 
 
-_FIELDS = ("sample", "sppx", "bounces", "seed", "tonemap_exposure", "tonemap_gamma", "tonemapping", "show_environment",
-           "albedo", "phase", "density_scale", "emission_scale", "vol_clip_min", "vol_clip_max",
-           "cam_pos", "cam_dir", "cam_up", "cam_fov")
+_SCALARS = ("sample", "sppx", "bounces", "seed", "tonemap_exposure", "tonemap_gamma", "tonemapping", "show_environment",
+            "phase", "density_scale", "emission_scale", "cam_fov")
+_VEC3S = ("albedo", "vol_clip_min", "vol_clip_max", "cam_pos", "cam_dir", "cam_up")
 
 
 class Renderer:
@@ -104,16 +261,21 @@ class Renderer:
         object.__setattr__(self, "_volume", None)
         object.__setattr__(self, "_environment", None)
         object.__setattr__(self, "_transferfunc", None)
+        object.__setattr__(self, "_committed", False)
 
     # -- fields ------------------------------------------------------------------------------------------------------
     def __getattr__(self, name):
-        if name in _FIELDS:
+        if name in _SCALARS:
             return getattr(self._r, name)
+        if name in _VEC3S:
+            return vec3(getattr(self._r, name))
         raise AttributeError(name)
 
     def __setattr__(self, name, value):
-        if name in _FIELDS:
+        if name in _SCALARS:
             setattr(self._r, name, value)
+        elif name in _VEC3S:
+            setattr(self._r, name, np.asarray(vec3(value) if np.ndim(value) == 0 else value, np.float32).reshape(3))
         elif name in ("volume", "environment", "transferfunc"):
             getattr(self, "_set_" + name)(value)
         else:
@@ -123,9 +285,22 @@ class Renderer:
     environment = property(lambda s: s._environment)
     transferfunc = property(lambda s: s._transferfunc)
 
+    def _attach_volume(self, v):
+        # like `renderer->volume = ...` in the reference: replaces the volume object only.  density_scale, the unit-cube
+        # transform and the device grids change in scale_and_move_to_unit_cube() / commit(), in the caller's order.
+        if v.path:
+            self._r.set_volume_path(v.path)
+        elif v.dense is not None:
+            self._r.set_volume_dense(v.dense, unit_cube=False, commit=False)
+        else:
+            raise RuntimeError("Renderer.volume: empty Volume")
+        object.__setattr__(self, "_committed", False)
+
     def _set_volume(self, v):
-        # assignment only stores the volume; like the reference the grids reach the device in commit()
         object.__setattr__(self, "_volume", v)
+        if v is not None:
+            v._owner = self
+            self._attach_volume(v)
 
     def _set_environment(self, e):
         object.__setattr__(self, "_environment", e)
@@ -133,43 +308,39 @@ class Renderer:
         e._owner = self
         self._r.env_strength = e.strength
 
-    def _set_transferfunc(self, t):
-        object.__setattr__(self, "_transferfunc", t)
-        if t is None:
-            self._r.set_transferfunc(None)
-            return
+    def _upload_transferfunc(self, t):
         if t.path:
             show = self._r.show_environment
             self._r.load_transferfunc(t.path)
             self._r.show_environment = show          # only main.cpp's loader hides the environment, not the binding
         else:
             self._r.set_transferfunc(t.lut)
-        t._owner = self
         self._r.tf_window_left, self._r.tf_window_width = t.window_left, t.window_width
+
+    def _set_transferfunc(self, t):
+        object.__setattr__(self, "_transferfunc", t)
+        if t is None:
+            self._r.set_transferfunc(None)
+            return
+        t._owner = self
+        self._upload_transferfunc(t)
 
     # -- methods -----------------------------------------------------------------------------------------------------
     def init(self):
         pass                                          # the HIP renderer is initialised by its constructor
 
     def scale_and_move_to_unit_cube(self):
-        object.__setattr__(self, "_unit_cube", True)
+        """renderer.cpp:227-242: volume.transform = scale(1/size) o translate(...), density_scale *= size."""
+        if self._volume is None:
+            raise RuntimeError("Renderer.scale_and_move_to_unit_cube: no volume")
+        self._r.scale_and_move_to_unit_cube()
 
     def commit(self):
-        v = self._volume
-        if v is None:
+        if self._volume is None:
             raise RuntimeError("Renderer.commit: no volume")
-        unit = bool(getattr(self, "_unit_cube", False))
-        ds = self._r.density_scale
-        if v.path:
-            self._r.load_volume(v.path)               # = Volume(path) + density_scale=1 + unit cube + commit (main.cpp:37-62)
-            if not unit:
-                raise RuntimeError("volpy on HIP: call scale_and_move_to_unit_cube() before commit() for file volumes")
-        else:
-            self._r.set_volume_dense(v.dense, unit_cube=unit, commit=True)
-        if not unit:
-            self._r.density_scale = ds
-        self._r.grid_frame_counter = int(v.grid_frame_counter)
-        object.__setattr__(self, "_unit_cube", False)
+        self._r.commit()
+        object.__setattr__(self, "_committed", True)
+        self._r.grid_frame_counter = int(self._volume.grid_frame_counter)
 
     def trace(self):
         self._r.trace()
@@ -182,10 +353,11 @@ class Renderer:
         self._r.render(int(spp))
 
     def draw(self):
-        self._r.draw()
+        if self._committed:
+            self._r.draw()                            # before the first commit there is nothing to show (the reference clears the window)
 
     def resolution(self):
-        return (self._r.width, self._r.height)
+        return ivec2(self._r.width, self._r.height)
 
     def fbo_data(self):
         """Float RGB of the accumulation buffer with the reference's declared buffer shape (w, h, 3) (bindings.cpp:69-77,143)."""
@@ -224,16 +396,17 @@ class Renderer:
 
     def colmap_view_trans(self):
         g = np.diag([1.0, -1.0, -1.0, 1.0])
-        return (g @ self._view())[:3, 3].astype(np.float32)
+        return vec3((g @ self._view())[:3, 3])
 
     def colmap_view_rot(self):
+        """glm::normalize(glm::toQuat(GL_TO_COLMAP * view)) as a `quat` (memory order x, y, z, w)."""
         m = (np.diag([1.0, -1.0, -1.0, 1.0]) @ self._view())[:3, :3]
         w = math.sqrt(max(0.0, 1.0 + m[0, 0] + m[1, 1] + m[2, 2])) / 2.0
         x = math.copysign(math.sqrt(max(0.0, 1.0 + m[0, 0] - m[1, 1] - m[2, 2])) / 2.0, m[2, 1] - m[1, 2])
         y = math.copysign(math.sqrt(max(0.0, 1.0 - m[0, 0] + m[1, 1] - m[2, 2])) / 2.0, m[0, 2] - m[2, 0])
         z = math.copysign(math.sqrt(max(0.0, 1.0 - m[0, 0] - m[1, 1] + m[2, 2])) / 2.0, m[1, 0] - m[0, 1])
-        q = np.array([w, x, y, z])
-        return (q / np.linalg.norm(q)).astype(np.float32)         # (w, x, y, z)
+        n = math.sqrt(w * w + x * x + y * y + z * z)
+        return quat(w / n, x / n, y / n, z / n)
 
     def colmap_focal_length(self):
         return self._r.height / (2.0 * math.tan(0.5 * math.radians(self._r.cam_fov)))
