@@ -205,7 +205,9 @@ class Bench:
             self.frame = 0
             self.step()
             self.barrier()
-        last_ms = self.slots[(self.frame - 1) % len(self.slots)]["r"].last_kernel_ms()                                       # HIP events on the renderer's stream around the last frame's launches
+        last_r = self.slots[(self.frame - 1) % len(self.slots)]["r"]
+        pt_ms = last_r.last_pathtrace_ms()                                      # HIP events around the path-tracing kernel alone (last sub-launch)
+        last_ms = last_r.last_kernel_ms()                                       # HIP events on the renderer's stream around the last frame's launches
         if self.world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if not self.staged else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -213,7 +215,7 @@ class Bench:
         samples = float(self.w) * self.h * self.spp
         launches = max(1, self.slots[(self.frame - 1) % len(self.slots)]["r"].last_launches)                                 # a frame is split so that a sub-launch fits the sample pool
         my_samples = len(self.shard.mine) * 256.0 * self.spp if self.world > 1 else samples
-        return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=last_ms / launches,
+        return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=pt_ms if pt_ms > 0 else last_ms / launches, frame_gpu_ms=last_ms,
                     launches=launches, samples_per_launch=my_samples / launches)
 
     def roofline(self, m, counters):

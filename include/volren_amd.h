@@ -102,6 +102,8 @@ int vr_render(vr_renderer* r, int spp);
 int vr_synchronize(vr_renderer* r);
 /* duration of the last path-tracing launch in ms, measured with HIP events on the renderer's stream (waits for it) */
 int vr_last_kernel_ms(vr_renderer* r, double* ms);
+/* duration of the path-tracing kernel alone (last sub-launch of the last vr_trace / vr_render; without the accumulation pass) */
+int vr_last_pathtrace_ms(vr_renderer* r, double* ms);
 
 /* --- results.  vr_framebuffer = fbo_data() without the alpha drop (src/bindings.cpp:141-148): W*H*4 floats, row 0 bottom.
  *     vr_draw = RendererOpenGL::draw (src/renderer.cpp:147-153) into a separate tonemapped buffer (shader/tonemap.glsl);

@@ -354,6 +354,12 @@ int vr_last_kernel_ms(vr_renderer* r, double* ms) {
     return guard([&] { use_device(r); *ms = r->impl.last_kernel_ms(); });
 }
 
+int vr_last_pathtrace_ms(vr_renderer* r, double* ms) {
+    NEED(r);
+    if (!ms) return fail(VR_ERR_ARG, "null output");
+    return guard([&] { use_device(r); *ms = r->impl.last_pathtrace_ms(); });
+}
+
 int vr_framebuffer(vr_renderer* r, float* out) {
     NEED(r);
     if (!out) return fail(VR_ERR_ARG, "null argument");

@@ -28,6 +28,8 @@ mat3 Camera::view_inverse() const {
 RendererHIP::~RendererHIP() {
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
+    if (ev2_) (void)hipEventDestroy(ev2_);
+    if (ev3_) (void)hipEventDestroy(ev3_);
 }
 
 void RendererHIP::init() {
@@ -39,7 +41,17 @@ void RendererHIP::init() {
         const float white[3] = { 1.f, 1.f, 1.f };             // renderer.cpp:36-38: 1x1 white background
         environment = std::make_shared<Environment>(white, 1, 1);
     }
-    if (!ev0_) { VR_HIP(hipEventCreate(&ev0_)); VR_HIP(hipEventCreate(&ev1_)); }
+    if (!ev0_) { VR_HIP(hipEventCreate(&ev0_)); VR_HIP(hipEventCreate(&ev1_)); VR_HIP(hipEventCreate(&ev2_)); VR_HIP(hipEventCreate(&ev3_)); }
+    if (const char* m = getenv("VR_DIAG_CU_FRACTION")) {
+        // diagnostic: render on a stream restricted to every n-th CU (n = VR_DIAG_CU_FRACTION) -- separates per-CU limits
+        // (throughput ~ 1/n) from chip-wide ones (L2 / Infinity Fabric: throughput falls by less)
+        const int n = atoi(m);
+        if (n > 1 && !stream) {
+            uint32_t mask[8];
+            for (int w = 0; w < 8; ++w) { mask[w] = 0u; for (int b = 0; b < 32; ++b) if (((w * 32 + b) % n) == 0) mask[w] |= 1u << b; }
+            VR_HIP(hipExtStreamCreateWithCUMask(&stream, 8, mask));
+        }
+    }
     if (!status_) {
         status_ = make_device_buffer(16 * sizeof(uint32_t));         // [0] watchdog flag, [1..8] work-queue heads (one per XCD segment)
         VR_HIP(hipMemset(status_->get(), 0, 16 * sizeof(uint32_t)));
@@ -415,7 +427,8 @@ void RendererHIP::launch(int n) {
     for (int done = 0; done < n; done += per_launch) {
         ++last_launches;
         const int m = std::min(per_launch, n - done);
-        launch_pathtrace(P, color->as<float>(), pool_->as<float>(), workspace_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, sample + 1 + done, m, status_->as<uint32_t>(), stream, fast_math);
+        launch_pathtrace(P, color->as<float>(), pool_->as<float>(), workspace_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, sample + 1 + done, m, status_->as<uint32_t>(), stream, fast_math,
+                         done + per_launch >= n ? ev2_ : nullptr, done + per_launch >= n ? ev3_ : nullptr);      // the last sub-launch's kernel alone
         VR_HIP(hipGetLastError());
     }
     VR_HIP(hipEventRecord(ev1_, stream));
@@ -446,10 +459,15 @@ double RendererHIP::last_kernel_ms() {
         float ms = 0.f;
         VR_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
         last_ms_ = (double)ms;
+        last_pathtrace_ms_ = 0.0;
+        if (hipEventQuery(ev3_) == hipSuccess && hipEventElapsedTime(&ms, ev2_, ev3_) == hipSuccess) last_pathtrace_ms_ = (double)ms;
+        (void)hipGetLastError();
         timing_pending_ = false;
     }
     return last_ms_;
 }
+
+double RendererHIP::last_pathtrace_ms() { (void)last_kernel_ms(); return last_pathtrace_ms_; }
 
 void RendererHIP::synchronize() const { VR_HIP(hipStreamSynchronize(stream)); }
 

@@ -119,7 +119,8 @@ struct RendererHIP {
     void download(float* rgba) const;                          // color -> host
     void download_display(float* rgba) const;
     void synchronize() const;
-    double last_kernel_ms();                                    // HIP-event time of the last launch (waits for it)
+    double last_kernel_ms();                                    // HIP-event time of the last trace()/render(): all sub-launches, path tracing + accumulation (waits for it)
+    double last_pathtrace_ms();                                 // HIP-event time of the path-tracing kernel of the last sub-launch alone (0 for integrators 2 / 3)
     uint32_t watchdog_status();
     ~RendererHIP();
 
@@ -131,8 +132,8 @@ private:
     DeviceBufferPtr status_;
     DeviceBufferPtr pool_;
     DeviceBufferPtr workspace_;
-    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
-    double last_ms_ = 0.0;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev2_ = nullptr, ev3_ = nullptr;
+    double last_ms_ = 0.0, last_pathtrace_ms_ = 0.0;
     bool timing_pending_ = false;
     // majorant cache key
     struct MajKey { float density_scale = -1.f; uint64_t tf_version = ~0ull; float wl = 0, ww = 0; size_t frame = ~(size_t)0; } maj_key_;   // tf_version: TransferFunction::version (unique per upload), 0 = no LUT

@@ -16,7 +16,8 @@ namespace vr {
 size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples);
 size_t pathtrace_workspace_floats();      // cold path state of all resident wavefronts
 void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
-                      int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math = false);
+                      int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math = false,
+                      hipEvent_t ev_kernel_begin = nullptr, hipEvent_t ev_kernel_end = nullptr);      // optional: bracket the path-tracing kernel alone
 // fast_math: the opt-in tolerance-mode kernels (hardware transcendentals, reciprocal division; vr_math.h VR_FAST_MATH); the default
 // kernels are bit-identical to the CPU oracle
 

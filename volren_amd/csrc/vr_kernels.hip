@@ -141,7 +141,7 @@ static int resident_blocks(int mode, int variant, bool tf, bool stats) {
 size_t pathtrace_workspace_floats() { return (size_t)kMaxWorkgroups * 4u * (kColdWaveFloats > 0 ? kColdWaveFloats : 4); }      // cold state of 4 wavefronts per resident workgroup
 
 void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
-                      int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math) {
+                      int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math, hipEvent_t ev_kernel_begin, hipEvent_t ev_kernel_end) {
     if (n_tiles <= 0 || n_samples <= 0) return;
     tuning_from_env();
     SchedParams S = g_sched;
@@ -170,7 +170,9 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
         hipLaunchKernelGGL(raymarch_kernel, dim3((unsigned)((items + 255) / 256)), block, 0, stream, P, sample_pool, D);
     } else {
         (void)hipMemsetAsync(unit_counter, 0, kQueueSegments * sizeof(uint32_t), stream);
+        if (ev_kernel_begin) (void)hipEventRecord(ev_kernel_begin, stream);
         kPtLaunch[mode][variant](tf, stats, grid.x, stream, &P, sample_pool, workspace, &D, &S, status, g_stats);
+        if (ev_kernel_end) (void)hipEventRecord(ev_kernel_end, stream);
     }
     hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)n_tiles), block, 0, stream, sample_pool, fb, tiles, n_tiles,
                        P.u.resolution[0], P.u.resolution[1], first_sample, n_samples, D.spu);

@@ -120,13 +120,12 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         h.majorant = 0.0f;
     }
 };
-// Cold path state of one wavefront in global memory, group-major: the six 16-byte field groups (vr_trace.h ColdField) are six
-// arrays of NSLOT entries, [group][slot][4].  An event reads or writes a few groups for up to 64 arbitrary slots: with this
-// layout one such access touches the <= 19 cache lines that hold a group's 152 entries, instead of 64 lines (one per slot) in
-// a slot-major layout -- the kernel is bound by L1 (TCP) accesses, profiles/r2i_pmc_c2_tcp.txt -- and successive groups go
-// to different lines, so their misses overlap instead of queueing on one pending line.
+// Cold path state of one wavefront in global memory: one 128-byte line per path slot (slot-major).  Measured alternative
+// (VR_COLD_SOA=1: group-major, [group][slot][4], an event's access then touches the <= 19 lines that hold a group's 152
+// entries instead of 64 lines): same speed, but MORE memory-side traffic -- a batch of ~45 slots drags in every line of every
+// group it touches (634 vs 585 B per sample on c2, profiles/r2_hbm_traffic.json) -- so slot-major stays.
 #ifndef VR_COLD_SOA
-#define VR_COLD_SOA 1
+#define VR_COLD_SOA 0
 #endif
 #ifndef VR_COLD_NT
 #define VR_COLD_NT 0               // experiment: non-temporal cold-state accesses

@@ -172,6 +172,12 @@ class Renderer:
         _lib.check(self._L.vr_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def last_pathtrace_ms(self):
+        """HIP-event duration of the path-tracing kernel alone (last sub-launch; no accumulation pass)."""
+        ms = C.c_double()
+        _lib.check(self._L.vr_last_pathtrace_ms(self._h, C.byref(ms)))
+        return ms.value
+
     def framebuffer(self):
         """RGBA32F [H][W][4], row 0 = bottom (GL order)."""
         out = np.empty((self.height, self.width, 4), np.float32)
