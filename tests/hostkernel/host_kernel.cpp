@@ -16,7 +16,8 @@ namespace {
 struct HostGrid {
     std::vector<BrickRec> recs;
     std::vector<uint8_t> atlas;
-    std::vector<float> majorant;
+    std::vector<float> majorant, rng;
+    std::vector<uint16_t> majorant16;
     GridView view{};
 };
 
@@ -50,6 +51,7 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
     }
     const uint32_t k = (uint32_t)(g.view.mshift[0] + g.view.mshift[1] + g.view.mshift[2]);
     g.majorant.assign(majorant_padded_cells(k), 0.0f);
+    g.majorant16.assign(majorant_padded_cells(k), 0);
     if (density) {
         SceneParams P{}; P.u = u; P.tf_lut = lut;
         for (int mip = 0; mip <= n_mips; ++mip) {            // == majorant_kernel of vr_kernels.hip
@@ -57,13 +59,18 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
             const uint32_t dx = (nb[0] + rnd) >> mip, dy = (nb[1] + rnd) >> mip, dz = (nb[2] + rnd) >> mip;
             const uint32_t sxm = (uint32_t)g.view.mshift[0] - mip, sym = (uint32_t)g.view.mshift[1] - mip;
             for (uint32_t cz = 0; cz < dz; ++cz) for (uint32_t cy = 0; cy < dy; ++cy) for (uint32_t cx = 0; cx < dx; ++cx) {
-                float m = u.vol_density_scale * half2float(words[mip_off[mip] + ((size_t)cz * dy + cy) * dx + cx] >> 16);
+                const uint32_t hw = words[mip_off[mip] + ((size_t)cz * dy + cy) * dx + cx] >> 16;
+                g.majorant16[majorant_level_offset(k, mip) + (((cz << sym) + cy) << sxm) + cx] = (uint16_t)hw;
+                float m = u.vol_density_scale * half2float(hw);
                 if (u.use_tf) { float rgba[4]; tf_lookup(P, m * u.vol_inv_majorant, rgba); m = u.vol_majorant * rgba[3]; }
                 g.majorant[majorant_level_offset(k, mip) + (((cz << sym) + cy) << sxm) + cx] = m;
             }
         }
     }
+    g.rng.resize(g.recs.size() * 2);
+    for (size_t i = 0; i < g.recs.size(); ++i) { g.rng[2 * i] = g.recs[i].rmin; g.rng[2 * i + 1] = g.recs[i].rdiff; }
     g.view.bricks = g.recs.data(); g.view.atlas = g.atlas.data(); g.view.majorant = g.majorant.data();
+    g.view.majorant16 = g.majorant16.data(); g.view.rng = g.rng.data();
     for (int i = 0; i < 3; ++i) g.view.nb[i] = (int32_t)nb[i];
     g.view.n_mips = n_mips;
 }
@@ -109,23 +116,23 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
             P.emission_from_density[4 * c + r] = a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1] + a[8 + r] * b[4 * c + 2] + a[12 + r] * b[4 * c + 3];
     }
     P.tf_lut = lut;
-    std::vector<float> env((size_t)env_w * env_h * 4);
-    for (size_t i = 0; i < (size_t)env_w * env_h; ++i) { env[4 * i] = env_rgb[3 * i]; env[4 * i + 1] = env_rgb[3 * i + 1]; env[4 * i + 2] = env_rgb[3 * i + 2]; env[4 * i + 3] = 1.f; }
+    std::vector<float> env((size_t)env_w * env_h * kEnvTexelFloats);
+    for (size_t i = 0; i < (size_t)env_w * env_h; ++i) for (int k = 0; k < 3; ++k) env[kEnvTexelFloats * i + k] = env_rgb[3 * i + k];
     P.envmap = env.data(); P.env_w = env_w; P.env_h = env_h;
     P.impmap = impmap; P.imp_dim = imp_dim;
-    std::vector<float> cdf(((size_t)imp_dim * imp_dim - 1) / 3 * 4);
+    std::vector<float> cdf(((size_t)imp_dim * imp_dim - 1) / 3 * kEnvCdfFloats);
     {   // == env_cdf_kernel of vr_kernels.hip
         int base = 0; while ((1 << base) < imp_dim) ++base;
         for (int mip = base - 1; mip >= 0; --mip) {
             const int d = imp_dim >> mip, hd = d >> 1;
             const float* level = impmap + imp_level_offset(imp_dim, mip);
-            float* dst = cdf.data() + 4 * (size_t)env_cdf_offset(base - 1 - mip);
+            float* dst = cdf.data() + kEnvCdfFloats * (size_t)env_cdf_offset(base - 1 - mip);
             for (int y = 0; y < hd; ++y) for (int x = 0; x < hd; ++x) {
                 const float w0 = level[(size_t)(2 * y) * d + 2 * x], w1 = level[(size_t)(2 * y) * d + 2 * x + 1];
                 const float w2 = level[(size_t)(2 * y + 1) * d + 2 * x], w3 = level[(size_t)(2 * y + 1) * d + 2 * x + 1];
                 const float q0 = w0 + w2, q1 = w1 + w3;
-                float* o = dst + 4 * ((size_t)y * hd + x);
-                o[0] = q0 / max_(1e-8f, q0 + q1); o[1] = w0 / q0; o[2] = w1 / q1; o[3] = 0.f;
+                float* o = dst + kEnvCdfFloats * ((size_t)y * hd + x);
+                o[0] = q0 / max_(1e-8f, q0 + q1); o[1] = w0 / q0; o[2] = w1 / q1;
             }
         }
     }

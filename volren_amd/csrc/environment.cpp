@@ -30,13 +30,14 @@ Environment::~Environment() {}
 void Environment::build(const float* rgb, int w, int h) {
     if (w <= 0 || h <= 0) throw std::runtime_error("Environment: empty image");
     width = w; height = h;
-    // texture order: image rows are stored top first, GL's v runs bottom-up -> flip; pad to RGBA for 16-byte texels
-    std::vector<float> tex((size_t)w * h * 4);
+    // texture order: image rows are stored top first, GL's v runs bottom-up -> flip; kEnvTexelFloats floats per texel (vr_scene.h)
+    std::vector<float> tex((size_t)w * h * kEnvTexelFloats);
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             const float* s = rgb + 3 * ((size_t)(h - 1 - y) * w + x);
-            float* d = &tex[4 * ((size_t)y * w + x)];
-            d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 1.0f;
+            float* d = &tex[kEnvTexelFloats * ((size_t)y * w + x)];
+            d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+            if (kEnvTexelFloats > 3) d[3] = 1.0f;
         }
     envmap = make_device_buffer(tex.size() * sizeof(float));
     envmap->upload(tex.data(), tex.size() * sizeof(float));
@@ -46,7 +47,7 @@ void Environment::build(const float* rgb, int w, int h) {
     // build importance map: env_setup.glsl + glGenerateMipmap
     launch_build_impmap(envmap->as<float>(), w, h, (int)DIMENSION, impmap->as<float>(), nullptr);
     VR_HIP(hipGetLastError());
-    cdf = make_device_buffer(((size_t)DIMENSION * DIMENSION - 1) / 3 * 4 * sizeof(float));
+    cdf = make_device_buffer(((size_t)DIMENSION * DIMENSION - 1) / 3 * kEnvCdfFloats * sizeof(float));
     launch_build_env_cdf(impmap->as<float>(), (int)DIMENSION, cdf->as<float>(), nullptr);
     VR_HIP(hipGetLastError());
     VR_HIP(hipStreamSynchronize(nullptr));

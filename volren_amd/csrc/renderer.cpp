@@ -107,6 +107,7 @@ static void set_layout(BrickGridHIP& out) {
         throw std::runtime_error("grid upload: more than 2^30 bricks after padding");
     const size_t cells = majorant_padded_cells((uint32_t)(out.mshift[0] + out.mshift[1] + out.mshift[2]));
     out.majorant = make_device_buffer(cells * sizeof(float));
+    out.majorant16 = make_device_buffer(cells * sizeof(uint16_t));
 }
 static size_t padded_brick_records(const BrickGridHIP& g) { return (size_t)g.nb[2] << (g.bshift[0] + g.bshift[1]); }
 
@@ -158,7 +159,9 @@ BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseG
     VR_HIP(hipMemsetAsync(out.atlas->get(), 0, out.atlas->size_bytes(), stream));
     out.bricks = make_device_buffer(padded_brick_records(out) * sizeof(BrickRec));
     VR_HIP(hipMemsetAsync(out.bricks->get(), 0, out.bricks->size_bytes(), stream));
-    launch_encode_bricks(dense.as<float>(), dim, nb, out.bshift, words, flag.as<uint32_t>(), out.bricks->as<BrickRec>(), out.atlas->as<uint8_t>(), stream);
+    out.rng = make_device_buffer(padded_brick_records(out) * 2 * sizeof(float));
+    VR_HIP(hipMemsetAsync(out.rng->get(), 0, out.rng->size_bytes(), stream));
+    launch_encode_bricks(dense.as<float>(), dim, nb, out.bshift, words, flag.as<uint32_t>(), out.bricks->as<BrickRec>(), out.rng->as<float>(), out.atlas->as<uint8_t>(), stream);
     for (int m = 1; m <= 3; ++m) launch_range_mip(words + out.mip_off[m - 1], mdim[m - 1], words + out.mip_off[m], mdim[m], stream);
     VR_HIP(hipGetLastError());
     VR_HIP(hipStreamSynchronize(stream));
@@ -241,6 +244,10 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
     }
     out.bricks = make_device_buffer(recs.size() * sizeof(BrickRec));
     out.bricks->upload(recs.data(), recs.size() * sizeof(BrickRec));
+    std::vector<float> rng(recs.size() * 2);
+    for (size_t i = 0; i < recs.size(); ++i) { rng[2 * i] = recs[i].rmin; rng[2 * i + 1] = recs[i].rdiff; }
+    out.rng = make_device_buffer(rng.size() * sizeof(float));
+    out.rng->upload(rng.data(), rng.size() * sizeof(float));
 #if defined(VR_ATLAS_F32) && VR_ATLAS_F32
     {   // experiment: decoded float voxels (rmin + unorm8(b) * rdiff, the decode of common.glsl:268-275 done once)
         std::vector<float> decoded(atlas.size());
@@ -284,6 +291,8 @@ static GridView make_view(const BrickGridHIP& g) {
     for (int i = 0; i < 3; ++i) v.dim[i] = g.dim[i];
     for (int i = 0; i < 2; ++i) v.dblk[i] = g.dblk[i];
     v.majorant = g.majorant->as<float>();
+    v.majorant16 = g.majorant16->as<uint16_t>();
+    v.rng = g.rng ? g.rng->as<float>() : nullptr;
     for (int i = 0; i < 3; ++i) v.nb[i] = g.nb[i];
     for (int i = 0; i < 2; ++i) v.bshift[i] = g.bshift[i];
     for (int i = 0; i < 3; ++i) { v.mshift[i] = g.mshift[i]; v.mlim[i] = (float)(8u << g.mshift[i]); }
@@ -373,7 +382,7 @@ void RendererHIP::update_majorants(const SceneParams& P, BrickGridHIP& g) {
     if (k.density_scale == maj_key_.density_scale && k.tf_version == maj_key_.tf_version &&
         k.wl == maj_key_.wl && k.ww == maj_key_.ww && k.frame == maj_key_.frame)
         return;
-    launch_majorants(P, g.range_words->as<uint32_t>(), g.nb, g.mip_off, g.n_mips, g.mshift, g.majorant->as<float>(), stream);
+    launch_majorants(P, g.range_words->as<uint32_t>(), g.nb, g.mip_off, g.n_mips, g.mshift, g.majorant->as<float>(), g.majorant16->as<uint16_t>(), stream);
     VR_HIP(hipGetLastError());
     maj_key_ = k;
 }

@@ -35,6 +35,8 @@ struct BrickGridHIP {
     DeviceBufferPtr atlas;         // brick-major u8 voxels, 512 B per slot
     DeviceBufferPtr range_words;   // fp16x2 range of every cell of mips 0..n_mips (input of the majorant kernel)
     DeviceBufferPtr majorant;      // effective majorants (float), padded power-of-two layout (vr_scene.h)
+    DeviceBufferPtr majorant16;    // raw fp16 range maxima in the same layout (read by the kernels without a transfer function)
+    DeviceBufferPtr rng;           // compact (rmin, rdiff) float pairs, same index as `bricks` (what a tap reads)
     DeviceBufferPtr dense;         // dense fp16 voxels in 4x4x4 blocks (DenseGridF16), then bricks/atlas are empty
     int32_t dim[3] = { 0, 0, 0 };
     int32_t dblk[2] = { 0, 0 };            // 4x4x4 blocks per axis (x, y) of the dense layout

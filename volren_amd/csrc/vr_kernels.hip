@@ -219,7 +219,9 @@ env_cdf_kernel(const float* __restrict__ level, int32_t d, float* __restrict__ o
     const float w0 = level[(size_t)(2 * y) * d + 2 * x], w1 = level[(size_t)(2 * y) * d + 2 * x + 1];
     const float w2 = level[(size_t)(2 * y + 1) * d + 2 * x], w3 = level[(size_t)(2 * y + 1) * d + 2 * x + 1];
     const float q0 = w0 + w2, q1 = w1 + w3;
-    reinterpret_cast<float4*>(out)[i] = make_float4(q0 / max_(1e-8f, q0 + q1), w0 / q0, w1 / q1, 0.0f);
+    float* o = out + (size_t)kEnvCdfFloats * i;
+    o[0] = q0 / max_(1e-8f, q0 + q1); o[1] = w0 / q0; o[2] = w1 / q1;
+    if (kEnvCdfFloats > 3) o[3] = 0.0f;
 }
 void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipStream_t stream) {
     // levels base-1 .. 0; level m lives at pyramid offset imp_level_offset(dim, m) and has (dim >> m)^2 texels
@@ -227,7 +229,7 @@ void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipSt
     while ((1 << base) < dim) ++base;
     for (int32_t mip = base - 1; mip >= 0; --mip) {
         const int32_t d = dim >> mip, n = (d >> 1) * (d >> 1);
-        float* dst = table + 4 * (size_t)env_cdf_offset(base - 1 - mip);
+        float* dst = table + kEnvCdfFloats * (size_t)env_cdf_offset(base - 1 - mip);
         hipLaunchKernelGGL(env_cdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pyramid + imp_level_offset(dim, mip), d, dst);
     }
 }
@@ -282,14 +284,14 @@ encode_range_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int
 __global__ void __launch_bounds__(64)
 encode_brick_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int32_t nz, int32_t nbx, int32_t nby, int32_t bsx, int32_t bsy,
                     const uint32_t* __restrict__ range, const uint32_t* __restrict__ flag,
-                    BrickRec* __restrict__ recs, uint8_t* __restrict__ atlas) {
+                    BrickRec* __restrict__ recs, float* __restrict__ rng, uint8_t* __restrict__ atlas) {
     const int32_t brick = blockIdx.x, lane = threadIdx.x;
     const int32_t bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
     const uint32_t rg = range[brick];
     const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
     const bool alloc = flag[brick] != 0u;                    // a brick whose range is one value keeps its zeroed block
     const size_t idx = ((((size_t)bz << bsy) + by) << bsx) + bx;      // brick-linear atlas: block index = record index
-    if (lane == 0) { BrickRec r; r.slot = (uint32_t)idx; r.rmin = lo; r.rdiff = hi - lo; r.range = rg; recs[idx] = r; }
+    if (lane == 0) { BrickRec r; r.slot = (uint32_t)idx; r.rmin = lo; r.rdiff = hi - lo; r.range = rg; recs[idx] = r; rng[2 * idx] = r.rmin; rng[2 * idx + 1] = r.rdiff; }
     if (!alloc) return;
     const float inv = 255.0f / (hi - lo);
     uint8_t* dst = atlas + idx * 512u;
@@ -324,9 +326,9 @@ void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_
     hipLaunchKernelGGL(encode_range_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], nb[2], range, flag);
 }
 void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const int32_t bshift[2], const uint32_t* range, const uint32_t* flag,
-                          BrickRec* recs, uint8_t* atlas, hipStream_t stream) {
+                          BrickRec* recs, float* rng, uint8_t* atlas, hipStream_t stream) {
     const int32_t n = nb[0] * nb[1] * nb[2];
-    hipLaunchKernelGGL(encode_brick_kernel, dim3(n), dim3(64), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], bshift[0], bshift[1], range, flag, recs, atlas);
+    hipLaunchKernelGGL(encode_brick_kernel, dim3(n), dim3(64), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], bshift[0], bshift[1], range, flag, recs, rng, atlas);
 }
 void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream) {
     const int32_t n = ddim[0] * ddim[1] * ddim[2];
@@ -338,7 +340,7 @@ void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst,
 // (vr_scene.h); cells beyond a level's real extent -- and levels the grid does not have -- hold 0
 struct MajorantLayout { int32_t nb[3], mip_off[4], n_mips, mshift[3]; };
 __global__ void __launch_bounds__(256)
-majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, const MajorantLayout L, uint32_t n_padded, float* __restrict__ out) {
+majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, const MajorantLayout L, uint32_t n_padded, float* __restrict__ out, uint16_t* __restrict__ out16) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_padded) return;
     const uint32_t k = (uint32_t)(L.mshift[0] + L.mshift[1] + L.mshift[2]);
@@ -350,8 +352,10 @@ majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, c
     const uint32_t rnd = (1u << mip) - 1u;
     const uint32_t dx = ((uint32_t)L.nb[0] + rnd) >> mip, dy = ((uint32_t)L.nb[1] + rnd) >> mip, dz = ((uint32_t)L.nb[2] + rnd) >> mip;
     float m = 0.0f;
+    uint32_t h = 0u;
     if ((int32_t)mip <= L.n_mips && cx < dx && cy < dy && cz < dz) {
-        m = P.u.vol_density_scale * half2float(range_words[(uint32_t)L.mip_off[mip] + (cz * dy + cy) * dx + cx] >> 16);
+        h = range_words[(uint32_t)L.mip_off[mip] + (cz * dy + cy) * dx + cx] >> 16;
+        m = P.u.vol_density_scale * half2float(h);
         if (P.u.use_tf) {
             float rgba[4];
             tf_lookup(P, m * P.u.vol_inv_majorant, rgba);
@@ -359,15 +363,16 @@ majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, c
         }
     }
     out[i] = m;
+    out16[i] = (uint16_t)h;
 }
 void launch_majorants(const SceneParams& P, const uint32_t* range_words_all_mips, const int32_t nb[3], const int32_t mip_off[4], int32_t n_mips,
-                      const int32_t mshift[3], float* out_padded, hipStream_t stream) {
+                      const int32_t mshift[3], float* out_padded, uint16_t* out16_padded, hipStream_t stream) {
     MajorantLayout L;
     for (int i = 0; i < 3; ++i) { L.nb[i] = nb[i]; L.mshift[i] = mshift[i]; }
     for (int i = 0; i < 4; ++i) L.mip_off[i] = mip_off[i];
     L.n_mips = n_mips;
     const uint32_t n = (uint32_t)majorant_padded_cells((uint32_t)(mshift[0] + mshift[1] + mshift[2]));
-    hipLaunchKernelGGL(majorant_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, P, range_words_all_mips, L, n, out_padded);
+    hipLaunchKernelGGL(majorant_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, P, range_words_all_mips, L, n, out_padded, out16_padded);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -330,11 +330,11 @@ pathtrace_kernel(const KernelArgs A) {
             MarchIO mio;
             march_idle(mio);
             if (is_m) march_prep(l, P, mio);
-            march_load(P, mio);
-            if (is_m) march_finish(l, mio);
+            march_load<K::tf>(P, mio);
+            if (is_m) march_finish<K::tf>(l, P, mio);
 #else
             for (int32_t k = 0; k < 2; ++k)            // diagnostic: two plain steps, one majorant load each, only where a step runs
-                if (slot >= 0 && l.state == ST_MARCH) do_march(l, P);
+                if (slot >= 0 && l.state == ST_MARCH) do_march<K::tf>(l, P);
 #endif
             if (STATS) { const int32_t nm = popc(__ballot(is_m)); if (nm) { st_exec[ST_MARCH] += 1u; st_lanes[ST_MARCH] += (uint32_t)nm; } const unsigned long long t_now = __builtin_readcyclecounter(); st_cyc[ST_MARCH] += t_now - t_blk; t_blk = t_now; }
             const bool is_c = slot >= 0 && l.state == ST_COLLIDE;

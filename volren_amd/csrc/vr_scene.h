@@ -37,10 +37,24 @@ VR_SCENE_HD size_t dense_blocked_index(uint32_t x, uint32_t y, uint32_t z, uint3
     return (((size_t)(z >> 2) * blocks_y + (y >> 2)) * blocks_x + (x >> 2)) * 64u + (((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u));
 }
 
+// Records of the environment arrays are packed to 12 bytes (no alpha / padding word): 10.7 instead of 8 records per cache line.
+// The kernel is bound by the L1 misses a CU can keep in flight; these gathers are a quarter of them.
+#ifndef VR_ENV_TEXEL_FLOATS
+#define VR_ENV_TEXEL_FLOATS 3
+#endif
+#ifndef VR_ENV_CDF_FLOATS
+#define VR_ENV_CDF_FLOATS 3
+#endif
+constexpr int32_t kEnvTexelFloats = VR_ENV_TEXEL_FLOATS;      // envmap texel: RGB (3) or RGBA (4) floats
+constexpr int32_t kEnvCdfFloats = VR_ENV_CDF_FLOATS;          // warp table record: (d, e0, e1) [+ pad]
+
 struct GridView {
     const BrickRec* bricks;      // nb[2] << (bshift[0] + bshift[1]) records, power-of-two pitches (see above)
     const uint8_t* atlas;        // one 512-byte block per brick record (same index), voxel (x&7) + 8*(y&7) + 64*(z&7)
     const float* majorant;       // all mips, padded (see above): "effective" majorant = density_scale * range.y, TF-remapped when a LUT is bound
+    const uint16_t* majorant16;  // the same cells as raw fp16 range.y (0 outside): what the kernels WITHOUT a transfer function read --
+                                 // density_scale * half2float(.) is one multiply, and the table is half as many cache lines
+    const float* rng;            // (rmin, rdiff) per brick record, 8 bytes, same padded index as `bricks`: the part of a record a tap needs
     int32_t nb[3];               // bricks per axis (mip 0); mip m has ceil(nb / 2^m) cells per axis
     int32_t bshift[2];           // log2 of the brick-record pitches (x, y)
     int32_t mshift[3];           // log2 of the padded level-0 majorant extent per axis (each >= 3)
@@ -73,11 +87,11 @@ struct SceneParams {
     GridView emission;
     float emission_from_density[16];   // vol_emission_inv_transform * vol_density_transform (common.glsl:325)
     const float* tf_lut;               // tf_size x vec4 (std430 SSBO binding 4)
-    const float* envmap;               // env_w*env_h texels, RGBA32F (A unused), row 0 = v~0
+    const float* envmap;               // env_w*env_h texels of kEnvTexelFloats floats (RGB), row 0 = v~0
     int32_t env_w, env_h;
     const float* impmap;               // importance pyramid, level 0 (dim^2) first, 2x2 box mips after it
     int32_t imp_dim;
-    const float* env_cdf;              // warp table: float4 (d, e0, e1, 0) per 2x2 block of every pyramid level, coarsest first
+    const float* env_cdf;              // warp table: kEnvCdfFloats floats (d, e0, e1) per 2x2 block of every pyramid level, coarsest first
     float cam_z;                       // -.5f / tan(.5f * M_PI * cam_fov / 180.f), common.glsl:78 (uniform per frame)
 };
 

@@ -147,8 +147,8 @@ VR_HD TapData tap_load(const GridView& g, TapAddr a) {
         d.rmin = 0.0f; d.rdiff = 0.0f;       // experiment: decoded voxels, one 4-byte load per tap
         d.raw = f2u(reinterpret_cast<const float*>(g.atlas)[(size_t)a.cell * 512u + a.off]);
 #else
-        const BrickRec* rec = g.bricks + a.cell;
-        d.rmin = rec->rmin; d.rdiff = rec->rdiff;
+        const float* rec = g.rng + 2u * (size_t)a.cell;          // compact (rmin, rdiff) pairs: twice as many bricks per cache line as BrickRec
+        d.rmin = rec[0]; d.rdiff = rec[1];
         d.raw = g.atlas[(size_t)a.cell * 512u + a.off];
 #endif
     }
@@ -180,10 +180,19 @@ VR_HD int32_t majorant_index(const GridView& g, v3 ipos, int32_t mip) {
     const uint32_t off = majorant_level_offset((uint32_t)(g.mshift[0] + g.mshift[1] + g.mshift[2]), (uint32_t)mip);
     return inside ? (int32_t)(off + (((bz << sy) + by) << sx) + bx) : -1;
 }
-VR_HD float majorant_fetch(const GridView& g, int32_t idx) { return g.majorant[idx < 0 ? 0 : idx]; }      // unconditional load (cell 0 when outside); the caller discards it then
-VR_HD float majorant_at(const GridView& g, v3 ipos, int32_t mip) {
-    const int32_t idx = majorant_index(g, ipos, mip);
-    const float m = majorant_fetch(g, idx);
+// Unconditional load (cell 0 when outside; the caller discards it then).  TF kernels read the float table (TF-remapped
+// majorants); the others read the raw fp16 range maximum -- half the cache lines -- and scale it themselves (majorant_value).
+template <bool TF>
+VR_HD uint32_t majorant_fetch(const GridView& g, int32_t idx) {
+    const int32_t i = idx < 0 ? 0 : idx;
+    return TF ? f2u(g.majorant[i]) : (uint32_t)g.majorant16[i];
+}
+template <bool TF>
+VR_HD float majorant_value(const SceneParams& P, uint32_t raw) { return TF ? u2f(raw) : P.u.vol_density_scale * half2float(raw); }
+template <bool TF>
+VR_HD float majorant_at(const SceneParams& P, v3 ipos, int32_t mip) {
+    const int32_t idx = majorant_index(P.density, ipos, mip);
+    const float m = majorant_value<TF>(P, majorant_fetch<TF>(P.density, idx));
     return idx < 0 ? 0.0f : m;
 }
 // a NaN coordinate must read "outside": on the device voxel_index turns NaN into index o, so one index is forced negative
@@ -398,10 +407,10 @@ VR_HD v3 env_texture(const SceneParams& P, float u, float v) {
     if (ix == kIntMin || iy == kIntMin || ix > (1 << 28) || ix < -(1 << 28)) { ix = 0; iy = 0; fx = 0.0f; fy = 0.0f; }
     const int32_t x0 = wrap_repeat(ix, w), x1 = wrap_repeat(ix + 1, w);
     const int32_t y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
-    const float* t00 = P.envmap + 4 * ((size_t)y0 * w + x0);
-    const float* t10 = P.envmap + 4 * ((size_t)y0 * w + x1);
-    const float* t01 = P.envmap + 4 * ((size_t)y1 * w + x0);
-    const float* t11 = P.envmap + 4 * ((size_t)y1 * w + x1);
+    const float* t00 = P.envmap + kEnvTexelFloats * ((size_t)y0 * w + x0);
+    const float* t10 = P.envmap + kEnvTexelFloats * ((size_t)y0 * w + x1);
+    const float* t01 = P.envmap + kEnvTexelFloats * ((size_t)y1 * w + x0);
+    const float* t11 = P.envmap + kEnvTexelFloats * ((size_t)y1 * w + x1);
     v3 r;
     r.x = mix_(mix_(t00[0], t10[0], fx), mix_(t01[0], t11[0], fx), fy);
     r.y = mix_(mix_(t00[1], t10[1], fx), mix_(t01[1], t11[1], fx), fy);
@@ -433,13 +442,8 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
     const int32_t top = P.u.env_imp_base_mip - 1;
     for (int32_t mip = top; mip >= 0; mip--) {
         const int32_t k = top - mip;                           // cells per axis at this level = 2^k
-        const float* rec = P.env_cdf + 4 * (env_cdf_offset(k) + (posy << k) + posx);
-#if defined(__HIP_DEVICE_COMPILE__)
-        const float4 t = *reinterpret_cast<const float4*>(rec);
-        const float d = t.x, e0 = t.y, e1 = t.z;
-#else
+        const float* rec = P.env_cdf + kEnvCdfFloats * (env_cdf_offset(k) + (posy << k) + posx);
         const float d = rec[0], e0 = rec[1], e1 = rec[2];
-#endif
         // common.glsl:118-131: "if (r < p) r /= p; else { pos += 1; r = (r - p) / (1 - p); }" per axis, written as operand
         // selects + ONE division so that a wavefront whose lanes go both ways does not execute two
         const bool right = !(px < d);
@@ -601,7 +605,7 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
 // of the next one, taken as if this one neither collides nor leaves the box (step lengths do not depend on the majorant) --
 // and loads both majorants; march_finish replays the reference's loop on those values.  A second step that the first one
 // cancels costs one unused load; the arithmetic of a step that does run is the reference's, operation for operation.
-struct MarchIO { float dt1, dt2, t1, maj1, maj2; int32_t i1, i2; bool go1, go2; };     // i*: majorant cell or -1 (outside: majorant 0); maj*: as loaded
+struct MarchIO { float dt1, dt2, t1; uint32_t maj1, maj2; int32_t i1, i2; bool go1, go2; };     // i*: majorant cell or -1 (outside: majorant 0); maj*: as loaded (majorant_fetch)
 VR_HD void march_idle(MarchIO& io) { io.i1 = io.i2 = -1; io.dt1 = io.dt2 = io.t1 = 0.0f; io.go1 = io.go2 = false; }      // a lane that is not marching
 VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
     io.go1 = h.t < h.far;
@@ -619,18 +623,20 @@ VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
 }
 // the loads: unconditional and for every lane of the wavefront (an idle lane reads cell 0), so that they sit in straight-line
 // code and the compiler's wait counts are exact
+template <bool TF>
 VR_HD void march_load(const SceneParams& P, MarchIO& io) {
-    io.maj1 = majorant_fetch(P.density, io.i1);
-    io.maj2 = majorant_fetch(P.density, io.i2);
+    io.maj1 = majorant_fetch<TF>(P.density, io.i1);
+    io.maj2 = majorant_fetch<TF>(P.density, io.i2);
 }
-VR_HD void march_finish(Hot& h, const MarchIO& io) {
+template <bool TF>
+VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     if (!io.go1) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
-    float t = io.t1, maj = io.i1 >= 0 ? io.maj1 : 0.0f;
+    float t = io.t1, maj = io.i1 >= 0 ? majorant_value<TF>(P, io.maj1) : 0.0f;
     float tau = h.tau - maj * io.dt1;
     int32_t q = h.mipq < 12 ? h.mipq + 1 : 12;
     if (tau > 0.0f) {                                              // no tentative collision in the first cell: second step
         if (!io.go2) { h.t = t; h.tau = tau; h.mipq = q; h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
-        maj = io.i2 >= 0 ? io.maj2 : 0.0f;
+        maj = io.i2 >= 0 ? majorant_value<TF>(P, io.maj2) : 0.0f;
         t = io.t1 + io.dt2;
         tau = tau - maj * io.dt2;
         q = q < 12 ? q + 1 : 12;
@@ -643,11 +649,12 @@ VR_HD void march_finish(Hot& h, const MarchIO& io) {
     h.state = ST_COLLIDE;
 }
 // one iteration (sequential form; the scheduler uses the two-phase form above)
+template <bool TF>
 VR_HD void do_march(Hot& h, const SceneParams& P) {
     if (!(h.t < h.far)) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
     const v3 curr = axpy(h.ipos, h.t, h.idir);
     const int32_t m = round_mip_q(h.mipq);
-    const float majorant = majorant_at(P.density, curr, m);
+    const float majorant = majorant_at<TF>(P, curr, m);
     const float dt = step_dda(curr, h.ri, m);
     h.t += dt;
     h.tau -= majorant * dt;
@@ -1008,7 +1015,7 @@ VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, 
         if (next_item >= (uint32_t)wu.n_items) { h.state = ST_DONE; break; }
         do_new<K>(h, c, P, wu, next_item++);
         break;
-    case ST_MARCH: { MarchIO io; march_prep(h, P, io); march_load(P, io); march_finish(h, io); break; }     // two DDA steps, as on the device
+    case ST_MARCH: { MarchIO io; march_prep(h, P, io); march_load<K::tf>(P, io); march_finish<K::tf>(h, P, io); break; }     // two DDA steps, as on the device
     case ST_COLLIDE: do_collide<K>(h, c, P); break;
     case ST_NEE: do_nee<K>(h, c, P); break;
     case ST_POSTNEE: do_postnee<K>(h, c, P, wu); break;
