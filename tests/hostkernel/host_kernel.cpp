@@ -22,7 +22,8 @@ struct HostGrid {
 };
 
 void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t nb[3], const uint32_t* indirection, const uint32_t* range,
-                const uint32_t ad[3], const uint8_t* atlas, int n_mips, const uint32_t* const* mips, bool density) {
+                const uint32_t ad[3], const uint8_t* atlas, int n_mips, const uint32_t* const* mips, bool density, bool blocked = false) {
+    g.view.maj_blocked = blocked ? 1 : 0;
     const size_t n = (size_t)nb[0] * nb[1] * nb[2];
     const uint32_t sx = ad[0] / 8, sy = ad[1] / 8, sz = ad[2] / 8;
     for (int i = 0; i < 2; ++i) g.view.bshift[i] = ceil_log2(nb[i]);
@@ -60,10 +61,11 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
             const uint32_t sxm = (uint32_t)g.view.mshift[0] - mip, sym = (uint32_t)g.view.mshift[1] - mip;
             for (uint32_t cz = 0; cz < dz; ++cz) for (uint32_t cy = 0; cy < dy; ++cy) for (uint32_t cx = 0; cx < dx; ++cx) {
                 const uint32_t hw = words[mip_off[mip] + ((size_t)cz * dy + cy) * dx + cx] >> 16;
-                g.majorant16[majorant_level_offset(k, mip) + (((cz << sym) + cy) << sxm) + cx] = (uint16_t)hw;
+                const uint32_t cell = majorant_level_offset(k, mip) + majorant_cell_index(cx, cy, cz, sxm, sym, (uint32_t)mip, blocked);
+                g.majorant16[cell] = (uint16_t)hw;
                 float m = u.vol_density_scale * half2float(hw);
                 if (u.use_tf) { float rgba[4]; tf_lookup(P, m * u.vol_inv_majorant, rgba); m = u.vol_majorant * rgba[3]; }
-                g.majorant[majorant_level_offset(k, mip) + (((cz << sym) + cy) << sxm) + cx] = m;
+                g.majorant[cell] = m;
             }
         }
     }
@@ -94,7 +96,7 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
     SceneParams P{};
     P.u = u;
     HostGrid dg, eg;
-    build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true);
+    build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true, density->dense != nullptr);
     P.density = dg.view;
     std::vector<uint16_t> blocked;                 // == dense_grid_to_device: 4x4x4 blocks
     if (density->dense) {

@@ -338,7 +338,7 @@ void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst,
 // ---------------------------------------------------------------------------------------------------
 // effective majorant of every cell of every level, written in the padded power-of-two layout that majorant_at indexes
 // (vr_scene.h); cells beyond a level's real extent -- and levels the grid does not have -- hold 0
-struct MajorantLayout { int32_t nb[3], mip_off[4], n_mips, mshift[3]; };
+struct MajorantLayout { int32_t nb[3], mip_off[4], n_mips, mshift[3], blocked; };
 __global__ void __launch_bounds__(256)
 majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, const MajorantLayout L, uint32_t n_padded, float* __restrict__ out, uint16_t* __restrict__ out16) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -348,7 +348,13 @@ majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, c
     while (mip < 3u && i >= majorant_level_offset(k, mip + 1u)) ++mip;
     const uint32_t j = i - majorant_level_offset(k, mip);
     const uint32_t sx = (uint32_t)L.mshift[0] - mip, sy = (uint32_t)L.mshift[1] - mip;
-    const uint32_t cx = j & ((1u << sx) - 1u), cy = (j >> sx) & ((1u << sy) - 1u), cz = j >> (sx + sy);
+    uint32_t cx, cy, cz;                                   // invert majorant_cell_index: which cell lives at position j of this level
+    if (L.blocked && mip <= 1u) {
+        const uint32_t blk = j >> 6, in = j & 63u;
+        cx = ((blk & ((1u << (sx - 2u)) - 1u)) << 2) | (in & 3u);
+        cy = (((blk >> (sx - 2u)) & ((1u << (sy - 2u)) - 1u)) << 2) | ((in >> 2) & 3u);
+        cz = ((blk >> (sx + sy - 4u)) << 2) | (in >> 4);
+    } else { cx = j & ((1u << sx) - 1u); cy = (j >> sx) & ((1u << sy) - 1u); cz = j >> (sx + sy); }
     const uint32_t rnd = (1u << mip) - 1u;
     const uint32_t dx = ((uint32_t)L.nb[0] + rnd) >> mip, dy = ((uint32_t)L.nb[1] + rnd) >> mip, dz = ((uint32_t)L.nb[2] + rnd) >> mip;
     float m = 0.0f;
@@ -368,6 +374,7 @@ majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, c
 void launch_majorants(const SceneParams& P, const uint32_t* range_words_all_mips, const int32_t nb[3], const int32_t mip_off[4], int32_t n_mips,
                       const int32_t mshift[3], float* out_padded, uint16_t* out16_padded, hipStream_t stream) {
     MajorantLayout L;
+    L.blocked = P.density.maj_blocked;
     for (int i = 0; i < 3; ++i) { L.nb[i] = nb[i]; L.mshift[i] = mshift[i]; }
     for (int i = 0; i < 4; ++i) L.mip_off[i] = mip_off[i];
     L.n_mips = n_mips;

@@ -58,6 +58,12 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #ifndef VR_MARCH_SPECULATIVE
 #define VR_MARCH_SPECULATIVE 1
 #endif
+#ifndef VR_DIAG_PAD_VALU
+#define VR_DIAG_PAD_VALU 0
+#endif
+#ifndef VR_DIAG_PAD_SLEEP
+#define VR_DIAG_PAD_SLEEP 0
+#endif
 #ifndef VR_BATCH_REGS
 #define VR_BATCH_REGS 1
 #endif
@@ -329,14 +335,25 @@ pathtrace_kernel(const KernelArgs A) {
 #if VR_MARCH_SPECULATIVE
             MarchIO mio;
             march_idle(mio);
-            if (is_m) march_prep(l, P, mio);
+            if (is_m) march_prep<K::dense>(l, P, mio);
             march_load<K::tf>(P, mio);
             if (is_m) march_finish<K::tf>(l, P, mio);
 #else
             for (int32_t k = 0; k < 2; ++k)            // diagnostic: two plain steps, one majorant load each, only where a step runs
-                if (slot >= 0 && l.state == ST_MARCH) do_march<K::tf>(l, P);
+                if (slot >= 0 && l.state == ST_MARCH) do_march<K::tf, K::dense>(l, P);
 #endif
             if (STATS) { const int32_t nm = popc(__ballot(is_m)); if (nm) { st_exec[ST_MARCH] += 1u; st_lanes[ST_MARCH] += (uint32_t)nm; } const unsigned long long t_now = __builtin_readcyclecounter(); st_cyc[ST_MARCH] += t_now - t_blk; t_blk = t_now; }
+#if VR_DIAG_PAD_VALU > 0
+            {   // diagnostic: VR_DIAG_PAD_VALU extra dependent-free vector instructions per pass -> how issue-bound is the pass?
+                float pad_ = l.t;
+#pragma unroll
+                for (int k_ = 0; k_ < VR_DIAG_PAD_VALU; ++k_) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(pad_));
+                asm volatile("" :: "v"(pad_));
+            }
+#endif
+#if VR_DIAG_PAD_SLEEP > 0
+            __builtin_amdgcn_s_sleep(VR_DIAG_PAD_SLEEP);       // diagnostic: 64 * n idle cycles per pass -> how latency-bound is the wavefront?
+#endif
             const bool is_c = slot >= 0 && l.state == ST_COLLIDE;
             CollideIO<K> cio;
             collide_idle<K>(cio);

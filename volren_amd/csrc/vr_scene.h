@@ -31,6 +31,15 @@ VR_SCENE_HD int32_t ceil_log2(uint32_t v) { int32_t s = 0; while (s < 31 && (1u 
 // offset of level m = S0 * (0, 1, 9/8, 73/64)[m], S0 = 2^k cells on level 0 (k >= 9)
 VR_SCENE_HD uint32_t majorant_level_offset(uint32_t k, uint32_t mip) { const uint32_t s = 9u - 3u * mip; return ((0x49u >> s) << s) << (k - 6u); }
 VR_SCENE_HD size_t majorant_padded_cells(uint32_t k) { return (size_t)majorant_level_offset(k, 3u) + ((size_t)1 << (k - 9u)); }
+// Cell (cx, cy, cz) of level `mip` inside its level.  Linear: x fastest with power-of-two pitches.  Blocked (GridView::maj_blocked,
+// used for the large tables of dense grids): levels 0 and 1 -- at least 4 cells per axis -- are stored as 4x4x4-cell blocks of 64
+// consecutive cells (128 bytes of fp16 = one cache line), so that a DDA step to ANY neighbouring cell usually stays in the line;
+// levels 2 and 3 (a few hundred cells) stay linear.  sx, sy: log2 of the level's padded extent in x and y.
+VR_SCENE_HD uint32_t majorant_cell_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t sx, uint32_t sy, uint32_t mip, bool blocked) {
+    if (blocked && mip <= 1u)
+        return (((((cz >> 2) << (sy - 2u)) + (cy >> 2)) << (sx - 2u)) + (cx >> 2)) * 64u + (((cz & 3u) << 4) | ((cy & 3u) << 2) | (cx & 3u));
+    return (((cz << sy) + cy) << sx) + cx;
+}
 
 // element index of voxel (x, y, z) in the blocked dense layout (see GridView::dense)
 VR_SCENE_HD size_t dense_blocked_index(uint32_t x, uint32_t y, uint32_t z, uint32_t blocks_x, uint32_t blocks_y) {
@@ -60,6 +69,7 @@ struct GridView {
     int32_t mshift[3];           // log2 of the padded level-0 majorant extent per axis (each >= 3)
     float mlim[3];               // the same extent in voxels, (float)(8 << mshift[i]): the inside test of the DDA compares against it
     int32_t n_mips;              // range mips available above level 0 (reference: 3)
+    int32_t maj_blocked;         // majorant levels 0 and 1 in 4x4x4-cell blocks (majorant_cell_index): set for dense grids
     const uint16_t* dense;       // dense fp16 voxels in 4x4x4 blocks of 128 contiguous bytes (one cache line): block (x>>2, y>>2, z>>2),
                                  // x fastest over dblk[0] x dblk[1] x ceil(dim.z/4) blocks, voxel (x&3) + 4*(y&3) + 16*(z&3) inside; or nullptr
     int32_t dim[3];              // voxel extent of the dense grid

@@ -172,13 +172,15 @@ VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
 // The padded layout (vr_scene.h) holds 0 in every cell beyond the real extent of a level, so only the padded extent -- the
 // same for all levels -- is tested, on the floats (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails), after
 // which truncation equals floor.
+template <int DENSE = 2>
 VR_HD int32_t majorant_index(const GridView& g, v3 ipos, int32_t mip) {
     const bool inside = (mip <= g.n_mips) & (ipos.x >= 0.0f) & (ipos.x < g.mlim[0]) & (ipos.y >= 0.0f) & (ipos.y < g.mlim[1]) & (ipos.z >= 0.0f) & (ipos.z < g.mlim[2]);
     const uint32_t sh = 3u + (uint32_t)mip;
     const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
     const uint32_t sx = (uint32_t)g.mshift[0] - (uint32_t)mip, sy = (uint32_t)g.mshift[1] - (uint32_t)mip;
     const uint32_t off = majorant_level_offset((uint32_t)(g.mshift[0] + g.mshift[1] + g.mshift[2]), (uint32_t)mip);
-    return inside ? (int32_t)(off + (((bz << sy) + by) << sx) + bx) : -1;
+    const bool blocked = g.maj_blocked != 0;          // run-time: the table is laid out by majorant_kernel from the same flag
+    return inside ? (int32_t)(off + majorant_cell_index(bx, by, bz, sx, sy, (uint32_t)mip, blocked)) : -1;
 }
 // Unconditional load (cell 0 when outside; the caller discards it then).  TF kernels read the float table (TF-remapped
 // majorants); the others read the raw fp16 range maximum -- half the cache lines -- and scale it themselves (majorant_value).
@@ -189,9 +191,9 @@ VR_HD uint32_t majorant_fetch(const GridView& g, int32_t idx) {
 }
 template <bool TF>
 VR_HD float majorant_value(const SceneParams& P, uint32_t raw) { return TF ? u2f(raw) : P.u.vol_density_scale * half2float(raw); }
-template <bool TF>
+template <bool TF, int DENSE = 2>
 VR_HD float majorant_at(const SceneParams& P, v3 ipos, int32_t mip) {
-    const int32_t idx = majorant_index(P.density, ipos, mip);
+    const int32_t idx = majorant_index<DENSE>(P.density, ipos, mip);
     const float m = majorant_value<TF>(P, majorant_fetch<TF>(P.density, idx));
     return idx < 0 ? 0.0f : m;
 }
@@ -607,18 +609,19 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
 // cancels costs one unused load; the arithmetic of a step that does run is the reference's, operation for operation.
 struct MarchIO { float dt1, dt2, t1; uint32_t maj1, maj2; int32_t i1, i2; bool go1, go2; };     // i*: majorant cell or -1 (outside: majorant 0); maj*: as loaded (majorant_fetch)
 VR_HD void march_idle(MarchIO& io) { io.i1 = io.i2 = -1; io.dt1 = io.dt2 = io.t1 = 0.0f; io.go1 = io.go2 = false; }      // a lane that is not marching
+template <int DENSE = 2>
 VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
     io.go1 = h.t < h.far;
     const v3 c1 = axpy(h.ipos, h.t, h.idir);
     const int32_t m1 = round_mip_q(h.mipq);
-    io.i1 = majorant_index(P.density, c1, m1);
+    io.i1 = majorant_index<DENSE>(P.density, c1, m1);
     io.dt1 = step_dda(c1, h.ri, m1);
     io.t1 = h.t + io.dt1;
     const int32_t q2 = h.mipq < 12 ? h.mipq + 1 : 12;              // mip = min(mip + 0.25, 3)
     const int32_t m2 = round_mip_q(q2);
     io.go2 = io.t1 < h.far;
     const v3 c2 = axpy(h.ipos, io.t1, h.idir);
-    io.i2 = majorant_index(P.density, c2, m2);
+    io.i2 = majorant_index<DENSE>(P.density, c2, m2);
     io.dt2 = step_dda(c2, h.ri, m2);
 }
 // the loads: unconditional and for every lane of the wavefront (an idle lane reads cell 0), so that they sit in straight-line
@@ -649,12 +652,12 @@ VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     h.state = ST_COLLIDE;
 }
 // one iteration (sequential form; the scheduler uses the two-phase form above)
-template <bool TF>
+template <bool TF, int DENSE = 2>
 VR_HD void do_march(Hot& h, const SceneParams& P) {
     if (!(h.t < h.far)) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
     const v3 curr = axpy(h.ipos, h.t, h.idir);
     const int32_t m = round_mip_q(h.mipq);
-    const float majorant = majorant_at<TF>(P, curr, m);
+    const float majorant = majorant_at<TF, DENSE>(P, curr, m);
     const float dt = step_dda(curr, h.ri, m);
     h.t += dt;
     h.tau -= majorant * dt;
@@ -1015,7 +1018,7 @@ VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, 
         if (next_item >= (uint32_t)wu.n_items) { h.state = ST_DONE; break; }
         do_new<K>(h, c, P, wu, next_item++);
         break;
-    case ST_MARCH: { MarchIO io; march_prep(h, P, io); march_load<K::tf>(P, io); march_finish<K::tf>(h, P, io); break; }     // two DDA steps, as on the device
+    case ST_MARCH: { MarchIO io; march_prep<K::dense>(h, P, io); march_load<K::tf>(P, io); march_finish<K::tf>(h, P, io); break; }     // two DDA steps, as on the device
     case ST_COLLIDE: do_collide<K>(h, c, P); break;
     case ST_NEE: do_nee<K>(h, c, P); break;
     case ST_POSTNEE: do_postnee<K>(h, c, P, wu); break;
