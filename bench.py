@@ -42,7 +42,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", help="c1 | c2 | c3 | readme | c4[:N] (synthetic N^3 dense fp16 grid, default 512) | c5[:N] (synthetic sparse brick grid + emission)")
+    ap.add_argument("--config", default="c2", help="c1 | c2 | c3 | readme | c4[:N] (synthetic N^3 dense fp16 grid, default 512) | c5[:N] (synthetic sparse brick grid + emission, dense generator) | c5full (1024^3 sparse brick grid + emission built in brick form)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=1024)
@@ -90,12 +90,13 @@ def algorithmic_bytes_per_sample(counters, use_tf, has_emission, dense=False):
                    primary_miss=counters["n_primary_miss"] / n)
 
 
-def cpu_baseline_and_counters(config, budget_s, integrator=0, kind="port"):
-    """Oracle on the host cores: low-resolution full view of the same scene (same camera, so the same mix of
-    box-missing and cloud pixels), spp chosen to fill ~budget_s seconds."""
+def cpu_baseline_and_counters(config, budget_s, integrator=0, kind="port", aspect=1.0):
+    """Oracle on the host cores: low-resolution full view of the same scene (same camera and aspect ratio, so the same mix
+    of box-missing and cloud pixels), spp chosen to fill ~budget_s seconds."""
     import scenes
     from oracle import binding as ob
-    cw = ch = 512
+    cw = 512
+    ch = max(16, int(round(cw / aspect / 2)) * 2)
 
     def scene():
         o = scenes.oracle_scene(config, cw, ch)
@@ -313,9 +314,9 @@ def main():
         use_tf = args.config == "c3"
         cpu = cpu_rm = None
         if world == 1 and args.cpu_budget > 0:
-            cpu, counters = cpu_baseline_and_counters(args.config, args.cpu_budget)
+            cpu, counters = cpu_baseline_and_counters(args.config, args.cpu_budget, aspect=w / h)
         else:
-            _, counters = cpu_baseline_and_counters(args.config, 0.5)
+            _, counters = cpu_baseline_and_counters(args.config, 0.5, aspect=w / h)
         out = {
             "metric": "Msamples/s (pixels x spp / s), volume path tracing",
             "value": m["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -323,13 +324,13 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else
                                       "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
             "config": {"workload": workload_name(args.config, w, h, spp),
-                       "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, ", consecutive frames pipelined over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, 1 fused launch/frame"},
+                       "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, ", consecutive frames pipelined over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, %d fused launch(es)/frame (16 GiB sample pool)" % m["launches"]},
             "roofline": b.roofline(m, counters),
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
             try:                                               # second baseline SURVEY 8d names: the 64-step ray marcher
-                cpu_rm, _ = cpu_baseline_and_counters(args.config, min(args.cpu_budget, 6.0), integrator=3, kind="raymarch-64")
+                cpu_rm, _ = cpu_baseline_and_counters(args.config, min(args.cpu_budget, 6.0), integrator=3, kind="raymarch-64", aspect=w / h)
                 out["cpu_baseline_raymarch"] = cpu_rm
             except Exception as e:                             # noqa: BLE001 -- a missing optional leg must not lose the headline line
                 out["cpu_baseline_raymarch"] = {"error": str(e)}
@@ -358,7 +359,7 @@ def main():
             try:
                 bx = Bench(name, w, h, spp, 1, 0, local_rank, None)
                 mx = bx.measure(2, 1)
-                _, cx = cpu_baseline_and_counters(name, 0.5)
+                _, cx = cpu_baseline_and_counters(name, 0.5, aspect=w / h)
                 out["configs"].append({"name": name, "workload": workload_name(name, w, h, spp), "value": mx["value"], "unit": "Msamples/s",
                                        "ms_per_step": mx["ms_per_step"], "steps": 2, "warmup": 1, "roofline": bx.roofline(mx, cx)})
                 del bx
