@@ -16,7 +16,7 @@ namespace {
 struct HostGrid {
     std::vector<BrickRec> recs;
     std::vector<uint8_t> atlas;
-    std::vector<float> majorant, rng;
+    std::vector<float> majorant, rng, atlas_f32;
     std::vector<uint16_t> majorant16;
     GridView view{};
 };
@@ -73,6 +73,12 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
     for (size_t i = 0; i < g.recs.size(); ++i) { g.rng[2 * i] = g.recs[i].rmin; g.rng[2 * i + 1] = g.recs[i].rdiff; }
     g.view.bricks = g.recs.data(); g.view.atlas = g.atlas.data(); g.view.majorant = g.majorant.data();
     g.view.majorant16 = g.majorant16.data(); g.view.rng = g.rng.data();
+    g.view.atlas_f32 = nullptr;
+    if (density && u.use_tf) {                  // == RendererHIP::launch: decoded float atlas for transfer-function renders
+        g.atlas_f32.resize(g.atlas.size());
+        for (size_t i = 0; i < g.atlas.size(); ++i) g.atlas_f32[i] = g.rng[2 * (i >> 9)] + unorm8(g.atlas[i]) * g.rng[2 * (i >> 9) + 1];
+        g.view.atlas_f32 = g.atlas_f32.data();
+    }
     for (int i = 0; i < 3; ++i) g.view.nb[i] = (int32_t)nb[i];
     g.view.n_mips = n_mips;
 }

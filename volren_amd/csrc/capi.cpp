@@ -245,6 +245,7 @@ int vr_set_int(vr_renderer* r, const char* name, int v) {
         else if (n == "tonemapping") R.tonemapping = v != 0;
         else if (n == "integrator") R.integrator = v;
         else if (n == "fast_math") R.fast_math = v != 0;
+        else if (n == "tf_float_atlas") R.tf_float_atlas = v != 0;
         else if (n == "gpu_encoder") R.gpu_encoder = v != 0;
         else if (n == "sample_pool_mb") { if (v < 16 || v > 49152) throw std::runtime_error("sample_pool_mb must be in [16, 49152] (item indices of a sub-launch are 32-bit: < 2^32 RGBA32F items)"); R.sample_pool_bytes = (size_t)v << 20; }
         else if (n == "grid_frame_counter") {
@@ -268,6 +269,7 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "tonemapping") *v = R.tonemapping ? 1 : 0;
         else if (n == "integrator") *v = R.integrator;
         else if (n == "fast_math") *v = R.fast_math ? 1 : 0;
+        else if (n == "tf_float_atlas") *v = R.tf_float_atlas ? 1 : 0;
         else if (n == "gpu_encoder") *v = R.gpu_encoder ? 1 : 0;
         else if (n == "sample_pool_mb") *v = (int)(R.sample_pool_bytes >> 20);
         else if (n == "grid_frame_counter") *v = R.volume ? (int)R.volume->grid_frame_counter : 0;

@@ -248,16 +248,6 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
     for (size_t i = 0; i < recs.size(); ++i) { rng[2 * i] = recs[i].rmin; rng[2 * i + 1] = recs[i].rdiff; }
     out.rng = make_device_buffer(rng.size() * sizeof(float));
     out.rng->upload(rng.data(), rng.size() * sizeof(float));
-#if defined(VR_ATLAS_F32) && VR_ATLAS_F32
-    {   // experiment: decoded float voxels (rmin + unorm8(b) * rdiff, the decode of common.glsl:268-275 done once)
-        std::vector<float> decoded(atlas.size());
-        for (size_t i = 0; i < recs.size(); ++i)
-            for (size_t v = 0; v < 512; ++v) decoded[i * 512 + v] = recs[i].rmin + unorm8(atlas[i * 512 + v]) * recs[i].rdiff;
-        out.atlas = make_device_buffer(decoded.size() * sizeof(float));
-        out.atlas->upload(decoded.data(), decoded.size() * sizeof(float));
-        return out;
-    }
-#endif
     out.atlas = make_device_buffer(atlas.size());
     out.atlas->upload(atlas.data(), atlas.size());
     return out;
@@ -293,6 +283,7 @@ static GridView make_view(const BrickGridHIP& g) {
     v.majorant = g.majorant->as<float>();
     v.majorant16 = g.majorant16->as<uint16_t>();
     v.rng = g.rng ? g.rng->as<float>() : nullptr;
+    v.atlas_f32 = g.atlas_f32 ? g.atlas_f32->as<float>() : nullptr;
     for (int i = 0; i < 3; ++i) v.nb[i] = g.nb[i];
     for (int i = 0; i < 2; ++i) v.bshift[i] = g.bshift[i];
     for (int i = 0; i < 3; ++i) { v.mshift[i] = g.mshift[i]; v.mlim[i] = (float)(8u << g.mshift[i]); }
@@ -406,6 +397,18 @@ void RendererHIP::launch(int n) {
     if (!color) throw std::runtime_error("RendererHIP::trace: no framebuffer (call resize first)");
     if (integrator == 2 && !transferfunc) throw std::runtime_error("RendererHIP::trace: integrator 2 (direct volume rendering) needs a transfer function");
     if (integrator < 0 || integrator > 3) throw std::runtime_error("RendererHIP::trace: unknown integrator");
+    {   // transfer-function renders of brick grids read a decoded float atlas (vr_trace.h trilinear_load): build it on first use.
+        // 4 bytes per voxel of every brick; when that does not fit, the byte atlas keeps serving (same values either way).
+        BrickGridHIP& g = density_grids.at(volume->grid_frame_counter);
+        if (transferfunc && tf_float_atlas && !g.dense && g.atlas && g.rng && !g.atlas_f32) {
+            try {
+                g.atlas_f32 = make_device_buffer(g.atlas->size_bytes() * sizeof(float));
+                launch_decode_atlas(g.rng->as<float>(), g.atlas->as<uint8_t>(), g.atlas_f32->as<float>(), g.atlas->size_bytes() / 512, stream);
+                VR_HIP(hipGetLastError());
+            } catch (const std::exception&) { (void)hipGetLastError(); g.atlas_f32.reset(); }
+        }
+        if (!transferfunc || !tf_float_atlas) g.atlas_f32.reset();
+    }
     SceneParams P;
     fill_params(P);
     update_majorants(P, density_grids[volume->grid_frame_counter]);

@@ -37,6 +37,7 @@ struct BrickGridHIP {
     DeviceBufferPtr majorant;      // effective majorants (float), padded power-of-two layout (vr_scene.h)
     DeviceBufferPtr majorant16;    // raw fp16 range maxima in the same layout (read by the kernels without a transfer function)
     DeviceBufferPtr rng;           // compact (rmin, rdiff) float pairs, same index as `bricks` (what a tap reads)
+    DeviceBufferPtr atlas_f32;     // decoded float atlas, built on the first render with a transfer function (4x the atlas; dropped by commit())
     DeviceBufferPtr dense;         // dense fp16 voxels in 4x4x4 blocks (DenseGridF16), then bricks/atlas are empty
     int32_t dim[3] = { 0, 0, 0 };
     int32_t dblk[2] = { 0, 0 };            // 4x4x4 blocks per axis (x, y) of the dense layout
@@ -111,6 +112,7 @@ struct RendererHIP {
     hipStream_t stream = nullptr;
     int integrator = 0;                               // 0: DDA tracking (both reference kernels), 1: global-majorant tracking (common.glsl:333-394),
                                                       // 2: direct volume rendering (:571-591, needs a LUT), 3: 64-step ray-marching trackers (:506-566)
+    bool tf_float_atlas = true;                       // transfer-function renders decode the brick atlas to floats once (4x its size): one load per corner tap
     bool fast_math = false;                           // opt-in tolerance mode: hardware log/sin/cos/rcp instead of the specified arithmetic
                                                       // (within 1e-3 relative L2 of the default, not bit-reproducible)
     int last_launches = 0;                            // path-tracing sub-launches of the last trace()/render()

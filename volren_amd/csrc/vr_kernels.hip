@@ -335,6 +335,20 @@ void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst,
     hipLaunchKernelGGL(range_mip_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, sdim[0], sdim[1], sdim[2], dst, ddim[0], ddim[1], ddim[2]);
 }
 
+// decoded float atlas for transfer-function renders: out[i*512 + v] = rmin_i + unorm8(atlas[i*512 + v]) * rdiff_i (common.glsl:268-275)
+__global__ void __launch_bounds__(256)
+decode_atlas_kernel(const float* __restrict__ rng, const uint8_t* __restrict__ atlas, float* __restrict__ out, size_t n_voxels) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_voxels) return;
+    const size_t cell = i >> 9;
+    out[i] = rng[2 * cell] + unorm8(atlas[i]) * rng[2 * cell + 1];
+}
+void launch_decode_atlas(const float* rng, const uint8_t* atlas, float* out, size_t n_records, hipStream_t stream) {
+    const size_t n = n_records * 512u;
+    if (n == 0) return;
+    hipLaunchKernelGGL(decode_atlas_kernel, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, stream, rng, atlas, out, n);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // effective majorant of every cell of every level, written in the padded power-of-two layout that majorant_at indexes
 // (vr_scene.h); cells beyond a level's real extent -- and levels the grid does not have -- hold 0

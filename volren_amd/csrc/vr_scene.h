@@ -63,6 +63,8 @@ struct GridView {
     const float* majorant;       // all mips, padded (see above): "effective" majorant = density_scale * range.y, TF-remapped when a LUT is bound
     const uint16_t* majorant16;  // the same cells as raw fp16 range.y (0 outside): what the kernels WITHOUT a transfer function read --
                                  // density_scale * half2float(.) is one multiply, and the table is half as many cache lines
+    const float* atlas_f32;      // optional: the atlas decoded to float (rmin + unorm8(b) * rdiff, 2 KiB per brick), built for transfer-function
+                                 // renders -- their 8 corner taps then cost one 4-byte load each instead of record + byte; nullptr otherwise
     const float* rng;            // (rmin, rdiff) per brick record, 8 bytes, same padded index as `bricks`: the part of a record a tap needs
     int32_t nb[3];               // bricks per axis (mip 0); mip m has ceil(nb / 2^m) cells per axis
     int32_t bshift[2];           // log2 of the brick-record pitches (x, y)

@@ -111,9 +111,6 @@ VR_HD void rng_skip9(uint32_t& s) {
 // (tap_value).  The scheduler (vr_pathtrace.h) runs the first two for all lanes of a pass before anything waits, so that one
 // memory round trip serves the DDA steps and the collisions of the whole wavefront.  The brick atlas is brick-linear
 // (block of brick record i = bytes [512 i, 512 i + 512)): record and voxel are fetched together, no dependent pointer chase.
-#ifndef VR_ATLAS_F32
-#define VR_ATLAS_F32 0
-#endif
 template <int DENSE>
 VR_HD bool grid_is_dense(const GridView& g) { return DENSE == 2 ? g.dense != nullptr : DENSE == 1; }
 struct TapAddr { uint32_t cell, off; bool in; };      // bricks: record index, byte inside the 8^3 block; dense: 4x4x4 block index, voxel inside it
@@ -143,24 +140,15 @@ VR_HD TapData tap_load(const GridView& g, TapAddr a) {
         d.rmin = 0.0f; d.rdiff = 0.0f;
         d.raw = g.dense[(size_t)a.cell * 64u + a.off];
     } else {
-#if VR_ATLAS_F32
-        d.rmin = 0.0f; d.rdiff = 0.0f;       // experiment: decoded voxels, one 4-byte load per tap
-        d.raw = f2u(reinterpret_cast<const float*>(g.atlas)[(size_t)a.cell * 512u + a.off]);
-#else
         const float* rec = g.rng + 2u * (size_t)a.cell;          // compact (rmin, rdiff) pairs: twice as many bricks per cache line as BrickRec
         d.rmin = rec[0]; d.rdiff = rec[1];
         d.raw = g.atlas[(size_t)a.cell * 512u + a.off];
-#endif
     }
     return d;
 }
 template <int DENSE = 2>
 VR_HD float tap_value(const GridView& g, TapData d, bool in) {
-#if VR_ATLAS_F32
-    const float v = grid_is_dense<DENSE>(g) ? half2float(d.raw) : u2f(d.raw);
-#else
     const float v = grid_is_dense<DENSE>(g) ? half2float(d.raw) : d.rmin + unorm8(d.raw) * d.rdiff;
-#endif
     return in ? v : 0.0f;
 }
 template <int DENSE = 2>
@@ -252,8 +240,15 @@ VR_HD void trilinear_prep(const GridView& g, v3 ipos, TriIO& io) {
             }
         }
 }
+// The 8 corner loads.  With a decoded float atlas (GridView::atlas_f32, brick grids under a transfer function) a corner is ONE
+// 4-byte load of the value the byte path would compute (rmin + unorm8(b) * rdiff, evaluated once when the atlas is decoded).
 template <int DENSE = 2>
 VR_HD void trilinear_load(const GridView& g, TriIO& io) {
+    if (!grid_is_dense<DENSE>(g) && g.atlas_f32) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) { io.d[n].rmin = 0.0f; io.d[n].rdiff = 0.0f; io.d[n].raw = f2u(g.atlas_f32[(size_t)io.a[n].cell * 512u + io.a[n].off]); }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < 8; ++n) io.d[n] = tap_load<DENSE>(g, io.a[n]);
 }
@@ -265,8 +260,13 @@ VR_HD void trilinear_idle(TriIO& io) {           // addresses of a lane without 
 template <int DENSE = 2>
 VR_HD float trilinear_value(const GridView& g, const TriIO& io) {
     float v[8];
+    if (!grid_is_dense<DENSE>(g) && g.atlas_f32) {
 #pragma unroll
-    for (int n = 0; n < 8; ++n) v[n] = tap_value<DENSE>(g, io.d[n], (io.in_mask >> n) & 1u);
+        for (int n = 0; n < 8; ++n) v[n] = ((io.in_mask >> n) & 1u) ? u2f(io.d[n].raw) : 0.0f;
+    } else {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) v[n] = tap_value<DENSE>(g, io.d[n], (io.in_mask >> n) & 1u);
+    }
     const float lx0 = mix_(v[0], v[1], io.fx);
     const float lx1 = mix_(v[2], v[3], io.fx);
     const float hx0 = mix_(v[4], v[5], io.fx);
@@ -602,49 +602,66 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
     begin_segment<K>(h, P, pos, dir, 0);
 }
 
-// Loop body of both DDA trackers up to the collision test (common.glsl:422-435, 469-482), TWO iterations at a time and in
-// two phases.  march_prep does everything that needs no memory -- positions, DDA levels, step lengths of this iteration AND
-// of the next one, taken as if this one neither collides nor leaves the box (step lengths do not depend on the majorant) --
-// and loads both majorants; march_finish replays the reference's loop on those values.  A second step that the first one
-// cancels costs one unused load; the arithmetic of a step that does run is the reference's, operation for operation.
-struct MarchIO { float dt1, dt2, t1; uint32_t maj1, maj2; int32_t i1, i2; bool go1, go2; };     // i*: majorant cell or -1 (outside: majorant 0); maj*: as loaded (majorant_fetch)
-VR_HD void march_idle(MarchIO& io) { io.i1 = io.i2 = -1; io.dt1 = io.dt2 = io.t1 = 0.0f; io.go1 = io.go2 = false; }      // a lane that is not marching
+// Loop body of both DDA trackers up to the collision test (common.glsl:422-435, 469-482), kMarchSteps iterations at a time and
+// in two phases.  march_prep does everything that needs no memory -- positions, DDA levels, step lengths of this iteration AND
+// of the following ones, each taken as if its predecessors neither collide nor leave the box (step lengths do not depend on the
+// majorant) -- and march_load fetches all their majorants together; march_finish replays the reference's loop on those
+// values.  A step that an earlier one cancels costs one unused load; the arithmetic of a step that does run is the
+// reference's, operation for operation.
+#ifndef VR_MARCH_STEPS
+#define VR_MARCH_STEPS 2
+#endif
+constexpr int32_t kMarchSteps = VR_MARCH_STEPS;
+struct MarchIO {
+    float dt[kMarchSteps], t[kMarchSteps];      // step length; ray parameter after the step
+    uint32_t maj[kMarchSteps];                  // majorant of the step's cell as loaded (majorant_fetch)
+    int32_t idx[kMarchSteps];                   // its table index or -1 (outside: majorant 0)
+    bool go[kMarchSteps];                       // the step starts inside [near, far)
+};
+VR_HD void march_idle(MarchIO& io) {             // a lane that is not marching
+#pragma unroll
+    for (int k = 0; k < kMarchSteps; ++k) { io.idx[k] = -1; io.dt[k] = io.t[k] = 0.0f; io.go[k] = false; }
+}
 template <int DENSE = 2>
 VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
-    io.go1 = h.t < h.far;
-    const v3 c1 = axpy(h.ipos, h.t, h.idir);
-    const int32_t m1 = round_mip_q(h.mipq);
-    io.i1 = majorant_index<DENSE>(P.density, c1, m1);
-    io.dt1 = step_dda(c1, h.ri, m1);
-    io.t1 = h.t + io.dt1;
-    const int32_t q2 = h.mipq < 12 ? h.mipq + 1 : 12;              // mip = min(mip + 0.25, 3)
-    const int32_t m2 = round_mip_q(q2);
-    io.go2 = io.t1 < h.far;
-    const v3 c2 = axpy(h.ipos, io.t1, h.idir);
-    io.i2 = majorant_index<DENSE>(P.density, c2, m2);
-    io.dt2 = step_dda(c2, h.ri, m2);
+    float t = h.t;
+    int32_t q = h.mipq;
+#pragma unroll
+    for (int k = 0; k < kMarchSteps; ++k) {
+        io.go[k] = t < h.far;
+        const v3 c = axpy(h.ipos, t, h.idir);
+        const int32_t m = round_mip_q(q);
+        io.idx[k] = majorant_index<DENSE>(P.density, c, m);
+        io.dt[k] = step_dda(c, h.ri, m);
+        t = t + io.dt[k];
+        io.t[k] = t;
+        q = q < 12 ? q + 1 : 12;                                   // mip = min(mip + 0.25, 3)
+    }
 }
 // the loads: unconditional and for every lane of the wavefront (an idle lane reads cell 0), so that they sit in straight-line
 // code and the compiler's wait counts are exact
 template <bool TF>
 VR_HD void march_load(const SceneParams& P, MarchIO& io) {
-    io.maj1 = majorant_fetch<TF>(P.density, io.i1);
-    io.maj2 = majorant_fetch<TF>(P.density, io.i2);
+#pragma unroll
+    for (int k = 0; k < kMarchSteps; ++k) io.maj[k] = majorant_fetch<TF>(P.density, io.idx[k]);
 }
 template <bool TF>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
-    if (!io.go1) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
-    float t = io.t1, maj = io.i1 >= 0 ? majorant_value<TF>(P, io.maj1) : 0.0f;
-    float tau = h.tau - maj * io.dt1;
-    int32_t q = h.mipq < 12 ? h.mipq + 1 : 12;
-    if (tau > 0.0f) {                                              // no tentative collision in the first cell: second step
-        if (!io.go2) { h.t = t; h.tau = tau; h.mipq = q; h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
-        maj = io.i2 >= 0 ? majorant_value<TF>(P, io.maj2) : 0.0f;
-        t = io.t1 + io.dt2;
-        tau = tau - maj * io.dt2;
-        q = q < 12 ? q + 1 : 12;
-        if (tau > 0.0f) { h.t = t; h.tau = tau; h.mipq = q; return; }
+    float tau = h.tau, maj = 0.0f, t = h.t;
+    int32_t q = h.mipq;
+    bool collided = false;
+#pragma unroll
+    for (int k = 0; k < kMarchSteps; ++k) {
+        if (!collided) {
+            if (!io.go[k]) { h.t = t; h.tau = tau; h.mipq = q; h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+            maj = io.idx[k] >= 0 ? majorant_value<TF>(P, io.maj[k]) : 0.0f;
+            t = io.t[k];
+            tau = tau - maj * io.dt[k];
+            q = q < 12 ? q + 1 : 12;
+            collided = !(tau > 0.0f);
+        }
     }
+    if (!collided) { h.t = t; h.tau = tau; h.mipq = q; return; }    // still marching
     t += tau / maj;
     h.t = t; h.tau = tau; h.mipq = q;
     if (t >= h.far) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }

@@ -7,7 +7,7 @@ import numpy as np
 from . import _lib
 
 _INT_FIELDS = ("sample", "sppx", "seed", "bounces", "show_environment", "tonemapping", "integrator", "grid_frame_counter",
-               "sample_pool_mb", "gpu_encoder", "fast_math")
+               "sample_pool_mb", "gpu_encoder", "fast_math", "tf_float_atlas")
 _FLOAT_FIELDS = {"tonemap_exposure": 1, "tonemap_gamma": 1, "albedo": 3, "phase": 1, "density_scale": 1,
                  "emission_scale": 1, "vol_clip_min": 3, "vol_clip_max": 3, "env_strength": 1, "env_transform": 9,
                  "tf_window_left": 1, "tf_window_width": 1, "cam_pos": 3, "cam_dir": 3, "cam_up": 3, "cam_fov": 1,
