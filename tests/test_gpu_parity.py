@@ -808,6 +808,31 @@ def test_hip_within_1e3_of_reference_glsl_at_1024_spp():
             assert rl2 <= (3e-3 if fast and name == "hi_c3_tf_spec" else 1e-3), (name, "fast_math" if fast else "bit-exact", rl2)
 
 
+@pytest.mark.parametrize("n_entries", [2, 256, 300])
+def test_transfer_function_lut_paths(n_entries):
+    """The transfer-function kernels stage LUTs of up to 256 entries in LDS and read larger ones from global memory; brick
+    grids are sampled through the decoded float atlas (default) or the byte atlas (`tf_float_atlas = 0`).  Every combination
+    must equal the oracle bit for bit."""
+    rs = np.random.RandomState(n_entries)
+    lut = rs.uniform(0, 1, (n_entries, 4)).astype(np.float32)
+    lut[:, 3] = np.sort(lut[:, 3])                       # monotone alpha: used as given (no CDF fix-up)
+    o = scenes.oracle_scene("c2", 64, 48)
+    o.set_transferfunc(lut)
+    o.tf_window_left, o.tf_window_width = 0.02, 0.7
+    want = o.render(6).copy()
+    for float_atlas in (1, 0):
+        r = scenes.hip_scene("c2", 64, 48)
+        r.tf_float_atlas = float_atlas
+        r.set_transferfunc(lut)
+        r.tf_window_left, r.tf_window_width = 0.02, 0.7
+        r.render(6)
+        _assert_same(r.framebuffer(), want, "LUT with %d entries, float atlas %d" % (n_entries, float_atlas))
+        r.set_transferfunc(None)                        # back to the no-TF kernel: the decoded atlas is dropped, the image is c2's
+        r.reset()
+        r.render(2)
+        assert np.isfinite(r.framebuffer()).all()
+
+
 def test_raymarch_integrator_matches_oracle_and_reference():
     """integrator = 3: trace_path with the 64-step ray-marching trackers (common.glsl:506-566; code the reference contains but
     calls from no kernel).  Bit for bit against the oracle; the oracle itself is pinned against the reference's text run on
