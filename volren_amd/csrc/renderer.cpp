@@ -42,16 +42,6 @@ void RendererHIP::init() {
         environment = std::make_shared<Environment>(white, 1, 1);
     }
     if (!ev0_) { VR_HIP(hipEventCreate(&ev0_)); VR_HIP(hipEventCreate(&ev1_)); VR_HIP(hipEventCreate(&ev2_)); VR_HIP(hipEventCreate(&ev3_)); }
-    if (const char* m = getenv("VR_DIAG_CU_FRACTION")) {
-        // diagnostic: render on a stream restricted to every n-th CU (n = VR_DIAG_CU_FRACTION) -- separates per-CU limits
-        // (throughput ~ 1/n) from chip-wide ones (L2 / Infinity Fabric: throughput falls by less)
-        const int n = atoi(m);
-        if (n > 1 && !stream) {
-            uint32_t mask[8];
-            for (int w = 0; w < 8; ++w) { mask[w] = 0u; for (int b = 0; b < 32; ++b) if (((w * 32 + b) % n) == 0) mask[w] |= 1u << b; }
-            VR_HIP(hipExtStreamCreateWithCUMask(&stream, 8, mask));
-        }
-    }
     if (!status_) {
         status_ = make_device_buffer(16 * sizeof(uint32_t));         // [0] watchdog flag, [1..8] work-queue heads (one per XCD segment)
         VR_HIP(hipMemset(status_->get(), 0, 16 * sizeof(uint32_t)));
