@@ -612,6 +612,53 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
 #define VR_MARCH_STEPS 2
 #endif
 constexpr int32_t kMarchSteps = VR_MARCH_STEPS;
+#if VR_MARCH_STEPS == 2
+// the two-step form written out (the default; the generic loop below compiles ~1 % slower for the same arithmetic)
+struct MarchIO { float dt1, dt2, t1; uint32_t maj1, maj2; int32_t i1, i2; bool go1, go2; };     // i*: majorant cell or -1 (outside: majorant 0); maj*: as loaded (majorant_fetch)
+VR_HD void march_idle(MarchIO& io) { io.i1 = io.i2 = -1; io.dt1 = io.dt2 = io.t1 = 0.0f; io.go1 = io.go2 = false; }      // a lane that is not marching
+template <int DENSE = 2>
+VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
+    io.go1 = h.t < h.far;
+    const v3 c1 = axpy(h.ipos, h.t, h.idir);
+    const int32_t m1 = round_mip_q(h.mipq);
+    io.i1 = majorant_index<DENSE>(P.density, c1, m1);
+    io.dt1 = step_dda(c1, h.ri, m1);
+    io.t1 = h.t + io.dt1;
+    const int32_t q2 = h.mipq < 12 ? h.mipq + 1 : 12;              // mip = min(mip + 0.25, 3)
+    const int32_t m2 = round_mip_q(q2);
+    io.go2 = io.t1 < h.far;
+    const v3 c2 = axpy(h.ipos, io.t1, h.idir);
+    io.i2 = majorant_index<DENSE>(P.density, c2, m2);
+    io.dt2 = step_dda(c2, h.ri, m2);
+}
+// the loads: unconditional and for every lane of the wavefront (an idle lane reads cell 0), so that they sit in straight-line
+// code and the compiler's wait counts are exact
+template <bool TF>
+VR_HD void march_load(const SceneParams& P, MarchIO& io) {
+    io.maj1 = majorant_fetch<TF>(P.density, io.i1);
+    io.maj2 = majorant_fetch<TF>(P.density, io.i2);
+}
+template <bool TF>
+VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
+    if (!io.go1) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    float t = io.t1, maj = io.i1 >= 0 ? majorant_value<TF>(P, io.maj1) : 0.0f;
+    float tau = h.tau - maj * io.dt1;
+    int32_t q = h.mipq < 12 ? h.mipq + 1 : 12;
+    if (tau > 0.0f) {                                              // no tentative collision in the first cell: second step
+        if (!io.go2) { h.t = t; h.tau = tau; h.mipq = q; h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+        maj = io.i2 >= 0 ? majorant_value<TF>(P, io.maj2) : 0.0f;
+        t = io.t1 + io.dt2;
+        tau = tau - maj * io.dt2;
+        q = q < 12 ? q + 1 : 12;
+        if (tau > 0.0f) { h.t = t; h.tau = tau; h.mipq = q; return; }
+    }
+    t += tau / maj;
+    h.t = t; h.tau = tau; h.mipq = q;
+    if (t >= h.far) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    h.majorant = maj;
+    h.state = ST_COLLIDE;
+}
+#else
 struct MarchIO {
     float dt[kMarchSteps], t[kMarchSteps];      // step length; ray parameter after the step
     uint32_t maj[kMarchSteps];                  // majorant of the step's cell as loaded (majorant_fetch)
@@ -649,25 +696,25 @@ template <bool TF>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     float tau = h.tau, maj = 0.0f, t = h.t;
     int32_t q = h.mipq;
-    bool collided = false;
 #pragma unroll
     for (int k = 0; k < kMarchSteps; ++k) {
-        if (!collided) {
-            if (!io.go[k]) { h.t = t; h.tau = tau; h.mipq = q; h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
-            maj = io.idx[k] >= 0 ? majorant_value<TF>(P, io.maj[k]) : 0.0f;
-            t = io.t[k];
-            tau = tau - maj * io.dt[k];
-            q = q < 12 ? q + 1 : 12;
-            collided = !(tau > 0.0f);
-        }
+        if (!io.go[k]) { h.t = t; h.tau = tau; h.mipq = q; h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+        maj = io.idx[k] >= 0 ? majorant_value<TF>(P, io.maj[k]) : 0.0f;
+        t = io.t[k];
+        tau = tau - maj * io.dt[k];
+        q = q < 12 ? q + 1 : 12;
+        if (!(tau > 0.0f)) goto tentative_collision;
     }
-    if (!collided) { h.t = t; h.tau = tau; h.mipq = q; return; }    // still marching
+    h.t = t; h.tau = tau; h.mipq = q;                              // still marching
+    return;
+tentative_collision:
     t += tau / maj;
     h.t = t; h.tau = tau; h.mipq = q;
     if (t >= h.far) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
     h.majorant = maj;
     h.state = ST_COLLIDE;
 }
+#endif
 // one iteration (sequential form; the scheduler uses the two-phase form above)
 template <bool TF, int DENSE = 2>
 VR_HD void do_march(Hot& h, const SceneParams& P) {
