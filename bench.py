@@ -34,6 +34,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+GATHER_CEILINGS = {"l1": 1002.0, "l2": 268.0, "beyond_l2": 56.0}      # G per-lane accesses/s, whole chip, fully divergent dword loads (profiles/r2_gather_rate.txt)
 CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}
 
 
@@ -230,12 +231,26 @@ class Bench:
             traffic = tj["configs"][cfg]["hbm_bytes_per_sample"] * m["samples_per_launch"]
             traffic_src = {"from_profile": "profiles/r2_hbm_traffic.json", "note": "not measured by this run: rocprofv3 --pmc passes of %s, scaled to this launch's samples" % tj["configs"][cfg].get("command", "?")}
         variant = "dense" if cfg.startswith("c4") else ("emission" if cfg.startswith("c5") else "brick")
+        # second yardstick: the path tracer's loads are per-lane gathers, priced here at the throughput this GPU sustains for fully
+        # divergent wave-level loads served by L1 / L2 / beyond L2 (tests/tools_gather_rate.hip, profiles/r2_gather_rate.txt)
+        gather = None
+        if tj and cfg in tj.get("configs", {}):
+            ps, hit = tj["configs"][cfg]["per_sample"], tj["configs"][cfg]["l2_hit_rate"]
+            acc, miss = ps["l1_accesses"], ps["l1_misses_to_l2"]
+            beyond = miss * (1.0 - hit)
+            ns = (acc - miss) / GATHER_CEILINGS["l1"] + (miss - beyond) / GATHER_CEILINGS["l2"] + beyond / GATHER_CEILINGS["beyond_l2"]
+            model = 1e3 / ns                                                    # Msamples/s
+            kernel_rate = m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e6
+            gather = {"model": "additive: per-lane accesses x the measured cost of a fully divergent gather at the level that serves it",
+                      "ceilings_G_lane_accesses_per_s": GATHER_CEILINGS, "ceilings_source": "profiles/r2_gather_rate.txt",
+                      "per_sample": {"l1_accesses": acc, "l1_misses": miss, "beyond_l2": beyond}, "counts_source": "profiles/r2_hbm_traffic.json",
+                      "model_Msamples_s": model, "kernel_Msamples_s": kernel_rate, "kernel_over_model": kernel_rate / model}
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "pathtrace_kernel<TraceCfg<tf=%s, %s>, false>" % ("true" if use_tf else "false", variant),
                 "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "samples_per_launch": m["samples_per_launch"],
-                "bytes_per_sample": b_sample, "events_per_sample": events,
-                "note": "bytes = algorithmic (SURVEY 8d); the kernel is bound by per-wavefront instruction issue and gather latency, not by HBM bandwidth (DESIGN.md 7)"}
+                "bytes_per_sample": b_sample, "events_per_sample": events, "gather": gather,
+                "note": "bytes = algorithmic (SURVEY 8d); the kernel runs at the rate the vector memory path sustains for its scattered per-lane gathers (`gather`, DESIGN.md 7), not at HBM bandwidth: 2-9 useful bytes per 128-byte line"}
 
 
 def workload_name(config, w, h, spp):
