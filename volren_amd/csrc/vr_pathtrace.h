@@ -414,7 +414,8 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_ESC * NS + cnt_esc - 1 - lane];
                     hs.load(b, bs);
-                    ColdT c{ cold_base + bs * kColdSlotStride };
+                    // a camera ray that missed the box carries its own state (do_new): its loads go to slot 0's line, shared by the batch
+                    ColdT c{ cold_base + (b.shadow == kPrimaryMiss ? 0 : bs) * kColdSlotStride };
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
                     do_escape(b, c, E.P, w);                              // writes the sample; the slot becomes free

@@ -524,6 +524,7 @@ VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
 
 // ---------------------------------------------------------------------------------------------------
 // state bodies
+constexpr int32_t kPrimaryMiss = 2;      // Hot::shadow of a path whose camera ray missed the box (do_new -> do_escape)
 
 VR_HD void hot_init(Hot& h) {
     h.seed = 0u;
@@ -554,15 +555,17 @@ VR_HD void accumulate_sample(float acc[4], const float L[4], int32_t current_sam
 }
 
 // head of sample_volumeDDA / transmittanceDDA (common.glsl:413-421, 459-468) for the ray (pos, d)
+// returns false when the ray misses the volume's box altogether (nothing of the segment has been set up then)
 template <class K>
-VR_HD void begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t shadow) {
+VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t shadow, int32_t shadow_if_missed) {
     h.shadow = shadow;
     h.Tr = 1.0f;          // both set before the branch on purpose: conditional stores to different fields make the
     h.mipq = 12;          // mip = 3; compiler address-select between them, which forces the state into scratch memory
     float tnear, tfar;
     if (!intersect_box(pos, d, P.u.vol_bb_min, P.u.vol_bb_max, tnear, tfar)) {
+        h.shadow = shadow_if_missed;
         h.state = shadow ? ST_POSTNEE : ST_ESCAPE;
-        return;
+        return false;
     }
     h.ipos = mat4_point(P.u.vol_density_inv_transform, pos);
     h.idir = mat4_dir(P.u.vol_density_inv_transform, d);
@@ -575,12 +578,13 @@ VR_HD void begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
         h.t = tnear + neg_log_1m(rng(h.seed)) * P.u.vol_inv_majorant;
         if (h.t < h.far) { h.majorant = P.u.vol_majorant; h.state = ST_COLLIDE; }
         else h.state = shadow ? ST_POSTNEE : ST_ESCAPE;
-        return;
+        return true;
     }
     h.ri = v3{ 1.0f / h.idir.x, 1.0f / h.idir.y, 1.0f / h.idir.z };
     h.t = tnear + 1e-6f;
     h.tau = neg_log_1m(rng(h.seed));
     h.state = ST_MARCH;
+    return true;
 }
 
 // pathtracer_brick.glsl:27-30 + common.glsl:76-80; the lane has just been given `item` (< n_items)
@@ -596,10 +600,16 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
     const float fy = (((float)py + jy) - (float)H * 0.5f) / (float)H;
     const v3 dir = normalize(mat3_mul(P.u.cam_transform, normalize(v3{ fx, fy, P.cam_z })));
     const v3 pos = v3{ P.u.cam_pos[0], P.u.cam_pos[1], P.u.cam_pos[2] };
+    // A camera ray that misses the box (a third of the samples of the bench scene) waits for the escape batch with all it needs --
+    // direction and sample slot -- in its hot state (fields that a path without a segment does not use), flagged kPrimaryMiss: its
+    // cold line is neither written here nor read there.
+    const bool hit = begin_segment<K>(h, P, pos, dir, 0, kPrimaryMiss);
+    h.ipos = v3{ hit ? h.ipos.x : dir.x, hit ? h.ipos.y : dir.y, hit ? h.ipos.z : dir.z };
+    h.far = hit ? h.far : u2f(wu.base + item);
+    if (!hit) return;
     st3(c, C_POS, pos); st3(c, C_DIR, dir);
     st3(c, C_L, v3{ 0, 0, 0 }); st3(c, C_THR, v3{ 1, 1, 1 });
     stu(c, C_NPATHS, 0u); c.st(C_FP, 0.0f); stu(c, C_ITEM, wu.base + item);    // C_ITEM: global slot in the sample buffer
-    begin_segment<K>(h, P, pos, dir, 0);
 }
 
 // Loop body of both DDA trackers up to the collision test (common.glsl:422-435, 469-482), kMarchSteps iterations at a time and
@@ -869,7 +879,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const SceneParams& P) {
         c.st(C_FP, f_p);
         st3(c, C_SHA, (ld3(c, C_THR) * mis) * f_p);
         st3(c, C_SHLE, Le);
-        begin_segment<K>(h, P, pos, w_i, 1);
+        begin_segment<K>(h, P, pos, w_i, 1, 1);
     } else {
         c.st(C_SHPDF, 0.0f);           // marks "no next-event estimate" for do_postnee (pdf <= 0 or NaN)
         h.shadow = 0;
@@ -902,25 +912,36 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
     const v3 sd = sample_phase_hg(dir, P.u.vol_phase_g, s0, s1);
     c.st(C_FP, phase_hg(dot(-dir, sd), P.u.vol_phase_g));
     st3(c, C_DIR, sd);
-    begin_segment<K>(h, P, ld3(c, C_POS), sd, 0);
+    begin_segment<K>(h, P, ld3(c, C_POS), sd, 0, 0);
 }
 
 // common.glsl:644-651
 template <class Cold>
 VR_HD void do_escape(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
-    v3 L = ld3(c, C_L);
-    const uint32_t n_paths = ldu(c, C_NPATHS);
+    // do_new's camera ray that missed the box: L = 0, throughput = 1, no scatter; direction and sample slot ride in the hot state.
+    // The loads stay unconditional (value selects afterwards; a conditional block makes the compiler select between the cold
+    // pointer and a stack copy of the hot state = scratch memory): the scheduler points `c` of such a path at a line the whole
+    // batch shares.
+    const bool direct = h.shadow == kPrimaryMiss;
+    v3 L = ld3(c, C_L), thr = ld3(c, C_THR), dir = ld3(c, C_DIR);
+    uint32_t n_paths = ldu(c, C_NPATHS), item = ldu(c, C_ITEM);
+    const float f_p = c.ld(C_FP);
+    L = v3{ direct ? 0.0f : L.x, direct ? 0.0f : L.y, direct ? 0.0f : L.z };                     // component-wise on purpose: a ternary
+    thr = v3{ direct ? 1.0f : thr.x, direct ? 1.0f : thr.y, direct ? 1.0f : thr.z };           // on the structs selects addresses
+    dir = v3{ direct ? h.ipos.x : dir.x, direct ? h.ipos.y : dir.y, direct ? h.ipos.z : dir.z };
+    n_paths = direct ? 0u : n_paths;
+    item = direct ? f2u(h.far) : item;
     if (P.u.show_environment > 0) {
-        const v3 Le = lookup_environment(P, ld3(c, C_DIR));
+        const v3 Le = lookup_environment(P, dir);
         float mis = 1.0f;
         if (n_paths > 0u) {
             const float avg_w = imp_fetch(P, 0, 0, P.u.env_imp_base_mip);
             const float pdf_env = (luma(Le) / avg_w) * kInv4Pi;
-            mis = power_heuristic(c.ld(C_FP), pdf_env);
+            mis = power_heuristic(f_p, pdf_env);
         }
-        L = L + (ld3(c, C_THR) * mis) * Le;
+        L = L + (thr * mis) * Le;
     }
-    write_sample(wu, ldu(c, C_ITEM), L, n_paths);
+    write_sample(wu, item, L, n_paths);
     h.state = ST_NEW;
 }
 
