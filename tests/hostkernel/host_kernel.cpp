@@ -180,6 +180,7 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
                 };
                 Hot lanes[64];
                 ColdHost cold[64] = {};
+                FirstStash stash[64] = {};
                 for (auto& l : lanes) hot_init(l);
                 uint32_t next_item = 0;
                 bool live = true;
@@ -189,7 +190,8 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
                         Hot& l = lanes[i];
                         if (l.state == ST_DONE) continue;
                         live = true;
-                        if (u.use_tf) lane_step<TraceCfg<true, 2, 2, 2>>(l, cold[i], P, wu, next_item); else lane_step<TraceCfg<false, 2, 2, 2>>(l, cold[i], P, wu, next_item);
+                        if (l.state == ST_NEW) for (float& v : cold[i].v) v = nan_();         // a new path must not depend on what its cold line held
+                        if (u.use_tf) lane_step<TraceCfg<true, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]); else lane_step<TraceCfg<false, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]);
                         if (++steps > (1ll << 40)) return -1;
                     }
                 }

@@ -3,6 +3,7 @@
 profiles/r2_hbm_traffic.json (memory-side traffic, L1/L2 request counts, instruction mix).
 
     python3 tests/tools_pmc_summary.py <dir> <tag>=<samples> [...]  > summary.json
+    python3 tests/tools_pmc_summary.py --merge summary.json profiles/r2_hbm_traffic.json c2=c2 c4=c4_512 c3=c3
 
 <dir> holds one sub-directory per pass, pmc_<tag>_<first counter of the set>/out_counter_collection.csv (the layout the
 collection scripts under build/ write); <samples> = pixel-samples traced by ALL path-tracing dispatches of one pass.
@@ -25,7 +26,23 @@ def sums(path):
     return out
 
 
+def merge(summary, target, names):
+    """--merge <profiles/r2_hbm_traffic.json> c2=c2 c4=c4_512 ...: refresh the measured fields of the committed profile"""
+    old = json.load(open(target))
+    for cfg, tag in names.items():
+        o, n = old["configs"][cfg], summary[tag]
+        for f in ("fetch_bytes_per_sample", "write_bytes_per_sample", "hbm_bytes_per_sample", "l2_hit_rate", "per_sample", "lane_utilisation", "wave_cycles_share"):
+            o[f] = n[f]
+        o["traffic_over_algorithmic"] = round(n["hbm_bytes_per_sample"] / o["algorithmic_bytes_per_sample"], 2)
+        o.setdefault("tcp", {}).update({"l2_read_latency_cycles": n["tcp"]["l2_read_latency_cycles"], "pending_stall_cycles_per_sample": n["tcp"]["pending_stall_per_sample"]})
+    json.dump(old, open(target, "w"), indent=1)
+
+
 def main():
+    if sys.argv[1] == "--merge":
+        summary = json.load(open(sys.argv[2]))
+        merge(summary, sys.argv[3], dict(a.split("=") for a in sys.argv[4:]))
+        return
     root = sys.argv[1]
     res = {}
     for spec in sys.argv[2:]:

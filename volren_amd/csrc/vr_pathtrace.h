@@ -101,17 +101,31 @@ enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE
 constexpr int32_t HOT_STRIDE = 15;     // dwords per slot in LDS (= the parked fields): odd, so that lanes with different slots spread over the banks
 struct HotStore {                      // [slot][field]: a path's 15 parked dwords are adjacent (ds_read2/ds_write2 pairs)
     uint32_t* base;
+    float cam_ipos[3];                 // index-space position of the camera (wave-uniform): ipos of every `first` path, see FirstStash
     // mip (a multiple of 1/4 in [0,3]) rides in the flag word
-    __device__ __forceinline__ void save(const Hot& h, int32_t slot) const {
+    __device__ __forceinline__ static uint32_t flags(const Hot& h) { return (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)h.first << 12) | ((uint32_t)h.mipq << 16); }
+    // a new path: everything, with the stash (world direction, sample slot) in the places of ipos and Tr
+    __device__ __forceinline__ void save_new(const Hot& h, int32_t slot) const {
         uint32_t* p = base + slot * HOT_STRIDE;
         p[0] = h.seed;
         p[1] = f2u(h.ipos.x); p[2] = f2u(h.ipos.y); p[3] = f2u(h.ipos.z);
         p[4] = f2u(h.idir.x); p[5] = f2u(h.idir.y); p[6] = f2u(h.idir.z);
         p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
         p[10] = f2u(h.Tr);
-        p[11] = (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)h.mipq << 16);
+        p[11] = flags(h);
         p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z);
     }
+    // any later store: a `first` path's stash stays where it is
+    __device__ __forceinline__ void save(const Hot& h, int32_t slot) const {
+        uint32_t* p = base + slot * HOT_STRIDE;
+        p[0] = h.seed;
+        if (!h.first) { p[1] = f2u(h.ipos.x); p[2] = f2u(h.ipos.y); p[3] = f2u(h.ipos.z); p[10] = f2u(h.Tr); }
+        p[4] = f2u(h.idir.x); p[5] = f2u(h.idir.y); p[6] = f2u(h.idir.z);
+        p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
+        p[11] = flags(h);
+        p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z);
+    }
+    // for an event batch: the slot as it is (a `first` path's ipos / Tr = its stash, which is what do_nee / do_escape want)
     __device__ __forceinline__ void load(Hot& h, int32_t slot) const {
         const uint32_t* p = base + slot * HOT_STRIDE;
         h.seed = p[0];
@@ -121,9 +135,16 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         h.t = u2f(p[7]); h.far = u2f(p[8]); h.tau = u2f(p[9]);
         h.Tr = u2f(p[10]);
         const uint32_t f = p[11];
-        h.state = (int32_t)(f & 0xFFu); h.shadow = (int32_t)((f >> 8) & 0xFFu);
+        h.state = (int32_t)(f & 0xFFu); h.shadow = (int32_t)((f >> 8) & 0xFu); h.first = (int32_t)((f >> 12) & 0xFu);
         h.mipq = (int32_t)(f >> 16);
         h.majorant = 0.0f;
+    }
+    // for marching: a `first` path gets the real values of the two fields (= first_resume, vr_trace.h)
+    __device__ __forceinline__ void load_resume(Hot& h, int32_t slot) const {
+        load(h, slot);
+        const bool first = h.first != 0;
+        h.ipos = v3{ first ? cam_ipos[0] : h.ipos.x, first ? cam_ipos[1] : h.ipos.y, first ? cam_ipos[2] : h.ipos.z };
+        h.Tr = first ? 1.0f : h.Tr;
     }
 };
 // Cold path state of one wavefront in global memory: one 128-byte line per path slot (slot-major).  Measured alternative
@@ -229,7 +250,14 @@ pathtrace_kernel(const KernelArgs A) {
     float* const cold_base = A.cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)kColdWaveFloats;
 #endif
     __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NS];
-    const HotStore hs{ lds_hot + wave * (HOT_STRIDE * NS) };
+    HotStore hs;
+    hs.base = lds_hot + wave * (HOT_STRIDE * NS);
+    {   // wave-uniform: keep it in scalar registers
+        const v3 ci = mat4_point(P.u.vol_density_inv_transform, v3{ P.u.cam_pos[0], P.u.cam_pos[1], P.u.cam_pos[2] });      // == first_resume
+        hs.cam_ipos[0] = u2f(__builtin_amdgcn_readfirstlane(f2u(ci.x)));
+        hs.cam_ipos[1] = u2f(__builtin_amdgcn_readfirstlane(f2u(ci.y)));
+        hs.cam_ipos[2] = u2f(__builtin_amdgcn_readfirstlane(f2u(ci.z)));
+    }
     // transfer function: the LUT (tf_size x vec4, 128 B for lut.txt, 4 KiB for a 256-entry colour map) is read twice per
     // tentative collision; one copy per workgroup in LDS replaces those global gathers.  Larger LUTs stay in global memory.
     __shared__ float lds_lut[K::tf ? 4 * kLutLdsEntries : 4];
@@ -318,7 +346,7 @@ pathtrace_kernel(const KernelArgs A) {
             if (take > 0) {
                 if (slot < 0) {
                     const int32_t r = (int32_t)lane_rank(idle);
-                    if (r < take) { slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load(l, slot); }
+                    if (r < take) { slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load_resume(l, slot); }
                 }
                 cnt_ready -= take;
             }
@@ -414,8 +442,8 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_ESC * NS + cnt_esc - 1 - lane];
                     hs.load(b, bs);
-                    // a camera ray that missed the box carries its own state (do_new): its loads go to slot 0's line, shared by the batch
-                    ColdT c{ cold_base + (b.shadow == kPrimaryMiss ? 0 : bs) * kColdSlotStride };
+                    // a path that never scattered carries what it needs in its stash (FirstStash): its loads go to slot 0's line, shared by the batch
+                    const ColdT c{ cold_base + (b.first ? 0 : bs) * kColdSlotStride };
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
                     do_escape(b, c, E.P, w);                              // writes the sample; the slot becomes free
@@ -465,7 +493,7 @@ pathtrace_kernel(const KernelArgs A) {
                         hot_init(b);
                         ColdT c{ cold_base + bs * kColdSlotStride };
                         do_new<K>(b, c, event_args().P, wu, cursor + (uint32_t)lane);
-                        hs.save(b, bs);
+                        hs.save_new(b, bs);
                     }
                     cnt_free -= n;
                     cursor += (uint32_t)n;
@@ -481,7 +509,8 @@ pathtrace_kernel(const KernelArgs A) {
                     bs = q[Q_NEE * NS + cnt_nee - 1 - lane];
                     hs.load(b, bs);
                     ColdT c{ cold_base + bs * kColdSlotStride };
-                    do_nee<K>(b, c, event_args().P);
+                    const ColdT crd{ cold_base + (b.first ? 0 : bs) * kColdSlotStride };      // first scatter of a path: nothing to read yet (do_nee)
+                    do_nee<K>(b, c, crd, event_args().P);
                     hs.save(b, bs);
                 }
                 cnt_nee -= n;
@@ -490,7 +519,7 @@ pathtrace_kernel(const KernelArgs A) {
             }
 #if !VR_BATCH_REGS
             __builtin_amdgcn_wave_barrier();
-            if (my_slot >= 0) hs.load(l, my_slot);
+            if (my_slot >= 0) hs.load_resume(l, my_slot);
 #endif
         }
         if (exhausted && cnt_free == VR_POOL) break;                        // every path of the pool has finished

@@ -64,7 +64,16 @@ struct Hot {
     int32_t mipq;            // 4 * mip: the DDA level moves in quarter steps (common.glsl:433,450), kept as an integer
     int32_t shadow;          // 0: sample_volumeDDA segment, 1: transmittanceDDA segment
     int32_t state;
+    int32_t first;           // 1: the camera segment of a new path whose cold line has not been written yet (see FirstStash)
 };
+// A new path needs nothing of its cold line until its first event: position = the camera's, throughput 1, radiance 0, no
+// scatter yet.  What it does need there -- its world direction and its slot in the sample buffer -- waits in the path's hot
+// storage, in the places of two fields that are redundant during a camera segment: ipos (the same for every camera ray:
+// first_resume recomputes it) and Tr (1).  So do_new writes no cold line, a path that escapes without scattering (or misses
+// the box) never touches one, and the first scatter event writes the line without having to read it: for the bench scene
+// 0.7 line fetches and 0.7 partial line writes fewer per sample, from memory that sits beyond the L2.
+// On the GPU the stash is the parked path's LDS slot (HotStore, vr_pathtrace.h); the host harness keeps it in a FirstStash.
+struct FirstStash { v3 dir; uint32_t item; };
 // Cold: path state that only the rare events (new sample, scatter, escape) read or write.  On the GPU it is parked
 // in LDS ([field][lane] dwords, conflict-free) so that it does not occupy registers while the lane marches; the
 // host harness backs it with a plain array.  `Cold` is any type with float ld(int) / void st(int, float).
@@ -524,7 +533,6 @@ VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
 
 // ---------------------------------------------------------------------------------------------------
 // state bodies
-constexpr int32_t kPrimaryMiss = 2;      // Hot::shadow of a path whose camera ray missed the box (do_new -> do_escape)
 
 VR_HD void hot_init(Hot& h) {
     h.seed = 0u;
@@ -533,6 +541,7 @@ VR_HD void hot_init(Hot& h) {
     h.mipq = 0;
     h.shadow = 0;
     h.state = ST_NEW;
+    h.first = 0;
 }
 
 // result of trace_path: vec4(L, clamp(n_paths, 0, 1)) -> the item's slot of the sample buffer
@@ -557,13 +566,12 @@ VR_HD void accumulate_sample(float acc[4], const float L[4], int32_t current_sam
 // head of sample_volumeDDA / transmittanceDDA (common.glsl:413-421, 459-468) for the ray (pos, d)
 // returns false when the ray misses the volume's box altogether (nothing of the segment has been set up then)
 template <class K>
-VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t shadow, int32_t shadow_if_missed) {
+VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t shadow) {
     h.shadow = shadow;
     h.Tr = 1.0f;          // both set before the branch on purpose: conditional stores to different fields make the
     h.mipq = 12;          // mip = 3; compiler address-select between them, which forces the state into scratch memory
     float tnear, tfar;
     if (!intersect_box(pos, d, P.u.vol_bb_min, P.u.vol_bb_max, tnear, tfar)) {
-        h.shadow = shadow_if_missed;
         h.state = shadow ? ST_POSTNEE : ST_ESCAPE;
         return false;
     }
@@ -600,16 +608,24 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
     const float fy = (((float)py + jy) - (float)H * 0.5f) / (float)H;
     const v3 dir = normalize(mat3_mul(P.u.cam_transform, normalize(v3{ fx, fy, P.cam_z })));
     const v3 pos = v3{ P.u.cam_pos[0], P.u.cam_pos[1], P.u.cam_pos[2] };
-    // A camera ray that misses the box (a third of the samples of the bench scene) waits for the escape batch with all it needs --
-    // direction and sample slot -- in its hot state (fields that a path without a segment does not use), flagged kPrimaryMiss: its
-    // cold line is neither written here nor read there.
-    const bool hit = begin_segment<K>(h, P, pos, dir, 0, kPrimaryMiss);
-    h.ipos = v3{ hit ? h.ipos.x : dir.x, hit ? h.ipos.y : dir.y, hit ? h.ipos.z : dir.z };
-    h.far = hit ? h.far : u2f(wu.base + item);
-    if (!hit) return;
-    st3(c, C_POS, pos); st3(c, C_DIR, dir);
-    st3(c, C_L, v3{ 0, 0, 0 }); st3(c, C_THR, v3{ 1, 1, 1 });
-    stu(c, C_NPATHS, 0u); c.st(C_FP, 0.0f); stu(c, C_ITEM, wu.base + item);    // C_ITEM: global slot in the sample buffer
+    const bool hit = begin_segment<K>(h, P, pos, dir, 0);
+    // With an emission grid the collision code accumulates into the cold line during the camera segment: then the line is
+    // initialised here; otherwise not at all (FirstStash).  A ray that misses the box never collides: always a `first` path.
+    const bool lazy = !hit || !(K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1);
+    if (!lazy) {
+        st3(c, C_POS, pos); st3(c, C_DIR, dir);
+        st3(c, C_L, v3{ 0, 0, 0 }); st3(c, C_THR, v3{ 1, 1, 1 });
+        stu(c, C_NPATHS, 0u); c.st(C_FP, 0.0f); stu(c, C_ITEM, wu.base + item);    // C_ITEM: global slot in the sample buffer
+    }
+    // the stash travels in ipos / Tr until the path is stored (HotStore::save_new; host: lane_step)
+    h.first = lazy ? 1 : 0;
+    h.ipos = v3{ lazy ? dir.x : h.ipos.x, lazy ? dir.y : h.ipos.y, lazy ? dir.z : h.ipos.z };
+    h.Tr = lazy ? u2f(wu.base + item) : h.Tr;
+}
+// a `first` path leaves its storage to march: the two fields that held the stash get their real values
+VR_HD void first_resume(Hot& h, const SceneParams& P) {
+    h.ipos = mat4_point(P.u.vol_density_inv_transform, v3{ P.u.cam_pos[0], P.u.cam_pos[1], P.u.cam_pos[2] });      // as begin_segment computed it
+    h.Tr = 1.0f;
 }
 
 // Loop body of both DDA trackers up to the collision test (common.glsl:422-435, 469-482), kMarchSteps iterations at a time and
@@ -854,20 +870,34 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
     collide_finish<K>(h, c, P, io, P.tf_lut);
 }
 
-// real collision: common.glsl:611-626 up to (and including the set-up of) the transmittance call
+// real collision: common.glsl:611-626 up to (and including the set-up of) the transmittance call.
+// `crd` is what the path's state is READ from: its own cold line, or -- for a `first` path, whose line holds nothing yet and whose
+// loads are discarded -- any line that is cheap to read (the scheduler passes one that the whole batch shares).  The loads stay
+// unconditional, followed by component-wise selects: a conditional block makes the compiler select between addresses and put
+// the path state into scratch memory.
 template <class K, class Cold>
-VR_HD void do_nee(Hot& h, Cold& c, const SceneParams& P) {
-    const v3 dir = ld3(c, C_DIR);
-    const v3 pos = axpy(ld3(c, C_POS), h.t, dir);
+VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
+    const bool first = h.first != 0;
+    v3 dir = ld3(crd, C_DIR), pos0 = ld3(crd, C_POS), thr = ld3(crd, C_THR);
+    dir = v3{ first ? h.ipos.x : dir.x, first ? h.ipos.y : dir.y, first ? h.ipos.z : dir.z };
+    pos0 = v3{ first ? P.u.cam_pos[0] : pos0.x, first ? P.u.cam_pos[1] : pos0.y, first ? P.u.cam_pos[2] : pos0.z };
+    thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
+    const v3 pos = axpy(pos0, h.t, dir);
     st3(c, C_POS, pos);
     // the real collision that led here: throughput *= albedo [* rgba.rgb] (common.glsl:383-388, 491-495; see collide_finish)
     {
         const v3 alb = v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };
-        v3 thr = ld3(c, C_THR);
         if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) thr = K::tf ? thr * (ld3(c, C_SHLE) * alb) : thr * alb;
         else { thr = thr * alb; if (K::tf) thr = thr * ld3(c, C_SHLE); }
         st3(c, C_THR, thr);
     }
+    if (first) {
+        // what do_new left unwritten
+        st3(c, C_DIR, dir); stu(c, C_NPATHS, 0u);
+        st3(c, C_L, v3{ 0, 0, 0 }); stu(c, C_ITEM, f2u(h.Tr));
+        c.st(C_FP, 0.0f);
+    }
+    h.first = 0;
     const float r0 = rng(h.seed), r1 = rng(h.seed);
     float pdf;
     v3 w_i, Le;
@@ -877,9 +907,9 @@ VR_HD void do_nee(Hot& h, Cold& c, const SceneParams& P) {
         const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
         const float mis = P.u.show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
         c.st(C_FP, f_p);
-        st3(c, C_SHA, (ld3(c, C_THR) * mis) * f_p);
+        st3(c, C_SHA, (thr * mis) * f_p);
         st3(c, C_SHLE, Le);
-        begin_segment<K>(h, P, pos, w_i, 1, 1);
+        begin_segment<K>(h, P, pos, w_i, 1);
     } else {
         c.st(C_SHPDF, 0.0f);           // marks "no next-event estimate" for do_postnee (pdf <= 0 or NaN)
         h.shadow = 0;
@@ -912,25 +942,24 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
     const v3 sd = sample_phase_hg(dir, P.u.vol_phase_g, s0, s1);
     c.st(C_FP, phase_hg(dot(-dir, sd), P.u.vol_phase_g));
     st3(c, C_DIR, sd);
-    begin_segment<K>(h, P, ld3(c, C_POS), sd, 0, 0);
+    begin_segment<K>(h, P, ld3(c, C_POS), sd, 0);
 }
 
 // common.glsl:644-651
+// `c` of a `first` path (never scattered: L = 0, throughput 1; direction and sample slot in the stash) is only read and the
+// values discarded: the scheduler points it at a line the batch shares (see do_nee)
 template <class Cold>
-VR_HD void do_escape(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
-    // do_new's camera ray that missed the box: L = 0, throughput = 1, no scatter; direction and sample slot ride in the hot state.
-    // The loads stay unconditional (value selects afterwards; a conditional block makes the compiler select between the cold
-    // pointer and a stack copy of the hot state = scratch memory): the scheduler points `c` of such a path at a line the whole
-    // batch shares.
-    const bool direct = h.shadow == kPrimaryMiss;
+VR_HD void do_escape(Hot& h, const Cold& c, const SceneParams& P, const WorkUnit& wu) {
+    const bool first = h.first != 0;
     v3 L = ld3(c, C_L), thr = ld3(c, C_THR), dir = ld3(c, C_DIR);
     uint32_t n_paths = ldu(c, C_NPATHS), item = ldu(c, C_ITEM);
     const float f_p = c.ld(C_FP);
-    L = v3{ direct ? 0.0f : L.x, direct ? 0.0f : L.y, direct ? 0.0f : L.z };                     // component-wise on purpose: a ternary
-    thr = v3{ direct ? 1.0f : thr.x, direct ? 1.0f : thr.y, direct ? 1.0f : thr.z };           // on the structs selects addresses
-    dir = v3{ direct ? h.ipos.x : dir.x, direct ? h.ipos.y : dir.y, direct ? h.ipos.z : dir.z };
-    n_paths = direct ? 0u : n_paths;
-    item = direct ? f2u(h.far) : item;
+    L = v3{ first ? 0.0f : L.x, first ? 0.0f : L.y, first ? 0.0f : L.z };
+    thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
+    dir = v3{ first ? h.ipos.x : dir.x, first ? h.ipos.y : dir.y, first ? h.ipos.z : dir.z };
+    n_paths = first ? 0u : n_paths;
+    item = first ? f2u(h.Tr) : item;
+    h.first = 0;
     if (P.u.show_environment > 0) {
         const v3 Le = lookup_environment(P, dir);
         float mis = 1.0f;
@@ -1097,15 +1126,18 @@ VR_HD void raymarch_path_sample(const SceneParams& P, int32_t px, int32_t py, in
 
 // sequential driver (host harness / reference order): one state transition of one lane
 template <class K, class Cold>
-VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uint32_t& next_item) {
+VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uint32_t& next_item, FirstStash& stash) {
+    // the events of a `first` path see its stash in ipos / Tr, as the GPU's event batches do after loading the parked path
+    if (h.first && (h.state == ST_NEE || h.state == ST_ESCAPE)) { h.ipos = stash.dir; h.Tr = u2f(stash.item); }
     switch (h.state) {
     case ST_NEW:
         if (next_item >= (uint32_t)wu.n_items) { h.state = ST_DONE; break; }
         do_new<K>(h, c, P, wu, next_item++);
+        if (h.first) { stash.dir = h.ipos; stash.item = f2u(h.Tr); first_resume(h, P); }      // = HotStore::save_new + load_resume
         break;
     case ST_MARCH: { MarchIO io; march_prep<K::dense>(h, P, io); march_load<K::tf>(P, io); march_finish<K::tf>(h, P, io); break; }     // two DDA steps, as on the device
     case ST_COLLIDE: do_collide<K>(h, c, P); break;
-    case ST_NEE: do_nee<K>(h, c, P); break;
+    case ST_NEE: do_nee<K>(h, c, c, P); break;
     case ST_POSTNEE: do_postnee<K>(h, c, P, wu); break;
     case ST_ESCAPE: do_escape(h, c, P, wu); break;
     default: break;
