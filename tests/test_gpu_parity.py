@@ -912,3 +912,15 @@ def test_sample_pool_falls_back_when_memory_is_short(monkeypatch):
     r2.render(512)
     assert r2.last_launches == 1
     _assert_same(img, r2.framebuffer(), "split launches vs one launch")
+
+
+@pytest.mark.parametrize("config", ["c1", "c3", "c5:32"])
+def test_no_path_depends_on_stale_cold_state(config, monkeypatch):
+    """A new path writes no cold line before its first scatter event (FirstStash, vr_trace.h) and a path that never scatters
+    none at all: whatever the workspace held before -- here NaN patterns (VR_TEST_POISON_WORKSPACE, renderer.cpp) -- must
+    not reach a result.  c5: with an emission grid the collision code accumulates into the line from the first segment on."""
+    monkeypatch.setenv("VR_TEST_POISON_WORKSPACE", "1")
+    r, o = scenes.hip_scene(config, 96, 64), scenes.oracle_scene(config, 96, 64)
+    r.render(4)                                   # the workspace is allocated (and poisoned) by the first launch
+    monkeypatch.delenv("VR_TEST_POISON_WORKSPACE")
+    _assert_same(r.framebuffer(), o.render(4), "poisoned workspace, " + config)

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
@@ -424,7 +425,11 @@ void RendererHIP::launch(int n) {
             if (per_launch > 32) per_launch -= per_launch % 32;
         }
     }
-    if (!workspace_) workspace_ = make_device_buffer(pathtrace_workspace_floats() * sizeof(float));
+    if (!workspace_) {
+        workspace_ = make_device_buffer(pathtrace_workspace_floats() * sizeof(float));
+        // test hook: no path may depend on what its cold line held before the path wrote it (tests/test_gpu_parity.py)
+        if (const char* e = std::getenv("VR_TEST_POISON_WORKSPACE"); e && *e == '1') VR_HIP(hipMemsetAsync(workspace_->get(), 0xFF, workspace_->size_bytes(), stream));
+    }
     VR_HIP(hipEventRecord(ev0_, stream));
     last_launches = 0;
     for (int done = 0; done < n; done += per_launch) {
