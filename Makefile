@@ -13,6 +13,10 @@ PT_VARIANTS := 0 1 2 3
 OBJS     := $(OBJDIR)/vr_kernels.o $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_%.o) $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_fast_%.o) $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
 # tolerance-mode kernels (opt-in, vr_math.h VR_FAST_MATH): hardware transcendentals, reciprocal division, contraction allowed
 FASTFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result -Iinclude -DVR_FAST_MATH=1
+# path-tracing kernels: no SLP vectorisation.  On gfx950 a packed fp32 instruction (v_pk_mul/add/fma_f32) occupies the SIMD for
+# 4.2 cycles against 1.8 for the plain one (profiles/r2_valu_issue_rate.txt) and needs extra moves to pair its operands: the
+# scalar form of the same arithmetic is 4 % (c2) / 2 % (c3) / 1 % (c4) faster (profiles/r2p_compiler_flags.txt); results identical.
+PTFLAGS  := -fno-slp-vectorize
 HDRS     := $(wildcard $(CSRC)/*.h) include/volren_amd.h
 
 all: volren_amd/libvolren_amd.so volren_amd/volren oracle
@@ -24,11 +28,11 @@ $(OBJDIR)/vr_kernels.o: $(CSRC)/vr_kernels.hip $(HDRS)
 # the path-tracing kernel, one compilation per variant (vr_pathtrace.hip); resource usage goes to build/*.resources.txt
 $(OBJDIR)/vr_pathtrace_%.o: $(CSRC)/vr_pathtrace.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_pathtrace_$*.resources.txt || (cat $(OBJDIR)/vr_pathtrace_$*.resources.txt; false)
+	$(HIPCC) $(HIPFLAGS) $(PTFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_pathtrace_$*.resources.txt || (cat $(OBJDIR)/vr_pathtrace_$*.resources.txt; false)
 
 $(OBJDIR)/vr_pathtrace_fast_%.o: $(CSRC)/vr_pathtrace.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(FASTFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_pathtrace_fast_$*.resources.txt || (cat $(OBJDIR)/vr_pathtrace_fast_$*.resources.txt; false)
+	$(HIPCC) $(FASTFLAGS) $(PTFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_pathtrace_fast_$*.resources.txt || (cat $(OBJDIR)/vr_pathtrace_fast_$*.resources.txt; false)
 
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)

@@ -8,7 +8,7 @@ out=build/exp_$name; mkdir -p $out
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -Iinclude"
 pids=""
 for v in 0 1 2 3; do
-  /opt/rocm/bin/hipcc $FLAGS -DVR_PT_VARIANT=$v "$@" -Rpass-analysis=kernel-resource-usage -c volren_amd/csrc/vr_pathtrace.hip -o $out/vr_pathtrace_$v.o 2> $out/res_$v.txt &
+  /opt/rocm/bin/hipcc $FLAGS -fno-slp-vectorize -DVR_PT_VARIANT=$v "$@" -Rpass-analysis=kernel-resource-usage -c volren_amd/csrc/vr_pathtrace.hip -o $out/vr_pathtrace_$v.o 2> $out/res_$v.txt &
   pids="$pids $!"
 done
 /opt/rocm/bin/hipcc $FLAGS "$@" -c volren_amd/csrc/vr_kernels.hip -o $out/vr_kernels.o 2>/dev/null &
@@ -18,7 +18,7 @@ pids="$pids $!"
 /opt/rocm/bin/hipcc $FLAGS "$@" -x hip -c volren_amd/csrc/environment.cpp -o $out/environment.o 2>/dev/null &
 pids="$pids $!"
 for v in 0 1 2 3; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result -Iinclude -DVR_FAST_MATH=1 -DVR_PT_VARIANT=$v "$@" -c volren_amd/csrc/vr_pathtrace.hip -o $out/vr_pathtrace_fast_$v.o 2>/dev/null &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result -Iinclude -DVR_FAST_MATH=1 -fno-slp-vectorize -DVR_PT_VARIANT=$v "$@" -c volren_amd/csrc/vr_pathtrace.hip -o $out/vr_pathtrace_fast_$v.o 2>/dev/null &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done

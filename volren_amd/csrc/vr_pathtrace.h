@@ -58,6 +58,9 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #ifndef VR_MARCH_SPECULATIVE
 #define VR_MARCH_SPECULATIVE 1
 #endif
+#ifndef VR_MARCH_LOADS_PINNED
+#define VR_MARCH_LOADS_PINNED (VR_MARCH_STEPS == 2)
+#endif
 #ifndef VR_DIAG_PAD_VALU
 #define VR_DIAG_PAD_VALU 0
 #endif
@@ -124,6 +127,15 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
         p[11] = flags(h);
         p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z);
+    }
+    // a path that leaves the hot pair for an event: the march / collision code only changes seed, t, tau, Tr and the flag word
+    // (state, mip); ray, far and 1/dir are still in the slot from the store that preceded the path's resume
+    __device__ __forceinline__ void save_marched(const Hot& h, int32_t slot) const {
+        uint32_t* p = base + slot * HOT_STRIDE;
+        p[0] = h.seed;
+        p[7] = f2u(h.t); p[9] = f2u(h.tau);
+        if (!h.first) p[10] = f2u(h.Tr);
+        p[11] = flags(h);
     }
     // for an event batch: the slot as it is (a `first` path's ipos / Tr = its stash, which is what do_nee / do_escape want)
     __device__ __forceinline__ void load(Hot& h, int32_t slot) const {
@@ -206,6 +218,8 @@ constexpr int32_t kColdWaveFloats = kColdGroups * NSLOT * 4, kColdSlotStride = V
 constexpr int32_t kColdWaveFloats = C_STRIDE * NSLOT, kColdSlotStride = C_STRIDE;
 #endif
 
+// the lanes for which `cond` holds; the builtin takes the i1 as it is (HIP's __ballot goes through an int: v_cndmask + v_cmp per call)
+__device__ __forceinline__ uint64_t wave_ballot(bool cond) { return __builtin_amdgcn_ballot_w64(cond); }
 __device__ __forceinline__ int32_t popc(uint64_t mask) { return (int32_t)__popcll(mask); }     // int: min(long long, int) would go through double
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -302,21 +316,21 @@ pathtrace_kernel(const KernelArgs A) {
 #define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
 // push the slots of all lanes where COND holds onto stack QI (wave-synchronous)
 #define VR_PUSH(QI, CNT, COND, SLOTV) do { \
-        const uint64_t m_ = __ballot(COND); \
+        const uint64_t m_ = wave_ballot(COND); \
         if (m_) { if (COND) q[(QI) * NS + (CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(SLOTV); (CNT) += popc(m_); } \
     } while (0)
 
 // route the batch paths to the stack of their new state; an impossible state is reported and the slot recycled
 #define VR_ROUTE_ST(BS, STV) do { \
-        const bool v_ = (BS) >= 0; \
-        const int32_t s_ = (STV); \
-        VR_PUSH(Q_READY, cnt_ready, v_ && (s_ == ST_MARCH || s_ == ST_COLLIDE), BS); \
-        VR_PUSH(Q_NEE, cnt_nee, v_ && s_ == ST_NEE, BS); \
-        VR_PUSH(Q_POST, cnt_post, v_ && s_ == ST_POSTNEE, BS); \
-        VR_PUSH(Q_ESC, cnt_esc, v_ && s_ == ST_ESCAPE, BS); \
-        const bool lost_ = v_ && (s_ < ST_NEW || s_ > ST_ESCAPE || s_ == ST_BEGIN); \
-        if (__ballot(lost_)) { if (lost_) atomicOr(event_args().status, 2u); } \
-        VR_PUSH(Q_FREE, cnt_free, v_ && (s_ == ST_NEW || lost_), BS); \
+        /* one integer per lane (its new state, or -1 without a batch path): every ballot below is then a single v_cmp */ \
+        const int32_t s_ = (BS) >= 0 ? (STV) : -1; \
+        VR_PUSH(Q_READY, cnt_ready, (uint32_t)(s_ - ST_MARCH) < 2u, BS);          /* ST_MARCH, ST_COLLIDE */ \
+        VR_PUSH(Q_NEE, cnt_nee, s_ == ST_NEE, BS); \
+        VR_PUSH(Q_POST, cnt_post, s_ == ST_POSTNEE, BS); \
+        VR_PUSH(Q_ESC, cnt_esc, s_ == ST_ESCAPE, BS); \
+        const bool lost_ = s_ == ST_BEGIN || s_ > ST_ESCAPE || s_ < -1; \
+        if (wave_ballot(lost_)) { if (lost_) atomicOr(event_args().status, 2u); } \
+        VR_PUSH(Q_FREE, cnt_free, s_ == ST_NEW || lost_, BS); \
     } while (0)
 #define VR_ROUTE(BS) VR_ROUTE_ST(BS, l.state)
 #define VR_ROUTE_B(BS) VR_ROUTE_ST(BS, b.state)
@@ -341,7 +355,7 @@ pathtrace_kernel(const KernelArgs A) {
         }
         // (1) idle lanes resume READY paths
         {
-            const uint64_t idle = __ballot(slot < 0);
+            const uint64_t idle = wave_ballot(slot < 0);
             const int32_t take = min(popc(idle), cnt_ready);
             if (take > 0) {
                 if (slot < 0) {
@@ -351,7 +365,7 @@ pathtrace_kernel(const KernelArgs A) {
                 cnt_ready -= take;
             }
         }
-        if (STATS) { occ[0] += (unsigned)popc(__ballot(slot >= 0)); occ[1] += (unsigned)cnt_ready; occ[2] += (unsigned)cnt_nee; occ[3] += (unsigned)cnt_post; occ[4] += (unsigned)cnt_esc; occ[5] += (unsigned)cnt_free; }
+        if (STATS) { occ[0] += (unsigned)popc(wave_ballot(slot >= 0)); occ[1] += (unsigned)cnt_ready; occ[2] += (unsigned)cnt_nee; occ[3] += (unsigned)cnt_post; occ[4] += (unsigned)cnt_esc; occ[5] += (unsigned)cnt_free; }
         // (2) the hot pair: two DDA steps for the marching lanes, then the collision code for every lane that now stands at a
         // tentative collision (after two steps that is most of them, so both blocks run nearly full width).  Two memory round
         // trips per pass instead of four: both majorants are loaded together (the second step is prepared speculatively,
@@ -365,12 +379,18 @@ pathtrace_kernel(const KernelArgs A) {
             march_idle(mio);
             if (is_m) march_prep<K::dense>(l, P, mio);
             march_load<K::tf>(P, mio);
+#if VR_MARCH_LOADS_PINNED
+            // Both majorants must have been REQUESTED before the first is used.  Left alone, the compiler sinks each load into the
+            // conditional block of march_finish that consumes it (load, wait, test, load, wait: two dependent round trips); an
+            // empty asm that takes both values as operands keeps the two loads above it, back to back.
+            asm volatile("" : "+v"(mio.maj1), "+v"(mio.maj2));
+#endif
             if (is_m) march_finish<K::tf>(l, P, mio);
 #else
             for (int32_t k = 0; k < 2; ++k)            // diagnostic: two plain steps, one majorant load each, only where a step runs
                 if (slot >= 0 && l.state == ST_MARCH) do_march<K::tf, K::dense>(l, P);
 #endif
-            if (STATS) { const int32_t nm = popc(__ballot(is_m)); if (nm) { st_exec[ST_MARCH] += 1u; st_lanes[ST_MARCH] += (uint32_t)nm; } const unsigned long long t_now = __builtin_readcyclecounter(); st_cyc[ST_MARCH] += t_now - t_blk; t_blk = t_now; }
+            if (STATS) { const int32_t nm = popc(wave_ballot(is_m)); if (nm) { st_exec[ST_MARCH] += 1u; st_lanes[ST_MARCH] += (uint32_t)nm; } const unsigned long long t_now = __builtin_readcyclecounter(); st_cyc[ST_MARCH] += t_now - t_blk; t_blk = t_now; }
 #if VR_DIAG_PAD_VALU > 0
             {   // diagnostic: VR_DIAG_PAD_VALU extra dependent-free vector instructions per pass -> how issue-bound is the pass?
                 float pad_ = l.t;
@@ -395,23 +415,24 @@ pathtrace_kernel(const KernelArgs A) {
             // every load of the pass has been consumed or belongs to a lane that left early: say so, or the compiler carries
             // "possibly outstanding" around the loop and waits where nothing is pending
             __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0)
-            if (STATS) { const int32_t nc = popc(__ballot(is_c)); if (nc) { st_exec[ST_COLLIDE] += 1u; st_lanes[ST_COLLIDE] += (uint32_t)nc; } st_cyc[ST_COLLIDE] += __builtin_readcyclecounter() - t_blk; }
+            if (STATS) { const int32_t nc = popc(wave_ballot(is_c)); if (nc) { st_exec[ST_COLLIDE] += 1u; st_lanes[ST_COLLIDE] += (uint32_t)nc; } st_cyc[ST_COLLIDE] += __builtin_readcyclecounter() - t_blk; }
         }
         // (3) park paths that reached an event
         {
-            const bool parked = slot >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE;
-            if (__ballot(parked)) {
-                if (parked) hs.save(l, slot);
-                // the hot pair can only leave a path in NEE, POSTNEE or ESCAPE
-                VR_PUSH(Q_NEE, cnt_nee, parked && l.state == ST_NEE, slot);
-                VR_PUSH(Q_POST, cnt_post, parked && l.state == ST_POSTNEE, slot);
-                VR_PUSH(Q_ESC, cnt_esc, parked && l.state == ST_ESCAPE, slot);
-                if (parked) slot = -1;
+            // the state of a lane's path if it has to be parked (the hot pair can only leave a path in NEE, POSTNEE or ESCAPE), else -1:
+            // one integer, so that every ballot below is a single v_cmp
+            const int32_t ps = (slot >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE) ? l.state : -1;
+            if (wave_ballot(ps >= 0)) {
+                if (ps >= 0) hs.save_marched(l, slot);
+                VR_PUSH(Q_NEE, cnt_nee, ps == ST_NEE, slot);
+                VR_PUSH(Q_POST, cnt_post, ps == ST_POSTNEE, slot);
+                VR_PUSH(Q_ESC, cnt_esc, ps == ST_ESCAPE, slot);
+                if (ps >= 0) slot = -1;
             }
         }
         // (4) event batches
         int32_t n;
-        const int32_t n_live = popc(__ballot(slot >= 0)) + cnt_ready;
+        const int32_t n_live = popc(wave_ballot(slot >= 0)) + cnt_ready;
         const bool hungry = n_live < VR_THR_HUNGRY;                    // the hot pair is about to run under-filled
         // a batch runs when it is full enough; a hungry wave additionally runs its LARGEST batch (only that one, so that the
         // others keep filling up)
