@@ -102,7 +102,7 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
     SceneParams P{};
     P.u = u;
     HostGrid dg, eg;
-    build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true, density->dense != nullptr);
+    build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true, VR_MAJORANT_BLOCKED != 0 && density->dense != nullptr);
     P.density = dg.view;
     std::vector<uint16_t> blocked;                 // == dense_grid_to_device: 4x4x4 blocks
     if (density->dense) {
@@ -128,18 +128,17 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
     for (size_t i = 0; i < (size_t)env_w * env_h; ++i) for (int k = 0; k < 3; ++k) env[kEnvTexelFloats * i + k] = env_rgb[3 * i + k];
     P.envmap = env.data(); P.env_w = env_w; P.env_h = env_h;
     P.impmap = impmap; P.imp_dim = imp_dim;
-    std::vector<float> cdf(((size_t)imp_dim * imp_dim - 1) / 3 * kEnvCdfFloats);
+    int base = 0; while ((1 << base) < imp_dim) ++base;
+    std::vector<float> cdf(env_cdf_table_floats(base - 1), 0.0f);
     {   // == env_cdf_kernel of vr_kernels.hip
-        int base = 0; while ((1 << base) < imp_dim) ++base;
         for (int mip = base - 1; mip >= 0; --mip) {
             const int d = imp_dim >> mip, hd = d >> 1;
             const float* level = impmap + imp_level_offset(imp_dim, mip);
-            float* dst = cdf.data() + kEnvCdfFloats * (size_t)env_cdf_offset(base - 1 - mip);
             for (int y = 0; y < hd; ++y) for (int x = 0; x < hd; ++x) {
                 const float w0 = level[(size_t)(2 * y) * d + 2 * x], w1 = level[(size_t)(2 * y) * d + 2 * x + 1];
                 const float w2 = level[(size_t)(2 * y + 1) * d + 2 * x], w3 = level[(size_t)(2 * y + 1) * d + 2 * x + 1];
                 const float q0 = w0 + w2, q1 = w1 + w3;
-                float* o = dst + kEnvCdfFloats * ((size_t)y * hd + x);
+                float* o = cdf.data() + env_cdf_index(base - 1, base - 1 - mip, (uint32_t)x, (uint32_t)y);
                 o[0] = q0 / max_(1e-8f, q0 + q1); o[1] = w0 / q0; o[2] = w1 / q1;
             }
         }

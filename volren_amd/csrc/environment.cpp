@@ -47,7 +47,7 @@ void Environment::build(const float* rgb, int w, int h) {
     // build importance map: env_setup.glsl + glGenerateMipmap
     launch_build_impmap(envmap->as<float>(), w, h, (int)DIMENSION, impmap->as<float>(), nullptr);
     VR_HIP(hipGetLastError());
-    cdf = make_device_buffer(((size_t)DIMENSION * DIMENSION - 1) / 3 * kEnvCdfFloats * sizeof(float));
+    cdf = make_device_buffer(env_cdf_table_floats((int32_t)num_mip_levels() - 2) * sizeof(float));      // levels 0 .. base mip - 1
     launch_build_env_cdf(impmap->as<float>(), (int)DIMENSION, cdf->as<float>(), nullptr);
     VR_HIP(hipGetLastError());
     VR_HIP(hipStreamSynchronize(nullptr));

@@ -279,7 +279,7 @@ static GridView make_view(const BrickGridHIP& g) {
     for (int i = 0; i < 2; ++i) v.bshift[i] = g.bshift[i];
     for (int i = 0; i < 3; ++i) { v.mshift[i] = g.mshift[i]; v.mlim[i] = (float)(8u << g.mshift[i]); }
     v.n_mips = g.n_mips;
-    v.maj_blocked = getenv("VR_MAJORANT_BLOCKED") ? 1 : 0;     // 4x4x4-cell blocks (vr_scene.h): measured on c4 (64^3 cells), -2 %: off by default
+    v.maj_blocked = VR_MAJORANT_BLOCKED;        // build-time experiment (vr_scene.h), off
     return v;
 }
 

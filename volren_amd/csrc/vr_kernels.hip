@@ -209,9 +209,10 @@ impmap_mip_kernel(const float* __restrict__ src, int32_t d, float* __restrict__ 
     const float c = src[(size_t)(2 * y + 1) * d + 2 * x], e = src[(size_t)(2 * y + 1) * d + 2 * x + 1];
     dst[i] = ((a + b) + (c + e)) * 0.25f;
 }
-// warp table of sample_environment (see vr_trace.h): one thread per 2x2 block of pyramid level `mip`
+// warp table of sample_environment (see vr_trace.h; layout: vr_scene.h env_cdf_index): one thread per 2x2 block of pyramid
+// level `mip` = one record of table level k = top - mip
 __global__ void __launch_bounds__(256)
-env_cdf_kernel(const float* __restrict__ level, int32_t d, float* __restrict__ out) {
+env_cdf_kernel(const float* __restrict__ level, int32_t d, int32_t top, int32_t k, float* __restrict__ table) {
     const int32_t hd = d >> 1;
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= hd * hd) return;
@@ -219,18 +220,17 @@ env_cdf_kernel(const float* __restrict__ level, int32_t d, float* __restrict__ o
     const float w0 = level[(size_t)(2 * y) * d + 2 * x], w1 = level[(size_t)(2 * y) * d + 2 * x + 1];
     const float w2 = level[(size_t)(2 * y + 1) * d + 2 * x], w3 = level[(size_t)(2 * y + 1) * d + 2 * x + 1];
     const float q0 = w0 + w2, q1 = w1 + w3;
-    float* o = out + (size_t)kEnvCdfFloats * i;
+    float* o = table + env_cdf_index(top, k, (uint32_t)x, (uint32_t)y);
     o[0] = q0 / max_(1e-8f, q0 + q1); o[1] = w0 / q0; o[2] = w1 / q1;
-    if (kEnvCdfFloats > 3) o[3] = 0.0f;
 }
 void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipStream_t stream) {
     // levels base-1 .. 0; level m lives at pyramid offset imp_level_offset(dim, m) and has (dim >> m)^2 texels
     int32_t base = 0;
     while ((1 << base) < dim) ++base;
+    (void)hipMemsetAsync(table, 0, env_cdf_table_floats(base - 1) * sizeof(float), stream);      // padding words and unused child records
     for (int32_t mip = base - 1; mip >= 0; --mip) {
         const int32_t d = dim >> mip, n = (d >> 1) * (d >> 1);
-        float* dst = table + kEnvCdfFloats * (size_t)env_cdf_offset(base - 1 - mip);
-        hipLaunchKernelGGL(env_cdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pyramid + imp_level_offset(dim, mip), d, dst);
+        hipLaunchKernelGGL(env_cdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pyramid + imp_level_offset(dim, mip), d, base - 1, base - 1 - mip, table);
     }
 }
 

@@ -35,6 +35,11 @@ VR_SCENE_HD size_t majorant_padded_cells(uint32_t k) { return (size_t)majorant_l
 // used for the large tables of dense grids): levels 0 and 1 -- at least 4 cells per axis -- are stored as 4x4x4-cell blocks of 64
 // consecutive cells (128 bytes of fp16 = one cache line), so that a DDA step to ANY neighbouring cell usually stays in the line;
 // levels 2 and 3 (a few hundred cells) stay linear.  sx, sy: log2 of the level's padded extent in x and y.
+// Measured on c4 (64^3 cells): -2 % (profiles/r2j_layout_experiments.txt), so the blocked layout is a build-time experiment
+// (-DVR_MAJORANT_BLOCKED=1), not a run-time switch: a run-time flag costs every DDA step a divergent branch.
+#ifndef VR_MAJORANT_BLOCKED
+#define VR_MAJORANT_BLOCKED 0
+#endif
 VR_SCENE_HD uint32_t majorant_cell_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t sx, uint32_t sy, uint32_t mip, bool blocked) {
     if (blocked && mip <= 1u)
         return (((((cz >> 2) << (sy - 2u)) + (cy >> 2)) << (sx - 2u)) + (cx >> 2)) * 64u + (((cz & 3u) << 4) | ((cy & 3u) << 2) | (cx & 3u));
@@ -51,11 +56,30 @@ VR_SCENE_HD size_t dense_blocked_index(uint32_t x, uint32_t y, uint32_t z, uint3
 #ifndef VR_ENV_TEXEL_FLOATS
 #define VR_ENV_TEXEL_FLOATS 3
 #endif
-#ifndef VR_ENV_CDF_FLOATS
-#define VR_ENV_CDF_FLOATS 3
-#endif
 constexpr int32_t kEnvTexelFloats = VR_ENV_TEXEL_FLOATS;      // envmap texel: RGB (3) or RGBA (4) floats
-constexpr int32_t kEnvCdfFloats = VR_ENV_CDF_FLOATS;          // warp table record: (d, e0, e1) [+ pad]
+// Warp table of sample_environment: one record (d, e0, e1) per 2x2 block of every importance-pyramid level (level k = 0 .. top has
+// 2^k x 2^k records; top = base mip - 1).  The descent reads one record per level, each chosen by the previous one: nine
+// dependent gathers for the 512^2 map.  Records of TWO consecutive levels share a 64-byte block -- the parent's record followed by
+// those of its four children ([parent | c00 | c10 | c01 | c11 | pad], child index 2 * (y & 1) + (x & 1)) -- so the second gather of
+// a pair hits the line the first one brought in: for the two finest levels (1 MiB of records) that is one miss instead of two.
+// Levels are paired from the finest up, (top-1, top), (top-3, top-2), ...; with an odd number of levels, level 0 (one record)
+// sits alone in block 0.  Pair p (upper level ku = 2p + s, s = 1 if level 0 is alone) starts at block s + 4^s (16^p - 1) / 15 and
+// holds one block per cell of its upper level, x fastest.
+constexpr int32_t kEnvCdfBlockFloats = 16;
+VR_SCENE_HD size_t env_cdf_pair_base(int32_t s, int32_t p) { return (size_t)s + (((size_t)1 << (2 * s)) * ((((size_t)1) << (4 * p)) - 1)) / 15; }
+VR_SCENE_HD size_t env_cdf_index(int32_t top, int32_t k, uint32_t x, uint32_t y) {      // float index of the record of cell (x, y) of level k
+    const int32_t s = (top & 1) ? 0 : 1;
+    if (k < s) return 0;
+    const int32_t kk = k - s, p = kk >> 1, ku = 2 * p + s;
+    const size_t blk = env_cdf_pair_base(s, p);
+    if (kk & 1) return (size_t)kEnvCdfBlockFloats * (blk + ((size_t)(y >> 1) << ku) + (x >> 1)) + 3u + 3u * (2u * (y & 1u) + (x & 1u));
+    return (size_t)kEnvCdfBlockFloats * (blk + ((size_t)y << ku) + x);
+}
+VR_SCENE_HD size_t env_cdf_table_floats(int32_t top) {
+    if (top < 0) return kEnvCdfBlockFloats;
+    const int32_t s = (top & 1) ? 0 : 1;
+    return (size_t)kEnvCdfBlockFloats * env_cdf_pair_base(s, (top + 1 - s) / 2);
+}
 
 struct GridView {
     const BrickRec* bricks;      // nb[2] << (bshift[0] + bshift[1]) records, power-of-two pitches (see above)
@@ -103,7 +127,7 @@ struct SceneParams {
     int32_t env_w, env_h;
     const float* impmap;               // importance pyramid, level 0 (dim^2) first, 2x2 box mips after it
     int32_t imp_dim;
-    const float* env_cdf;              // warp table: kEnvCdfFloats floats (d, e0, e1) per 2x2 block of every pyramid level, coarsest first
+    const float* env_cdf;              // warp table: (d, e0, e1) per 2x2 block of every pyramid level, two levels per 64-byte block (env_cdf_index)
     float cam_z;                       // -.5f / tan(.5f * M_PI * cam_fov / 180.f), common.glsl:78 (uniform per frame)
 };
 

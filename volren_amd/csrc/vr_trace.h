@@ -176,7 +176,7 @@ VR_HD int32_t majorant_index(const GridView& g, v3 ipos, int32_t mip) {
     const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
     const uint32_t sx = (uint32_t)g.mshift[0] - (uint32_t)mip, sy = (uint32_t)g.mshift[1] - (uint32_t)mip;
     const uint32_t off = majorant_level_offset((uint32_t)(g.mshift[0] + g.mshift[1] + g.mshift[2]), (uint32_t)mip);
-    const bool blocked = g.maj_blocked != 0;          // run-time: the table is laid out by majorant_kernel from the same flag
+    const bool blocked = VR_MAJORANT_BLOCKED != 0;    // compile-time (vr_scene.h): majorant_kernel lays the table out from GridView::maj_blocked = the same constant
     return inside ? (int32_t)(off + majorant_cell_index(bx, by, bz, sx, sy, (uint32_t)mip, blocked)) : -1;
 }
 // Unconditional load (cell 0 when outside; the caller discards it then).  TF kernels read the float table (TF-remapped
@@ -444,26 +444,34 @@ VR_HD v3 lookup_environment(const SceneParams& P, v3 dir) {
 }
 // The 2x2 warp of level `mip` only needs three numbers per parent cell: d = q0 / max(1e-8, q0 + q1), e0 = w0 / q0,
 // e1 = w1 / q1 (common.glsl:116,126).  They depend on the importance pyramid alone, so they are tabulated once per
-// environment (cdf_kernel, same operations) as one 16-byte record per cell: 1 load and 2 divisions per level instead
-// of 4 loads and 4 divisions.  Cells of level base-1 (1 cell) come first, level 0 ((dim/2)^2 cells) last.
-VR_HD int32_t env_cdf_offset(int32_t levels_above) { return ((1 << (2 * levels_above)) - 1) / 3; }   // sum_{i<k} 4^i
+// environment (env_cdf_kernel, same operations) as one 12-byte record per cell: 1 load and 2 divisions per level instead
+// of 4 loads and 4 divisions.  Two consecutive levels share a 64-byte block (vr_scene.h, env_cdf_index): the record of the child
+// cell is in the line its parent's record came from.
+// one level of the descent (common.glsl:118-131: "if (r < p) r /= p; else { pos += 1; r = (r - p) / (1 - p); }" per axis, written
+// as operand selects + ONE division so that a wavefront whose lanes go both ways does not execute two); returns the child 0..3
+VR_HD int32_t env_warp_level(const float* rec, float& px, float& py, int32_t& posx, int32_t& posy) {
+    const float d = rec[0], e0 = rec[1], e1 = rec[2];
+    const bool right = !(px < d);
+    const float e = right ? e1 : e0;
+    px = (right ? px - d : px) / (right ? 1.0f - d : d);
+    const bool up = !(py < e);
+    py = (up ? py - e : py) / (up ? 1.0f - e : e);
+    posx = 2 * posx + (right ? 1 : 0);
+    posy = 2 * posy + (up ? 1 : 0);
+    return (up ? 2 : 0) + (right ? 1 : 0);
+}
 VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i, v3& Le, float& pdf_out) {
     int32_t posx = 0, posy = 0;
     float px = r0, py = r1;
-    const int32_t top = P.u.env_imp_base_mip - 1;
-    for (int32_t mip = top; mip >= 0; mip--) {
-        const int32_t k = top - mip;                           // cells per axis at this level = 2^k
-        const float* rec = P.env_cdf + kEnvCdfFloats * (env_cdf_offset(k) + (posy << k) + posx);
-        const float d = rec[0], e0 = rec[1], e1 = rec[2];
-        // common.glsl:118-131: "if (r < p) r /= p; else { pos += 1; r = (r - p) / (1 - p); }" per axis, written as operand
-        // selects + ONE division so that a wavefront whose lanes go both ways does not execute two
-        const bool right = !(px < d);
-        const float e = right ? e1 : e0;
-        px = (right ? px - d : px) / (right ? 1.0f - d : d);
-        const bool up = !(py < e);
-        py = (up ? py - e : py) / (up ? 1.0f - e : e);
-        posx = 2 * posx + (right ? 1 : 0);
-        posy = 2 * posy + (up ? 1 : 0);
+    const int32_t top = P.u.env_imp_base_mip - 1;              // levels 0 (one cell) .. top
+    const float* blk = P.env_cdf;
+    int32_t k = 0;
+    if ((top & 1) == 0) { env_warp_level(blk, px, py, posx, posy); blk += kEnvCdfBlockFloats; k = 1; }      // odd number of levels: level 0 alone
+    for (; k <= top; k += 2) {                                  // levels k and k + 1: parent record, then the chosen child's in the same block
+        const float* b = blk + kEnvCdfBlockFloats * (size_t)((posy << k) + posx);
+        const int32_t c = env_warp_level(b, px, py, posx, posy);
+        env_warp_level(b + 3 + 3 * c, px, py, posx, posy);
+        blk += (size_t)kEnvCdfBlockFloats << (2 * k);
     }
     const float u = ((float)posx + px) * P.u.env_imp_inv_dim[0];
     const float v = ((float)posy + py) * P.u.env_imp_inv_dim[1];
