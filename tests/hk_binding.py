@@ -11,8 +11,11 @@ _SO = os.path.join(_DIR, "libhostkernel.so")
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build(sanitize=False):
+def build(sanitize=False, fast_tap=False):
+    """fast_tap: the device's decision of the stochastic-filter tests (VR_TAP_FAST, vr_trace.h) instead of the reference's loop."""
     so = _SO if not sanitize else os.path.join(_DIR, "libhostkernel_san.so")
+    if fast_tap:
+        so = os.path.join(_DIR, "libhostkernel_fasttap.so")
     src = os.path.join(_DIR, "host_kernel.cpp")
     deps = [src] + [os.path.join(_ROOT, "volren_amd", "csrc", f) for f in ("vr_trace.h", "vr_math.h", "vr_scene.h")]
     if os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps):
@@ -21,8 +24,21 @@ def build(sanitize=False):
            "-Wno-unknown-pragmas", "-o", so, src]
     if sanitize:
         cmd[1:1] = ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-g"]
+    if fast_tap:
+        cmd[1:1] = ["-DVR_TAP_FAST=1"]
     subprocess.check_call(cmd)
     return so
+
+
+def build_tricubic_band_tool():
+    """tests/tools_tricubic_band.cpp: exhaustive / strided check of the fast filter tests against the reference's."""
+    exe = os.path.join(_DIR, "tricubic_band")
+    src = os.path.join(os.path.dirname(_DIR), "tools_tricubic_band.cpp")
+    deps = [src] + [os.path.join(_ROOT, "volren_amd", "csrc", f) for f in ("vr_trace.h", "vr_math.h", "vr_scene.h")]
+    if not (os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-mavx2", "-fopenmp",
+                               "-Wno-unknown-pragmas", "-o", exe, src])
+    return exe
 
 
 class GridDesc(C.Structure):
@@ -47,22 +63,22 @@ def grid_desc(g):
     return d
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(build())
-        _lib.hk_render.restype = C.c_longlong
-        _lib.hk_math.restype = C.c_float
-        _lib.hk_math.argtypes = [C.c_int, C.c_float, C.c_float]
-    return _lib
+def lib(fast_tap=False):
+    if fast_tap not in _libs:
+        L = C.CDLL(build(fast_tap=fast_tap))
+        L.hk_render.restype = C.c_longlong
+        L.hk_math.restype = C.c_float
+        L.hk_math.argtypes = [C.c_int, C.c_float, C.c_float]
+        _libs[fast_tap] = L
+    return _libs[fast_tap]
 
 
-def render(orc_renderer, spp, rect=None, fb=None, first_sample=1):
+def render(orc_renderer, spp, rect=None, fb=None, first_sample=1, fast_tap=False):
     """Run the host-compiled product kernel on the scene held by an oracle.binding.OracleRenderer."""
-    L = lib()
+    L = lib(fast_tap)
     p = orc_renderer.params()
     assert C.sizeof(p) == L.hk_uniforms_size(), (C.sizeof(p), L.hk_uniforms_size())
     dd = grid_desc(orc_renderer.density)

@@ -23,6 +23,28 @@ def test_state_machine_matches_oracle(name, w, h, spp):
     assert _same(got, want), "relative L2 %.3e" % scenes.rel_l2(got[..., :3], want[..., :3])
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("c1", 64, 64, 16), ("c2", 48, 48, 16)])
+def test_state_machine_with_the_device_filter_tests(name, w, h, spp):
+    """The same with the DEVICE's decision of the nine stochastic-filter tests (VR_TAP_FAST: Horner weights, cross-multiplied,
+    guard band, exact fallback) switched on in the host build -- the GPU kernels' collision code, run on the CPU."""
+    r = scenes.oracle_scene(name, w, h)
+    want = r.render(spp).copy()
+    got, steps = hk.render(r, spp, fast_tap=True)
+    assert steps > 0
+    assert _same(got, want), "relative L2 %.3e" % scenes.rel_l2(got[..., :3], want[..., :3])
+
+
+def test_tricubic_fast_path_agrees_with_the_reference():
+    """tests/tools_tricubic_band.cpp: for every 61st float t in [0, 1] (17 million; `tricubic_band 1` runs all 1.07e9, recorded in
+    profiles/r2q_tricubic_band_exhaustive.txt) and all 2^24 values of a draw, a filter test decided by the fast path is decided the same
+    way by the reference's r < w / s; non-finite coordinates end in the guard band."""
+    import subprocess
+    exe = hk.build_tricubic_band_tool()
+    out = subprocess.run([exe, "61"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "violations 0" in out.stdout
+
+
 @pytest.mark.parametrize("name", ["c1", "c3"])
 def test_global_majorant_tracking_variant(name):
     """common.glsl:333-394 (delta / ratio tracking against the global majorant; the reference compiles it out with USE_DDA):
@@ -183,7 +205,7 @@ def test_harness_under_ubsan():
     code = (
         "import sys; sys.path[:0]=[%r,%r]\n"
         "import ctypes as C, numpy as np, scenes, hk_binding as hk\n"
-        "hk._lib = C.CDLL(%r); hk._lib.hk_render.restype = C.c_longlong\n"
+        "L = C.CDLL(%r); L.hk_render.restype = C.c_longlong; hk._libs[False] = L\n"
         "r = scenes.oracle_scene('c3', 24, 24); want = r.render(4).copy(); got,_ = hk.render(r, 4)\n"
         "assert np.array_equal(got.view(np.uint32), want.view(np.uint32)); print('ok')\n"
     ) % (scenes.ROOT, scenes.ROOT + "/tests", so)

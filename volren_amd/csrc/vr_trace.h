@@ -308,6 +308,15 @@ VR_HD AxisWeights tricubic_axis_weights(float q) {
     a.fl = fl;
     return a;
 }
+// ---- fast decision of the nine filter tests (device; the host harness can switch it on to run the same code) ----------------
+// Test j of an axis asks "r_j < w / s" with r_j = k_j * 2^-24 (k_j: the low 24 bits of the LCG state after j draws), w one of the
+// weights above and s its partial sum.  The fast path evaluates the same polynomials the cheap way (6 w_i in Horner form, fused:
+// 12 operations per axis instead of 28; s4 = 6 exactly), cross-multiplies instead of dividing, and decides only when k_j * s'
+// lies outside a guard band of +-2^-18 (relative) around w' * 2^24.  The two evaluations' thresholds differ by at most 2^-21.3
+// (relative) anywhere in [0, 1], so a draw outside the band is decided as the reference decides it: tests/tools_tricubic_band.cpp
+// checks exactly that -- for EVERY float t in [0, 1] and all 2^24 values of a draw -- with this very code compiled for the host
+// (3.2e9 (t, test) pairs, no exception; test_tricubic_fast_path_agrees_with_the_reference runs a strided pass).
+// A draw inside a band (9 x ~4e-6 per call) sends the call to the exact code: the reference's weights and divisions.
 // LCG jump-ahead: state_j = A_j * state_0 + C_j (mod 2^32) after j draws
 struct LcgJump { uint32_t A, C; };
 constexpr LcgJump lcg_jump(int j) {
@@ -315,14 +324,44 @@ constexpr LcgJump lcg_jump(int j) {
     for (int i = 0; i < j; ++i) { A = A * 1664525u; C = C * 1664525u + 1013904223u; }
     return LcgJump{ A, C };
 }
+struct AxisFast { float w2, s2, w3, s3, w4, fl; };      // 6 x the weights; s4 = 6
+VR_HD AxisFast tricubic_axis_fast(float q) {
+    AxisFast a;
+    a.fl = floor_(q);
+    const float t = q - a.fl, t2 = t * t, u = 1.0f - t;
+    a.w4 = t2 * t;                                                    // t^3
+    a.w2 = fma_(fma_(3.0f, t, -6.0f), t2, 4.0f);                      // 3t^3 - 6t^2 + 4
+    a.w3 = fma_(fma_(fma_(-3.0f, t, 3.0f), t, 3.0f), t, 1.0f);        // -3t^3 + 3t^2 + 3t + 1
+    a.s2 = (u * u) * u + a.w2;                                        // (1 - t)^3 + 6 w2
+    a.s3 = a.s2 + a.w3;
+    return a;
+}
+constexpr float kTapLo = 16777152.0f;       // 2^24 (1 - 2^-18)
+constexpr float kTapHi = 16777280.0f;       // 2^24 (1 + 2^-18)
+// one test: yes / no as the reference decides, or neither (inside the band).  k: the draw's 24 bits as a float
+VR_HD void tricubic_fast_test(float k, float w, float s, bool& yes, bool& no) {
+    const float x = k * s;
+    // the absolute term keeps k = 0 out of "yes" where the reference's weight has underflowed to 0 (t < 1e-9) and the fast one has not
+    yes = x < fma_(w, kTapLo, -1e-20f);
+    no = x > fma_(w, kTapHi, 1e-20f);
+}
+#ifndef VR_TAP_FAST
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VR_TAP_FAST 1
+#else
+#define VR_TAP_FAST 0
+#endif
+#endif
+
 VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) {
-    const AxisWeights ax = tricubic_axis_weights(ipos.x - 0.5f);
-    const AxisWeights ay = tricubic_axis_weights(ipos.y - 0.5f);
-    const AxisWeights az = tricubic_axis_weights(ipos.z - 0.5f);
     int32_t jx = 0, jy = 0, jz = 0;
 #if VR_FAST_DEVICE
     // tolerance mode: draw j is k_j * 2^-24 and "r_j < w / s" is taken as k_j * s < w * 2^24, unguarded (one rounding apart
     // from the reference's quotient; a decision flips only when the draw lands within that rounding of the threshold)
+    const AxisWeights ax = tricubic_axis_weights(ipos.x - 0.5f);
+    const AxisWeights ay = tricubic_axis_weights(ipos.y - 0.5f);
+    const AxisWeights az = tricubic_axis_weights(ipos.z - 0.5f);
+    const float flx = ax.fl, fly = ay.fl, flz = az.fl;
     {
         const uint32_t lo24 = seed & 0x00FFFFFFu;
 #define VR_TAPF(J, V, W, S, N) do { \
@@ -336,34 +375,36 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
 #undef VR_TAPF
         rng_skip9(seed);
     }
-#elif defined(__HIP_DEVICE_COMPILE__)
-    // Device fast path, no division and no 32-bit multiply per test.
-    //  * draw j is r_j = k_j * 2^-24 with k_j = state_j & 0xFFFFFF, and the low 24 bits of state_j = A_j * seed + C_j only
-    //    need the low 24 bits of seed and A_j: one 24-bit multiply-add (full rate) instead of a chained 32-bit multiply;
-    //  * the reference's test r_j < w / s is decided as k_j * s < w * 2^24 (s > 0) whenever the two sides differ by more
-    //    than a guard band of 8 ulp (+1e-30 absolute, for vanishing weights) -- far more than the two roundings involved;
-    //  * a test inside its band (~1e-5 per call) sends all 9 to ONE exact fallback below.
+#else
+#if VR_TAP_FAST
+    // a draw only uses the low 24 bits of the state, and those of state_j = A_j * seed + C_j only need the low 24 bits of seed and
+    // A_j: one 24-bit multiply-add per draw instead of a chained 32-bit multiply
+    const AxisFast fx = tricubic_axis_fast(ipos.x - 0.5f), fy = tricubic_axis_fast(ipos.y - 0.5f), fz = tricubic_axis_fast(ipos.z - 0.5f);
+    const float flx = fx.fl, fly = fy.fl, flz = fz.fl;
     const uint32_t seed0 = seed, lo24 = seed & 0x00FFFFFFu;
     bool unsure = false;
 #define VR_TAP(J, V, W, S, N) do { \
         constexpr LcgJump g_ = lcg_jump(N); \
-        const float k_ = (float)((mul24(lo24, g_.A & 0x00FFFFFFu) + g_.C) & 0x00FFFFFFu); \
-        const float x_ = k_ * (S); \
-        const float w_ = (W) * 16777216.0f; \
-        const float m_ = __builtin_fmaf(abs_(w_), 9.5367431640625e-07f, 1e-30f); \
-        const bool yes_ = x_ < w_ - m_, no_ = x_ > w_ + m_; \
+        bool yes_, no_; \
+        tricubic_fast_test((float)((mul24(lo24, g_.A & 0x00FFFFFFu) + g_.C) & 0x00FFFFFFu), W, S, yes_, no_); \
         J = yes_ ? V : J; \
         unsure = unsure | !(yes_ | no_); \
     } while (0)
-    VR_TAP(jx, 1, ax.w2, ax.s2, 1); VR_TAP(jy, 1, ay.w2, ay.s2, 2); VR_TAP(jz, 1, az.w2, az.s2, 3);
-    VR_TAP(jx, 2, ax.w3, ax.s3, 4); VR_TAP(jy, 2, ay.w3, ay.s3, 5); VR_TAP(jz, 2, az.w3, az.s3, 6);
-    VR_TAP(jx, 3, ax.w4, ax.s4, 7); VR_TAP(jy, 3, ay.w4, ay.s4, 8); VR_TAP(jz, 3, az.w4, az.s4, 9);
+    VR_TAP(jx, 1, fx.w2, fx.s2, 1); VR_TAP(jy, 1, fy.w2, fy.s2, 2); VR_TAP(jz, 1, fz.w2, fz.s2, 3);
+    VR_TAP(jx, 2, fx.w3, fx.s3, 4); VR_TAP(jy, 2, fy.w3, fy.s3, 5); VR_TAP(jz, 2, fz.w3, fz.s3, 6);
+    VR_TAP(jx, 3, fx.w4, 6.0f, 7); VR_TAP(jy, 3, fy.w4, 6.0f, 8); VR_TAP(jz, 3, fz.w4, 6.0f, 9);
 #undef VR_TAP
     rng_skip9(seed);
     if (unsure) {
         seed = seed0; jx = jy = jz = 0;
+#else
+    const float flx = floor_(ipos.x - 0.5f), fly = floor_(ipos.y - 0.5f), flz = floor_(ipos.z - 0.5f);
+    {
 #endif
-#if !VR_FAST_DEVICE
+        // the reference's code (common.glsl:221-244)
+        const AxisWeights ax = tricubic_axis_weights(ipos.x - 0.5f);
+        const AxisWeights ay = tricubic_axis_weights(ipos.y - 0.5f);
+        const AxisWeights az = tricubic_axis_weights(ipos.z - 0.5f);
         float r;
         r = rng(seed); if (r < ax.w2 / ax.s2) jx = 1;
         r = rng(seed); if (r < ay.w2 / ay.s2) jy = 1;
@@ -374,11 +415,9 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
         r = rng(seed); if (r < ax.w4 / ax.s4) jx = 3;
         r = rng(seed); if (r < ay.w4 / ay.s4) jy = 3;
         r = rng(seed); if (r < az.w4 / az.s4) jz = 3;
-#if defined(__HIP_DEVICE_COMPILE__)
     }
 #endif
-#endif
-    tx = nan_guard(voxel_index(ax.fl, jx - 1), ax.fl, ay.fl, az.fl); ty = voxel_index(ay.fl, jy - 1); tz = voxel_index(az.fl, jz - 1);
+    tx = nan_guard(voxel_index(flx, jx - 1), flx, fly, flz); ty = voxel_index(fly, jy - 1); tz = voxel_index(flz, jz - 1);
 }
 
 // transfer function (common.glsl:203-212)
