@@ -140,6 +140,7 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
                 const float q0 = w0 + w2, q1 = w1 + w3;
                 float* o = cdf.data() + env_cdf_index(base - 1, base - 1 - mip, (uint32_t)x, (uint32_t)y);
                 o[0] = q0 / max_(1e-8f, q0 + q1); o[1] = w0 / q0; o[2] = w1 / q1;
+                if (mip == 0) { o[3] = w0; o[4] = w1; o[5] = w2; o[6] = w3; }
             }
         }
     }

@@ -222,6 +222,7 @@ env_cdf_kernel(const float* __restrict__ level, int32_t d, int32_t top, int32_t 
     const float q0 = w0 + w2, q1 = w1 + w3;
     float* o = table + env_cdf_index(top, k, (uint32_t)x, (uint32_t)y);
     o[0] = q0 / max_(1e-8f, q0 + q1); o[1] = w0 / q0; o[2] = w1 / q1;
+    if (k == top) { o[3] = w0; o[4] = w1; o[5] = w2; o[6] = w3; }      // finest level: the texels themselves (pdf of the sampled direction)
 }
 void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipStream_t stream) {
     // levels base-1 .. 0; level m lives at pyramid offset imp_level_offset(dim, m) and has (dim >> m)^2 texels

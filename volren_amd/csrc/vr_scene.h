@@ -59,26 +59,39 @@ VR_SCENE_HD size_t dense_blocked_index(uint32_t x, uint32_t y, uint32_t z, uint3
 constexpr int32_t kEnvTexelFloats = VR_ENV_TEXEL_FLOATS;      // envmap texel: RGB (3) or RGBA (4) floats
 // Warp table of sample_environment: one record (d, e0, e1) per 2x2 block of every importance-pyramid level (level k = 0 .. top has
 // 2^k x 2^k records; top = base mip - 1).  The descent reads one record per level, each chosen by the previous one: nine
-// dependent gathers for the 512^2 map.  Records of TWO consecutive levels share a 64-byte block -- the parent's record followed by
-// those of its four children ([parent | c00 | c10 | c01 | c11 | pad], child index 2 * (y & 1) + (x & 1)) -- so the second gather of
-// a pair hits the line the first one brought in: for the two finest levels (1 MiB of records) that is one miss instead of two.
-// Levels are paired from the finest up, (top-1, top), (top-3, top-2), ...; with an odd number of levels, level 0 (one record)
-// sits alone in block 0.  Pair p (upper level ku = 2p + s, s = 1 if level 0 is alone) starts at block s + 4^s (16^p - 1) / 15 and
-// holds one block per cell of its upper level, x fastest.
-constexpr int32_t kEnvCdfBlockFloats = 16;
+// dependent gathers for the 512^2 map.  Records of TWO consecutive levels share a block -- the parent's record followed by those
+// of its four children (child index 2 * (y & 1) + (x & 1)) -- so the second gather of a pair hits the line the first one brought
+// in.  Levels are paired from the finest up, (top-1, top), (top-3, top-2), ...; with an odd number of levels, level 0 (one
+// record) sits alone in block 0.  Pair p (upper level ku = 2p + s, s = 1 if level 0 is alone) starts at block
+// s + 4^s (16^p - 1) / 15 and holds one block per cell of its upper level, x fastest.  Blocks are 64 bytes,
+// [parent | c0 | c1 | c2 | c3 | pad]; the LAST pair's are 128 bytes, one cache line, [parent | pad | c0 .. c3] with 28-byte child
+// records (d, e0, e1, w0, w1, w2, w3): the finest level also carries the four importance texels its cell splits into, which is the
+// value the pdf needs (imp_fetch(pos, 0)) -- one gather into a 1 MiB map less per next-event estimate.
+constexpr int32_t kEnvCdfBlockFloats = 16, kEnvCdfLastBlockFloats = 32, kEnvCdfLastChildFloats = 7, kEnvCdfLastChild0 = 4;
 VR_SCENE_HD size_t env_cdf_pair_base(int32_t s, int32_t p) { return (size_t)s + (((size_t)1 << (2 * s)) * ((((size_t)1) << (4 * p)) - 1)) / 15; }
+// float offset of the last pair's first block: after the 64-byte blocks, on a 128-byte boundary
+VR_SCENE_HD size_t env_cdf_last_pair_floats(int32_t s, int32_t n_pairs) {
+    const size_t f = (size_t)kEnvCdfBlockFloats * env_cdf_pair_base(s, n_pairs - 1);
+    return (f + (size_t)kEnvCdfLastBlockFloats - 1u) / (size_t)kEnvCdfLastBlockFloats * (size_t)kEnvCdfLastBlockFloats;
+}
 VR_SCENE_HD size_t env_cdf_index(int32_t top, int32_t k, uint32_t x, uint32_t y) {      // float index of the record of cell (x, y) of level k
     const int32_t s = (top & 1) ? 0 : 1;
     if (k < s) return 0;
-    const int32_t kk = k - s, p = kk >> 1, ku = 2 * p + s;
+    const int32_t kk = k - s, p = kk >> 1, ku = 2 * p + s, n_pairs = (top + 1 - s) / 2;
+    const uint32_t c = 2u * (y & 1u) + (x & 1u);
+    if (p == n_pairs - 1) {
+        const size_t base = env_cdf_last_pair_floats(s, n_pairs);
+        if (kk & 1) return base + (size_t)kEnvCdfLastBlockFloats * (((size_t)(y >> 1) << ku) + (x >> 1)) + (size_t)kEnvCdfLastChild0 + (size_t)kEnvCdfLastChildFloats * c;
+        return base + (size_t)kEnvCdfLastBlockFloats * (((size_t)y << ku) + x);
+    }
     const size_t blk = env_cdf_pair_base(s, p);
-    if (kk & 1) return (size_t)kEnvCdfBlockFloats * (blk + ((size_t)(y >> 1) << ku) + (x >> 1)) + 3u + 3u * (2u * (y & 1u) + (x & 1u));
+    if (kk & 1) return (size_t)kEnvCdfBlockFloats * (blk + ((size_t)(y >> 1) << ku) + (x >> 1)) + 3u + 3u * c;
     return (size_t)kEnvCdfBlockFloats * (blk + ((size_t)y << ku) + x);
 }
 VR_SCENE_HD size_t env_cdf_table_floats(int32_t top) {
-    if (top < 0) return kEnvCdfBlockFloats;
-    const int32_t s = (top & 1) ? 0 : 1;
-    return (size_t)kEnvCdfBlockFloats * env_cdf_pair_base(s, (top + 1 - s) / 2);
+    if (top < 1) return kEnvCdfBlockFloats;                      // no level, or level 0 alone (its record carries the texels: 7 floats)
+    const int32_t s = (top & 1) ? 0 : 1, n_pairs = (top + 1 - s) / 2, ku = 2 * (n_pairs - 1) + s;
+    return env_cdf_last_pair_floats(s, n_pairs) + ((size_t)kEnvCdfLastBlockFloats << (2 * ku));
 }
 
 struct GridView {
@@ -127,7 +140,7 @@ struct SceneParams {
     int32_t env_w, env_h;
     const float* impmap;               // importance pyramid, level 0 (dim^2) first, 2x2 box mips after it
     int32_t imp_dim;
-    const float* env_cdf;              // warp table: (d, e0, e1) per 2x2 block of every pyramid level, two levels per 64-byte block (env_cdf_index)
+    const float* env_cdf;              // warp table: (d, e0, e1) per 2x2 block of every pyramid level, two levels per block; the finest with its texels (env_cdf_index)
     float cam_z;                       // -.5f / tan(.5f * M_PI * cam_fov / 180.f), common.glsl:78 (uniform per frame)
 };
 

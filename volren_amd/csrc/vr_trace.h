@@ -504,13 +504,26 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
     float px = r0, py = r1;
     const int32_t top = P.u.env_imp_base_mip - 1;              // levels 0 (one cell) .. top
     const float* blk = P.env_cdf;
+    float w_texel = 0.0f;                                       // importance of the texel the descent ends in == imp_fetch(P, posx, posy, 0)
     int32_t k = 0;
-    if ((top & 1) == 0) { env_warp_level(blk, px, py, posx, posy); blk += kEnvCdfBlockFloats; k = 1; }      // odd number of levels: level 0 alone
-    for (; k <= top; k += 2) {                                  // levels k and k + 1: parent record, then the chosen child's in the same block
+    if ((top & 1) == 0) {                                       // odd number of levels: level 0 alone
+        const int32_t c = env_warp_level(blk, px, py, posx, posy);
+        if (top == 0) w_texel = blk[3 + c];
+        blk += kEnvCdfBlockFloats; k = 1;
+    }
+    for (; k + 1 < top; k += 2) {                               // levels k and k + 1: parent record, then the chosen child's in the same block
         const float* b = blk + kEnvCdfBlockFloats * (size_t)((posy << k) + posx);
         const int32_t c = env_warp_level(b, px, py, posx, posy);
         env_warp_level(b + 3 + 3 * c, px, py, posx, posy);
         blk += (size_t)kEnvCdfBlockFloats << (2 * k);
+    }
+    if (k < top) {                                              // the last pair: one 128-byte line, the finest records carry their four texels
+        const int32_t s = (top & 1) ? 0 : 1;
+        const float* b = P.env_cdf + env_cdf_last_pair_floats(s, (top + 1 - s) / 2) + kEnvCdfLastBlockFloats * (size_t)((posy << k) + posx);
+        const int32_t c = env_warp_level(b, px, py, posx, posy);
+        const float* child = b + kEnvCdfLastChild0 + kEnvCdfLastChildFloats * c;
+        const int32_t c2 = env_warp_level(child, px, py, posx, posy);
+        w_texel = child[3 + c2];
     }
     const float u = ((float)posx + px) * P.u.env_imp_inv_dim[0];
     const float v = ((float)posy + py) * P.u.env_imp_inv_dim[1];
@@ -523,7 +536,7 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
     const v3 c = env_texture(P, u, v);
     Le = v3{ P.u.env_strength * c.x, P.u.env_strength * c.y, P.u.env_strength * c.z };
     const float avg_w = imp_fetch(P, 0, 0, P.u.env_imp_base_mip);
-    pdf_out = (imp_fetch(P, posx, posy, 0) / avg_w) * kInv4Pi;
+    pdf_out = (w_texel / avg_w) * kInv4Pi;
 }
 
 // ---------------------------------------------------------------------------------------------------
