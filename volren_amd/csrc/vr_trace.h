@@ -77,11 +77,15 @@ struct FirstStash { v3 dir; uint32_t item; };
 // Cold: path state that only the rare events (new sample, scatter, escape) read or write.  On the GPU it is parked
 // in LDS ([field][lane] dwords, conflict-free) so that it does not occupy registers while the lane marches; the
 // host harness backs it with a plain array.  `Cold` is any type with float ld(int) / void st(int, float).
-// Field order = six 16-byte groups that the events read and write whole, so that a path's cold state is one
-// 128-byte line of [slot][field] storage and adjacent accesses fuse into dwordx4:
-//   (pos, f_p) (dir, n_paths) (thr, item) (L, -) (sh_a, sh_pdf) (sh_Le, -)
+// Field order = six 16-byte groups (a vec3 and a scalar each: adjacent accesses fuse into dwordx4) in three 32-byte sectors, the
+// granularity at which the L2 writes a dirty line back, sorted by WHO WRITES them:
+//   sector 0 (the scatter event, POSTNEE):      (L, n_paths) (dir, f_p)
+//   sector 1 (the collision event, NEE):        (pos, sh_pdf) (thr, item)
+//   sector 2 (NEE; read by POSTNEE only):       (sh_a, -) (sh_Le, -)
+// so that a bounce dirties 2 + 1 sectors of the path's 128-byte line (96 bytes written back) instead of the 3 + 2 of the
+// event-agnostic order used before (160 bytes); the last 32 bytes of the line are never touched.
 enum ColdField : int32_t {
-    C_POS = 0, C_FP = 3, C_DIR = 4, C_NPATHS = 7, C_THR = 8, C_ITEM = 11, C_L = 12, C_SHA = 16, C_SHPDF = 19, C_SHLE = 20,
+    C_L = 0, C_NPATHS = 3, C_DIR = 4, C_FP = 7, C_POS = 8, C_SHPDF = 11, C_THR = 12, C_ITEM = 15, C_SHA = 16, C_SHLE = 20,
     C_COUNT = 24, C_STRIDE = 32
 };
 template <class Cold> VR_HD v3 ld3(const Cold& c, int32_t f) { return v3{ c.ld(f), c.ld(f + 1), c.ld(f + 2) }; }
@@ -966,7 +970,6 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     if (pdf > 0.0f) {
         const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
         const float mis = P.u.show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
-        c.st(C_FP, f_p);
         st3(c, C_SHA, (thr * mis) * f_p);
         st3(c, C_SHLE, Le);
         begin_segment<K>(h, P, pos, w_i, 1);
