@@ -55,6 +55,11 @@ struct WorkUnit {
     float* out;              // sample buffer: RGBA32F per item, trace_path's vec4(L, alpha), unsanitised
 };
 
+// state of a path whose segment has ended without a real collision: a shadow segment (shadow = 1) goes to POSTNEE, a camera /
+// scatter segment (0) to ESCAPE -- one subtraction instead of compare + select
+static_assert(ST_POSTNEE == ST_ESCAPE - 1, "segment_end_state");
+VR_HD int32_t segment_end_state(int32_t shadow) { return ST_ESCAPE - shadow; }
+
 // Per-lane state is split by temperature.
 // Hot: what the DDA march / collision loop touches every iteration -- lives in registers.
 struct Hot {
@@ -636,7 +641,7 @@ VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
     h.mipq = 12;          // mip = 3; compiler address-select between them, which forces the state into scratch memory
     float tnear, tfar;
     if (!intersect_box(pos, d, P.u.vol_bb_min, P.u.vol_bb_max, tnear, tfar)) {
-        h.state = shadow ? ST_POSTNEE : ST_ESCAPE;
+        h.state = segment_end_state(shadow);
         return false;
     }
     h.ipos = mat4_point(P.u.vol_density_inv_transform, pos);
@@ -649,7 +654,7 @@ VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
         h.tau = 0.0f;
         h.t = tnear + neg_log_1m(rng(h.seed)) * P.u.vol_inv_majorant;
         if (h.t < h.far) { h.majorant = P.u.vol_majorant; h.state = ST_COLLIDE; }
-        else h.state = shadow ? ST_POSTNEE : ST_ESCAPE;
+        else h.state = segment_end_state(shadow);
         return true;
     }
     h.ri = v3{ 1.0f / h.idir.x, 1.0f / h.idir.y, 1.0f / h.idir.z };
@@ -730,12 +735,12 @@ VR_HD void march_load(const SceneParams& P, MarchIO& io) {
 }
 template <bool TF>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
-    if (!io.go1) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    if (!io.go1) { h.state = segment_end_state(h.shadow); return; }
     float t = io.t1, maj = io.i1 >= 0 ? majorant_value<TF>(P, io.maj1) : 0.0f;
     float tau = h.tau - maj * io.dt1;
     int32_t q = h.mipq < 12 ? h.mipq + 1 : 12;
     if (tau > 0.0f) {                                              // no tentative collision in the first cell: second step
-        if (!io.go2) { h.t = t; h.tau = tau; h.mipq = q; h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+        if (!io.go2) { h.t = t; h.tau = tau; h.mipq = q; h.state = segment_end_state(h.shadow); return; }
         maj = io.i2 >= 0 ? majorant_value<TF>(P, io.maj2) : 0.0f;
         t = io.t1 + io.dt2;
         tau = tau - maj * io.dt2;
@@ -744,7 +749,7 @@ VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     }
     t += tau / maj;
     h.t = t; h.tau = tau; h.mipq = q;
-    if (t >= h.far) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    if (t >= h.far) { h.state = segment_end_state(h.shadow); return; }
     h.majorant = maj;
     h.state = ST_COLLIDE;
 }
@@ -788,7 +793,7 @@ VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     int32_t q = h.mipq;
 #pragma unroll
     for (int k = 0; k < kMarchSteps; ++k) {
-        if (!io.go[k]) { h.t = t; h.tau = tau; h.mipq = q; h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+        if (!io.go[k]) { h.t = t; h.tau = tau; h.mipq = q; h.state = segment_end_state(h.shadow); return; }
         maj = io.idx[k] >= 0 ? majorant_value<TF>(P, io.maj[k]) : 0.0f;
         t = io.t[k];
         tau = tau - maj * io.dt[k];
@@ -800,7 +805,7 @@ VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
 tentative_collision:
     t += tau / maj;
     h.t = t; h.tau = tau; h.mipq = q;
-    if (t >= h.far) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    if (t >= h.far) { h.state = segment_end_state(h.shadow); return; }
     h.majorant = maj;
     h.state = ST_COLLIDE;
 }
@@ -808,7 +813,7 @@ tentative_collision:
 // one iteration (sequential form; the scheduler uses the two-phase form above)
 template <bool TF, int DENSE = 2>
 VR_HD void do_march(Hot& h, const SceneParams& P) {
-    if (!(h.t < h.far)) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    if (!(h.t < h.far)) { h.state = segment_end_state(h.shadow); return; }
     const v3 curr = axpy(h.ipos, h.t, h.idir);
     const int32_t m = round_mip_q(h.mipq);
     const float majorant = majorant_at<TF, DENSE>(P, curr, m);
@@ -818,7 +823,7 @@ VR_HD void do_march(Hot& h, const SceneParams& P) {
     h.mipq = h.mipq < 12 ? h.mipq + 1 : 12;                 // mip = min(mip + 0.25, 3)
     if (h.tau > 0.0f) return;
     h.t += h.tau / majorant;
-    if (h.t >= h.far) { h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE; return; }
+    if (h.t >= h.far) { h.state = segment_end_state(h.shadow); return; }
     h.majorant = majorant;
     h.state = ST_COLLIDE;
 }
@@ -919,7 +924,7 @@ VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO
     if (global) {
         // stays in ST_COLLIDE while the ray is inside the box
         h.t = h.t + neg_log_1m(rng(h.seed)) * u.vol_inv_majorant;
-        if (!(h.t < h.far)) h.state = h.shadow ? ST_POSTNEE : ST_ESCAPE;
+        if (!(h.t < h.far)) h.state = segment_end_state(h.shadow);
         return;
     }
     h.tau = neg_log_1m(rng(h.seed));
