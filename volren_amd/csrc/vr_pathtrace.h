@@ -276,6 +276,7 @@ pathtrace_kernel(const KernelArgs A) {
     // tentative collision; one copy per workgroup in LDS replaces those global gathers.  Larger LUTs stay in global memory.
     __shared__ float lds_lut[K::tf ? 4 * kLutLdsEntries : 4];
     const bool lut_in_lds = K::tf && P.u.tf_size <= (uint32_t)kLutLdsEntries;
+    const bool emission_on = K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1;
     if (K::tf) {
         if (lut_in_lds)
             for (uint32_t i = threadIdx.x; i < 4u * P.u.tf_size; i += 256u) lds_lut[i] = P.tf_lut[i];
@@ -360,7 +361,13 @@ pathtrace_kernel(const KernelArgs A) {
             if (take > 0) {
                 if (slot < 0) {
                     const int32_t r = (int32_t)lane_rank(idle);
-                    if (r < take) { slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load_resume(l, slot); }
+                    if (r < take) {
+                        slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load_resume(l, slot);
+                        if (emission_on && !l.shadow) {              // EmissionCache (vr_trace.h Hot): the collisions of this segment add to L
+                            const ColdT c{ cold_base + slot * kColdSlotStride };
+                            l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L);
+                        }
+                    }
                 }
                 cnt_ready -= take;
             }
@@ -409,8 +416,8 @@ pathtrace_kernel(const KernelArgs A) {
             collide_load<K>(P, cio);
             if (is_c) {
                 ColdT c{ cold_base + slot * kColdSlotStride };
-                if (lut_in_lds) collide_finish<K>(l, c, P, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
-                else collide_finish<K>(l, c, P, cio, P.tf_lut);
+                if (lut_in_lds) collide_finish<K, ColdT, true>(l, c, P, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
+                else collide_finish<K, ColdT, true>(l, c, P, cio, P.tf_lut);
             }
             // every load of the pass has been consumed or belongs to a lane that left early: say so, or the compiler carries
             // "possibly outstanding" around the loop and waits where nothing is pending
@@ -423,7 +430,10 @@ pathtrace_kernel(const KernelArgs A) {
             // one integer, so that every ballot below is a single v_cmp
             const int32_t ps = (slot >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE) ? l.state : -1;
             if (wave_ballot(ps >= 0)) {
-                if (ps >= 0) hs.save_marched(l, slot);
+                if (ps >= 0) {
+                    hs.save_marched(l, slot);
+                    if (emission_on && !l.shadow) { ColdT c{ cold_base + slot * kColdSlotStride }; st3(c, C_L, l.eL); }      // EmissionCache: L back to the cold line
+                }
                 VR_PUSH(Q_NEE, cnt_nee, ps == ST_NEE, slot);
                 VR_PUSH(Q_POST, cnt_post, ps == ST_POSTNEE, slot);
                 VR_PUSH(Q_ESC, cnt_esc, ps == ST_ESCAPE, slot);
@@ -452,7 +462,7 @@ pathtrace_kernel(const KernelArgs A) {
             Hot b;
 #else
             const int32_t my_slot = slot;
-            if (my_slot >= 0) hs.save(l, my_slot);
+            if (my_slot >= 0) { hs.save(l, my_slot); if (emission_on && !l.shadow) { ColdT c{ cold_base + my_slot * kColdSlotStride }; st3(c, C_L, l.eL); } }
             __builtin_amdgcn_wave_barrier();
             Hot& b = l;
 #endif
@@ -540,7 +550,7 @@ pathtrace_kernel(const KernelArgs A) {
             }
 #if !VR_BATCH_REGS
             __builtin_amdgcn_wave_barrier();
-            if (my_slot >= 0) hs.load_resume(l, my_slot);
+            if (my_slot >= 0) { hs.load_resume(l, my_slot); if (emission_on && !l.shadow) { const ColdT c{ cold_base + my_slot * kColdSlotStride }; l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L); } }
 #endif
         }
         if (exhausted && cnt_free == VR_POOL) break;                        // every path of the pool has finished

@@ -70,6 +70,10 @@ struct Hot {
     int32_t shadow;          // 0: sample_volumeDDA segment, 1: transmittanceDDA segment
     int32_t state;
     int32_t first;           // 1: the camera segment of a new path whose cold line has not been written yet (see FirstStash)
+    // emission kernels on the device only (EmissionCache): the path's throughput and radiance while it marches a camera / scatter
+    // segment -- every tentative collision there adds emitted light to L -- loaded when the path is resumed, L stored back when it
+    // is parked; the same additions in the same order as on the cold line, without a load-load-store per collision
+    v3 ethr, eL;
 };
 // A new path needs nothing of its cold line until its first event: position = the camera's, throughput 1, radiance 0, no
 // scatter yet.  What it does need there -- its world direction and its slot in the sample buffer -- waits in the path's hot
@@ -605,7 +609,7 @@ VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
 
 VR_HD void hot_init(Hot& h) {
     h.seed = 0u;
-    h.ipos = h.idir = h.ri = v3{ 0, 0, 0 };
+    h.ipos = h.idir = h.ri = h.ethr = h.eL = v3{ 0, 0, 0 };
     h.t = h.far = h.tau = h.majorant = h.Tr = 0.0f;
     h.mipq = 0;
     h.shadow = 0;
@@ -872,7 +876,8 @@ VR_HD void collide_load(const SceneParams& P, CollideIO<K>& io) {      // uncond
     else io.d = tap_load<K::dense>(P.density, io.a);
     if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) io.ed = tap_load<2>(P.emission, io.ea);
 }
-template <class K, class Cold>
+// CACHED: throughput and radiance of the marching path are in h.ethr / h.eL (device scheduler, see Hot); otherwise on the cold line
+template <class K, class Cold, bool CACHED = false>
 VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO<K>& io, const float* tf_lut) {
     constexpr bool USE_TF = K::tf;
     const Uniforms& u = P.u;
@@ -893,9 +898,10 @@ VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO
             const v3 e3 = v3{ tt, sqr(tt), sqr(sqr(tt)) };
             const v3 em = v3{ u.vol_emission_scale * sqr(e3.x), u.vol_emission_scale * sqr(e3.y), u.vol_emission_scale * sqr(e3.z) };
             const v3 oma = v3{ 1.0f - u.vol_albedo[0], 1.0f - u.vol_albedo[1], 1.0f - u.vol_albedo[2] };
-            const v3 thr = ld3(c, C_THR);
-            if (global) st3(c, C_L, ld3(c, C_L) + ((thr * oma) * em) * P_real);
-            else st3(c, C_L, ld3(c, C_L) + (((thr * oma) * em) * d) * u.vol_inv_majorant);
+            const v3 thr = CACHED ? h.ethr : ld3(c, C_THR);
+            const v3 L0 = CACHED ? h.eL : ld3(c, C_L);
+            const v3 L1 = global ? L0 + ((thr * oma) * em) * P_real : L0 + (((thr * oma) * em) * d) * u.vol_inv_majorant;
+            if (CACHED) h.eL = L1; else st3(c, C_L, L1);
         }
         if (global ? rng(h.seed) < P_real : rng(h.seed) * h.majorant < d) {
             // real collision.  "throughput *= albedo [* rgba.rgb]" is applied by do_nee (the one event that follows): the
