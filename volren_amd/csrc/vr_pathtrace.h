@@ -199,7 +199,7 @@ struct ColdGlobal {
 #ifndef VR_COLD_LDS
 #define VR_COLD_LDS 0
 #endif
-constexpr int32_t COLD_LDS_STRIDE = 23;          // C_SHLE + 3 = 23 dwords are used; odd: conflict-free for lanes with different slots
+constexpr int32_t COLD_LDS_STRIDE = 25;          // C_COUNT = 24 dwords are used; odd: conflict-free for lanes with different slots
 struct ColdLDS {
     float* base;
     __device__ __forceinline__ float ld(int32_t f) const { return base[f]; }
