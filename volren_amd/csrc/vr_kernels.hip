@@ -129,7 +129,6 @@ static int pathtrace_variant(const SceneParams& P) {
     return P.density.dense ? 1 : 0;
 }
 
-constexpr int kMaxWorkgroups = 2048;                // the cold-state workspace is sized for this many resident workgroups
 static int resident_blocks(int mode, int variant, bool tf, bool stats) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
@@ -138,7 +137,7 @@ static int resident_blocks(int mode, int variant, bool tf, bool stats) {
     return std::min(cus * per_cu, kMaxWorkgroups);
 }
 
-size_t pathtrace_workspace_floats() { return (size_t)kMaxWorkgroups * 4u * (kColdWaveFloats > 0 ? kColdWaveFloats : 4); }      // cold state of 4 wavefronts per resident workgroup
+size_t pathtrace_workspace_floats() { return kColdMainFloats + (size_t)kMaxWorkgroups * 4u * (size_t)kColdSideWaveFloats; }      // cold state of 4 wavefronts per resident workgroup: main slots, then the side array
 
 void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math, hipEvent_t ev_kernel_begin, hipEvent_t ev_kernel_end) {

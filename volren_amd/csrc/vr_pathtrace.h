@@ -159,64 +159,29 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         h.Tr = first ? 1.0f : h.Tr;
     }
 };
-// Cold path state of one wavefront in global memory: one 128-byte line per path slot (slot-major).  Measured alternative
-// (VR_COLD_SOA=1: group-major, [group][slot][4], an event's access then touches the <= 19 lines that hold a group's 152
-// entries instead of 64 lines): same speed, but MORE memory-side traffic -- a batch of ~45 slots drags in every line of every
-// group it touches (634 vs 585 B per sample on c2, profiles/r2_hbm_traffic.json) -- so slot-major stays.
-#ifndef VR_COLD_SOA
-#define VR_COLD_SOA 0
-#endif
-#ifndef VR_COLD_NT
-#define VR_COLD_NT 0               // experiment: non-temporal cold-state accesses
-#endif
-#ifndef VR_WHATIF_COLD_ALIAS
-#define VR_WHATIF_COLD_ALIAS 0     // diagnostic (wrong images): all slots of a wavefront share one cold entry -> what the cold traffic costs
-#endif
-constexpr int32_t kColdGroups = C_COUNT / 4;          // 6
+// Cold path state of one wavefront in global memory (vr_trace.h ColdField): a 64-byte slot per path -- half a cache line: the 16
+// floats that live as long as the path -- and, in a separate compact array, the 16 bytes that only live from a collision event to
+// the scatter event that follows it (the radiance of the pending light sample).  An event touches one half-line of the big array
+// (159 -> 80 MB for all resident wavefronts); the small one (20 MB, eight slots per line, written and read back within a shadow
+// segment) mostly stays in the L2.  Earlier layouts, measured: one 128-byte line per slot with everything in it (this file's
+// history; +7 % slower on c4), group-major [group][slot][4] (same speed, more traffic), non-temporal accesses (-21 %), everything
+// in LDS (-28 ... -42 %: the pool slots it costs), profiles/r2j_layout_experiments.txt, r2m_cold_state_in_lds_experiments.txt.
+constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state workspace is sized for this many resident workgroups (launch_pathtrace clamps the grid to it)
 struct ColdGlobal {
-    float* base;                       // the wavefront's slice + this slot's offset inside a group
-    __device__ __forceinline__ float ld(int32_t f) const {
-#if VR_COLD_NT
-        return __builtin_nontemporal_load(static_cast<const float*>(__builtin_assume_aligned(base, 16)) + ((f >> 2) * (NSLOT * 4) + (f & 3)));
-#elif VR_COLD_SOA
-        return static_cast<const float*>(__builtin_assume_aligned(base, 16))[(f >> 2) * (NSLOT * 4) + (f & 3)];
-#else
-        return static_cast<const float*>(__builtin_assume_aligned(base, 128))[f];
-#endif
+    float* base;                       // this slot's 16 floats in the wavefront's slice of the main array
+    float* side;                       // this slot's 4 floats in the wavefront's slice of the side array
+    __device__ __forceinline__ float ld(int32_t f) const {     // f is a compile-time constant at every call: the selection folds
+        return f < C_SIDE ? static_cast<const float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[f]
+                          : static_cast<const float*>(__builtin_assume_aligned(side, C_SIDE_STRIDE * 4))[f - C_SIDE];
     }
     __device__ __forceinline__ void st(int32_t f, float v) {
-#if VR_COLD_NT
-        __builtin_nontemporal_store(v, static_cast<float*>(__builtin_assume_aligned(base, 16)) + ((f >> 2) * (NSLOT * 4) + (f & 3)));
-#elif VR_COLD_SOA
-        static_cast<float*>(__builtin_assume_aligned(base, 16))[(f >> 2) * (NSLOT * 4) + (f & 3)] = v;
-#else
-        static_cast<float*>(__builtin_assume_aligned(base, 128))[f] = v;
-#endif
+        if (f < C_SIDE) static_cast<float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[f] = v;
+        else static_cast<float*>(__builtin_assume_aligned(side, C_SIDE_STRIDE * 4))[f - C_SIDE] = v;
     }
 };
-// VR_COLD_LDS: the cold state lives in LDS next to the parked hot state ([slot][field], odd stride).  Nothing of a path is in
-// global memory then; the price is LDS capacity, i.e. fewer path slots per wavefront and / or fewer wavefronts per CU.
-#ifndef VR_COLD_LDS
-#define VR_COLD_LDS 0
-#endif
-constexpr int32_t COLD_LDS_STRIDE = 25;          // C_COUNT = 24 dwords are used; odd: conflict-free for lanes with different slots
-struct ColdLDS {
-    float* base;
-    __device__ __forceinline__ float ld(int32_t f) const { return base[f]; }
-    __device__ __forceinline__ void st(int32_t f, float v) { base[f] = v; }
-};
-#if VR_COLD_LDS
-typedef ColdLDS ColdT;
-#else
 typedef ColdGlobal ColdT;
-#endif
-#if VR_COLD_LDS
-constexpr int32_t kColdWaveFloats = 0, kColdSlotStride = COLD_LDS_STRIDE;
-#elif VR_COLD_SOA
-constexpr int32_t kColdWaveFloats = kColdGroups * NSLOT * 4, kColdSlotStride = VR_WHATIF_COLD_ALIAS ? 0 : 4;
-#else
-constexpr int32_t kColdWaveFloats = C_STRIDE * NSLOT, kColdSlotStride = C_STRIDE;
-#endif
+constexpr int32_t kColdWaveFloats = C_STRIDE * NSLOT, kColdSideWaveFloats = C_SIDE_STRIDE * NSLOT;
+constexpr size_t kColdMainFloats = (size_t)kMaxWorkgroups * 4u * (size_t)kColdWaveFloats;       // the side arrays follow the main arrays of all wavefronts
 
 // the lanes for which `cond` holds; the builtin takes the i1 as it is (HIP's __ballot goes through an int: v_cndmask + v_cmp per call)
 __device__ __forceinline__ uint64_t wave_ballot(bool cond) { return __builtin_amdgcn_ballot_w64(cond); }
@@ -256,13 +221,11 @@ pathtrace_kernel(const KernelArgs A) {
 
     __shared__ uint8_t lds_q[4 * Q_COUNT * NS];
     uint8_t* const q = lds_q + wave * (Q_COUNT * NS);
-    // per-wavefront slice of the workspace: the cold fields of its NSLOT paths
-#if VR_COLD_LDS
-    __shared__ float lds_cold[4 * COLD_LDS_STRIDE * NS];
-    float* const cold_base = lds_cold + wave * (COLD_LDS_STRIDE * NS);
-#else
-    float* const cold_base = A.cold_ws + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * (size_t)kColdWaveFloats;
-#endif
+    // per-wavefront slices of the workspace: the cold fields of its NSLOT paths
+    const uint32_t wave_index = blockIdx.x * 4u + (uint32_t)wave;
+    float* const cold_base = A.cold_ws + (size_t)wave_index * (size_t)kColdWaveFloats;
+    float* const side_base = A.cold_ws + kColdMainFloats + (size_t)wave_index * (size_t)kColdSideWaveFloats;
+#define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE }
     __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NS];
     HotStore hs;
     hs.base = lds_hot + wave * (HOT_STRIDE * NS);
@@ -364,7 +327,7 @@ pathtrace_kernel(const KernelArgs A) {
                     if (r < take) {
                         slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load_resume(l, slot);
                         if (emission_on && !l.shadow) {              // EmissionCache (vr_trace.h Hot): the collisions of this segment add to L
-                            const ColdT c{ cold_base + slot * kColdSlotStride };
+                            const ColdT c = VR_COLD(slot);
                             l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L);
                         }
                     }
@@ -415,7 +378,7 @@ pathtrace_kernel(const KernelArgs A) {
             if (is_c) collide_prep<K>(l, P, cio);
             collide_load<K>(P, cio);
             if (is_c) {
-                ColdT c{ cold_base + slot * kColdSlotStride };
+                ColdT c = VR_COLD(slot);
                 if (lut_in_lds) collide_finish<K, ColdT, true>(l, c, P, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
                 else collide_finish<K, ColdT, true>(l, c, P, cio, P.tf_lut);
             }
@@ -432,7 +395,7 @@ pathtrace_kernel(const KernelArgs A) {
             if (wave_ballot(ps >= 0)) {
                 if (ps >= 0) {
                     hs.save_marched(l, slot);
-                    if (emission_on && !l.shadow) { ColdT c{ cold_base + slot * kColdSlotStride }; st3(c, C_L, l.eL); }      // EmissionCache: L back to the cold line
+                    if (emission_on && !l.shadow) { ColdT c = VR_COLD(slot); st3(c, C_L, l.eL); }      // EmissionCache: L back to the cold line
                 }
                 VR_PUSH(Q_NEE, cnt_nee, ps == ST_NEE, slot);
                 VR_PUSH(Q_POST, cnt_post, ps == ST_POSTNEE, slot);
@@ -462,7 +425,7 @@ pathtrace_kernel(const KernelArgs A) {
             Hot b;
 #else
             const int32_t my_slot = slot;
-            if (my_slot >= 0) { hs.save(l, my_slot); if (emission_on && !l.shadow) { ColdT c{ cold_base + my_slot * kColdSlotStride }; st3(c, C_L, l.eL); } }
+            if (my_slot >= 0) { hs.save(l, my_slot); if (emission_on && !l.shadow) { ColdT c = VR_COLD(my_slot); st3(c, C_L, l.eL); } }
             __builtin_amdgcn_wave_barrier();
             Hot& b = l;
 #endif
@@ -474,7 +437,7 @@ pathtrace_kernel(const KernelArgs A) {
                     bs = q[Q_ESC * NS + cnt_esc - 1 - lane];
                     hs.load(b, bs);
                     // a path that never scattered carries what it needs in its stash (FirstStash): its loads go to slot 0's line, shared by the batch
-                    const ColdT c{ cold_base + (b.first ? 0 : bs) * kColdSlotStride };
+                    const ColdT c = VR_COLD(b.first ? 0 : bs);
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
                     do_escape(b, c, E.P, w);                              // writes the sample; the slot becomes free
@@ -490,7 +453,7 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_POST * NS + cnt_post - 1 - lane];
                     hs.load(b, bs);
-                    ColdT c{ cold_base + bs * kColdSlotStride };
+                    ColdT c = VR_COLD(bs);
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
                     do_postnee<K>(b, c, E.P, w);
@@ -522,7 +485,7 @@ pathtrace_kernel(const KernelArgs A) {
                     if (lane < n) {
                         bs = q[Q_FREE * NS + cnt_free - 1 - lane];
                         hot_init(b);
-                        ColdT c{ cold_base + bs * kColdSlotStride };
+                        ColdT c = VR_COLD(bs);
                         do_new<K>(b, c, event_args().P, wu, cursor + (uint32_t)lane);
                         hs.save_new(b, bs);
                     }
@@ -539,8 +502,8 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) {
                     bs = q[Q_NEE * NS + cnt_nee - 1 - lane];
                     hs.load(b, bs);
-                    ColdT c{ cold_base + bs * kColdSlotStride };
-                    const ColdT crd{ cold_base + (b.first ? 0 : bs) * kColdSlotStride };      // first scatter of a path: nothing to read yet (do_nee)
+                    ColdT c = VR_COLD(bs);
+                    const ColdT crd = VR_COLD(b.first ? 0 : bs);      // first scatter of a path: nothing to read yet (do_nee)
                     do_nee<K>(b, c, crd, event_args().P);
                     hs.save(b, bs);
                 }
@@ -550,7 +513,7 @@ pathtrace_kernel(const KernelArgs A) {
             }
 #if !VR_BATCH_REGS
             __builtin_amdgcn_wave_barrier();
-            if (my_slot >= 0) { hs.load_resume(l, my_slot); if (emission_on && !l.shadow) { const ColdT c{ cold_base + my_slot * kColdSlotStride }; l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L); } }
+            if (my_slot >= 0) { hs.load_resume(l, my_slot); if (emission_on && !l.shadow) { const ColdT c = VR_COLD(my_slot); l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L); } }
 #endif
         }
         if (exhausted && cnt_free == VR_POOL) break;                        // every path of the pool has finished
@@ -568,6 +531,7 @@ pathtrace_kernel(const KernelArgs A) {
         for (int k = 0; k < 6; ++k) atomicAdd(&stats[26 + k], occ[k]);
     }
 #undef VR_STAT
+#undef VR_COLD
 #undef VR_THR_NEW
 #undef VR_THR_NEE
 #undef VR_THR_POST

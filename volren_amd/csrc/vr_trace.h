@@ -86,17 +86,19 @@ struct FirstStash { v3 dir; uint32_t item; };
 // Cold: path state that only the rare events (new sample, scatter, escape) read or write.  On the GPU it is parked
 // in LDS ([field][lane] dwords, conflict-free) so that it does not occupy registers while the lane marches; the
 // host harness backs it with a plain array.  `Cold` is any type with float ld(int) / void st(int, float).
-// Field order = six 16-byte groups (a vec3 and a scalar each: adjacent accesses fuse into dwordx4) in three 32-byte sectors, the
-// granularity at which the L2 writes a dirty line back, sorted by WHO WRITES them:
-//   sectors 0, 1 = the line's first 64-byte half (the collision event, NEE):   (pos, sh_pdf) (thr, item) | (sh_a, -) (sh_Le, -)
-//   sector 2 (the scatter event, POSTNEE):                                     (L, n_paths) (dir, f_p)
-// so that a bounce dirties 2 + 1 sectors of the path's 128-byte line (96 bytes written back) instead of the 3 + 2 of the
-// event-agnostic order used before (160 bytes), and each event's stores fall into one half-line; the last 32 bytes are never touched.
-// Measured (profiles/r2t_ab_cold_fields_by_writer.txt): c4 write-back 717 -> 509 B per sample, +2.3 %; NEE's two sectors in one
-// half-line instead of straddling both: same bytes, another +1.9 % (c4) / +0.6 % (c2).
+// The 16 floats that live as long as the path fill a 64-byte slot, half a cache line, in two 32-byte sectors (the granularity at
+// which the L2 writes a dirty line back) sorted by WHO WRITES them; adjacent accesses fuse into dwordx4:
+//   sector 0 (the collision event, NEE):    (pos, sh_pdf) (thr, f_p)     f_p: phase function of the light sample until the scatter
+//   sector 1 (the scatter event, POSTNEE):  (L, n_paths) (dir, item)          event replaces it by that of the scattered direction
+// The radiance of the pending light sample (3 floats, collision event -> scatter event; in the transfer-function kernels also the
+// colour of the collision, collide -> NEE) lives in a separate compact array ("side", fields >= C_SIDE): Cold types map the two
+// ranges to their storage.  The weight thr * mis * f_p of that sample is recomputed by the scatter event from thr, sh_pdf and f_p
+// (same operations on the same values as when the collision event stored it).  History: one 128-byte line per path with all 24
+// floats (c4: 2.11x the algorithmic bytes moved), fields ordered by writer (1.80x), this layout (profiles/r2y_*).
 enum ColdField : int32_t {
-    C_POS = 0, C_SHPDF = 3, C_THR = 4, C_ITEM = 7, C_SHA = 8, C_SHLE = 12, C_L = 16, C_NPATHS = 19, C_DIR = 20, C_FP = 23,
-    C_COUNT = 24, C_STRIDE = 32
+    C_POS = 0, C_SHPDF = 3, C_THR = 4, C_FP = 7, C_L = 8, C_NPATHS = 11, C_DIR = 12, C_ITEM = 15,
+    C_SIDE = 16, C_SHLE = 16,
+    C_COUNT = 20, C_STRIDE = 16, C_SIDE_STRIDE = 4
 };
 template <class Cold> VR_HD v3 ld3(const Cold& c, int32_t f) { return v3{ c.ld(f), c.ld(f + 1), c.ld(f + 2) }; }
 template <class Cold> VR_HD void st3(Cold& c, int32_t f, v3 v) { c.st(f, v.x); c.st(f + 1, v.y); c.st(f + 2, v.z); }
@@ -981,8 +983,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     c.st(C_SHPDF, pdf);
     if (pdf > 0.0f) {
         const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
-        const float mis = P.u.show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
-        st3(c, C_SHA, (thr * mis) * f_p);
+        c.st(C_FP, f_p);                // with sh_pdf and thr: what do_postnee needs for the sample's weight (thr * mis) * f_p
         st3(c, C_SHLE, Le);
         begin_segment<K>(h, P, pos, w_i, 1);
     } else {
@@ -997,13 +998,16 @@ template <class K, class Cold>
 VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
     v3 L = ld3(c, C_L);
     const float sh_pdf = c.ld(C_SHPDF);
+    v3 thr = ld3(c, C_THR);
     if (sh_pdf > 0.0f) {
-        L = L + ((ld3(c, C_SHA) * h.Tr) * ld3(c, C_SHLE)) / sh_pdf;
+        // common.glsl:620-626: L += throughput * mis * f_p * Tr * Le / pdf, the factors of the light sample do_nee drew
+        const float f_p = c.ld(C_FP);
+        const float mis = P.u.show_environment > 0 ? power_heuristic(sh_pdf, f_p) : 1.0f;
+        L = L + ((((thr * mis) * f_p) * h.Tr) * ld3(c, C_SHLE)) / sh_pdf;
         st3(c, C_L, L);
     }
     const uint32_t n_paths = ldu(c, C_NPATHS) + 1u;
     if (n_paths >= (uint32_t)P.u.bounces) { write_sample(wu, ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
-    v3 thr = ld3(c, C_THR);
     const float rr = luma(thr);
     if (rr < 0.1f) {
         const float prob = 1.0f - rr;
