@@ -160,12 +160,12 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
     }
 };
 // Cold path state of one wavefront in global memory (vr_trace.h ColdField): a 64-byte slot per path -- half a cache line: the 16
-// floats that live as long as the path -- and, in a separate compact array, the 16 bytes that only live from a collision event to
-// the scatter event that follows it (the radiance of the pending light sample).  An event touches one half-line of the big array
-// (159 -> 80 MB for all resident wavefronts); the small one (20 MB, eight slots per line, written and read back within a shadow
-// segment) mostly stays in the L2.  Earlier layouts, measured: one 128-byte line per slot with everything in it (this file's
-// history; +7 % slower on c4), group-major [group][slot][4] (same speed, more traffic), non-temporal accesses (-21 %), everything
-// in LDS (-28 ... -42 %: the pool slots it costs), profiles/r2j_layout_experiments.txt, r2m_cold_state_in_lds_experiments.txt.
+// floats that live as long as the path -- and, in a separate compact array, 16 bytes per path: the radiance of the pending light
+// sample (collision event -> scatter event) and the path's slot in the sample buffer.  An event touches one half-line of the
+// big array (159 -> 80 MB for all resident wavefronts) and dirties one of its two sectors.  Measured against one 128-byte line per
+// path with everything in it: c4 +3.3 %, c2 +1.1 %, same bytes moved (profiles/r2y_ab_cold_64_byte_slots.txt).  Earlier experiments:
+// group-major [group][slot][4] (same speed, more traffic), non-temporal accesses (-21 %), everything in LDS (-28 ... -42 %: the
+// pool slots it costs), profiles/r2j_layout_experiments.txt, r2m_cold_state_in_lds_experiments.txt.
 constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state workspace is sized for this many resident workgroups (launch_pathtrace clamps the grid to it)
 struct ColdGlobal {
     float* base;                       // this slot's 16 floats in the wavefront's slice of the main array

@@ -88,16 +88,17 @@ struct FirstStash { v3 dir; uint32_t item; };
 // host harness backs it with a plain array.  `Cold` is any type with float ld(int) / void st(int, float).
 // The 16 floats that live as long as the path fill a 64-byte slot, half a cache line, in two 32-byte sectors (the granularity at
 // which the L2 writes a dirty line back) sorted by WHO WRITES them; adjacent accesses fuse into dwordx4:
-//   sector 0 (the collision event, NEE):    (pos, sh_pdf) (thr, f_p)     f_p: phase function of the light sample until the scatter
-//   sector 1 (the scatter event, POSTNEE):  (L, n_paths) (dir, item)          event replaces it by that of the scattered direction
+//   sector 0 (the collision event, NEE):    (pos, sh_pdf) (thr, f_p of the light sample)
+//   sector 1 (the scatter event, POSTNEE):  (L, n_paths) (dir, f_p of the scattered direction)
 // The radiance of the pending light sample (3 floats, collision event -> scatter event; in the transfer-function kernels also the
-// colour of the collision, collide -> NEE) lives in a separate compact array ("side", fields >= C_SIDE): Cold types map the two
-// ranges to their storage.  The weight thr * mis * f_p of that sample is recomputed by the scatter event from thr, sh_pdf and f_p
+// colour of the collision, collide -> NEE) lives in a separate compact array ("side", fields >= C_SIDE: 16 bytes per path, with
+// the path's slot in the sample buffer, which only its first collision writes and its end reads): Cold types map the two ranges to
+// their storage.  The weight thr * mis * f_p of that sample is recomputed by the scatter event from thr, sh_pdf and f_p
 // (same operations on the same values as when the collision event stored it).  History: one 128-byte line per path with all 24
 // floats (c4: 2.11x the algorithmic bytes moved), fields ordered by writer (1.80x), this layout (profiles/r2y_*).
 enum ColdField : int32_t {
-    C_POS = 0, C_SHPDF = 3, C_THR = 4, C_FP = 7, C_L = 8, C_NPATHS = 11, C_DIR = 12, C_ITEM = 15,
-    C_SIDE = 16, C_SHLE = 16,
+    C_POS = 0, C_SHPDF = 3, C_THR = 4, C_FPL = 7, C_L = 8, C_NPATHS = 11, C_DIR = 12, C_FP = 15,
+    C_SIDE = 16, C_SHLE = 16, C_ITEM = 19,
     C_COUNT = 20, C_STRIDE = 16, C_SIDE_STRIDE = 4
 };
 template <class Cold> VR_HD v3 ld3(const Cold& c, int32_t f) { return v3{ c.ld(f), c.ld(f + 1), c.ld(f + 2) }; }
@@ -983,7 +984,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     c.st(C_SHPDF, pdf);
     if (pdf > 0.0f) {
         const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
-        c.st(C_FP, f_p);                // with sh_pdf and thr: what do_postnee needs for the sample's weight (thr * mis) * f_p
+        c.st(C_FPL, f_p);               // with sh_pdf and thr: what do_postnee needs for the sample's weight (thr * mis) * f_p
         st3(c, C_SHLE, Le);
         begin_segment<K>(h, P, pos, w_i, 1);
     } else {
@@ -1001,7 +1002,7 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
     v3 thr = ld3(c, C_THR);
     if (sh_pdf > 0.0f) {
         // common.glsl:620-626: L += throughput * mis * f_p * Tr * Le / pdf, the factors of the light sample do_nee drew
-        const float f_p = c.ld(C_FP);
+        const float f_p = c.ld(C_FPL);
         const float mis = P.u.show_environment > 0 ? power_heuristic(sh_pdf, f_p) : 1.0f;
         L = L + ((((thr * mis) * f_p) * h.Tr) * ld3(c, C_SHLE)) / sh_pdf;
         st3(c, C_L, L);
