@@ -170,12 +170,16 @@ constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state worksp
 struct ColdGlobal {
     float* base;                       // this slot's 16 floats in the wavefront's slice of the main array
     float* side;                       // this slot's 4 floats in the wavefront's slice of the side array
+    float* col;                        // C_COL: the three dwords of the path's parked hot state (LDS) that hold 1/dir -- dead between a real collision and
+                                       // the event that follows it, which is when the transfer-function kernels keep the collision's colour there
     __device__ __forceinline__ float ld(int32_t f) const {     // f is a compile-time constant at every call: the selection folds
-        return f < C_SIDE ? static_cast<const float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[f]
+        return f >= C_COL ? col[f - C_COL]
+             : f < C_SIDE ? static_cast<const float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[f]
                           : static_cast<const float*>(__builtin_assume_aligned(side, C_SIDE_STRIDE * 4))[f - C_SIDE];
     }
     __device__ __forceinline__ void st(int32_t f, float v) {
-        if (f < C_SIDE) static_cast<float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[f] = v;
+        if (f >= C_COL) col[f - C_COL] = v;
+        else if (f < C_SIDE) static_cast<float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[f] = v;
         else static_cast<float*>(__builtin_assume_aligned(side, C_SIDE_STRIDE * 4))[f - C_SIDE] = v;
     }
 };
@@ -188,6 +192,41 @@ __device__ __forceinline__ uint64_t wave_ballot(bool cond) { return __builtin_am
 __device__ __forceinline__ int32_t popc(uint64_t mask) { return (int32_t)__popcll(mask); }     // int: min(long long, int) would go through double
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Radiance of the pending light samples of a wavefront's parked paths (Hot::shle), in vector registers: slot s lives in lane
+// s & 63 of bank s >> 6 -- 3 banks x 3 components = 9 registers hold it for all <= 192 slots.  The collision-event batch
+// (lane i works on slot bs_i) moves its values to their home lanes: every lane learns through a 64-dword LDS row which batch lane
+// holds "its" slot of each bank (byte k of the row's word d = 1 + the batch lane working on slot 64 k + d) and pulls the value
+// with ds_bpermute; the scatter-event batch pulls them back from the home lanes.  Both run with all 64 lanes active.
+// What this replaces: a 12-byte store and load per bounce in a global side array (one 32-byte sector written back and a 64-byte
+// fetch each): profiles/r2z_*.
+struct ShleBanks { v3 b[3]; };
+__device__ __forceinline__ float lane_pull(uint32_t src_lane, float v) { return u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)f2u(v))); }
+// valid: this lane's batch path (slot bs) carries a value to park
+__device__ __forceinline__ void shle_park(ShleBanks& B, uint32_t* stage, int32_t lane, bool valid, int32_t bs, v3 val) {
+    // the row is how the lanes talk to each other: the fences keep a lane's read from being satisfied from its own earlier store
+    // (wavefront scope: no instruction, the LDS executes a wavefront's accesses in order)
+    stage[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (valid) reinterpret_cast<uint8_t*>(stage)[((bs & 63) << 2) + (bs >> 6)] = (uint8_t)(lane + 1);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const uint32_t w = stage[lane];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t src = (w >> (8 * k)) & 0xFFu;                 // 1 + the batch lane that holds slot 64 k + lane, or 0
+        const uint32_t from = src ? src - 1u : (uint32_t)lane;
+        const float x = lane_pull(from, val.x), y = lane_pull(from, val.y), z = lane_pull(from, val.z);
+        B.b[k] = v3{ src ? x : B.b[k].x, src ? y : B.b[k].y, src ? z : B.b[k].z };
+    }
+}
+__device__ __forceinline__ v3 shle_fetch(const ShleBanks& B, int32_t lane, int32_t bs) {
+    const uint32_t home = bs >= 0 ? (uint32_t)(bs & 63) : (uint32_t)lane;
+    const int32_t k = bs >> 6;
+    v3 r[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r[j] = v3{ lane_pull(home, B.b[j].x), lane_pull(home, B.b[j].y), lane_pull(home, B.b[j].z) };
+    return v3{ k == 0 ? r[0].x : (k == 1 ? r[1].x : r[2].x), k == 0 ? r[0].y : (k == 1 ? r[1].y : r[2].y), k == 0 ? r[0].z : (k == 1 ? r[1].z : r[2].z) };
 }
 
 // All kernel arguments travel as ONE struct so that the event code can address any of them through the kernarg pointer.
@@ -225,7 +264,15 @@ pathtrace_kernel(const KernelArgs A) {
     const uint32_t wave_index = blockIdx.x * 4u + (uint32_t)wave;
     float* const cold_base = A.cold_ws + (size_t)wave_index * (size_t)kColdWaveFloats;
     float* const side_base = A.cold_ws + kColdMainFloats + (size_t)wave_index * (size_t)kColdSideWaveFloats;
-#define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE }
+#define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE, reinterpret_cast<float*>(hs.base + (SLOT) * HOT_STRIDE + 12) }
+    // where the radiance of a parked path's pending light sample waits: vector registers (ShleBanks), or -- in the emission
+    // and transfer-function variants, which have no registers to spare -- the side array
+    constexpr bool kShleInRegs = K::emission == 0 && !K::tf;
+    static_assert(NS <= 192, "ShleBanks holds 3 x 64 slots");
+    __shared__ uint32_t lds_stage[kShleInRegs ? 4 * 64 : 4];
+    uint32_t* const stage = lds_stage + (kShleInRegs ? wave * 64 : 0);
+    ShleBanks banks;
+    banks.b[0] = banks.b[1] = banks.b[2] = v3{ 0, 0, 0 };
     __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NS];
     HotStore hs;
     hs.base = lds_hot + wave * (HOT_STRIDE * NS);
@@ -450,13 +497,13 @@ pathtrace_kernel(const KernelArgs A) {
                 n = min(64, cnt_post);
                 VR_STAT(ST_POSTNEE, n);
                 int32_t bs = -1;
+                if (lane < n) { bs = q[Q_POST * NS + cnt_post - 1 - lane]; hs.load(b, bs); }
+                if (kShleInRegs) b.shle = shle_fetch(banks, lane, bs);                     // all lanes: the values come from their home lanes
                 if (lane < n) {
-                    bs = q[Q_POST * NS + cnt_post - 1 - lane];
-                    hs.load(b, bs);
                     ColdT c = VR_COLD(bs);
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
-                    do_postnee<K>(b, c, E.P, w);
+                    do_postnee<K, ColdT, kShleInRegs>(b, c, E.P, w);
                     hs.save(b, bs);
                 }
                 cnt_post -= n;
@@ -504,9 +551,10 @@ pathtrace_kernel(const KernelArgs A) {
                     hs.load(b, bs);
                     ColdT c = VR_COLD(bs);
                     const ColdT crd = VR_COLD(b.first ? 0 : bs);      // first scatter of a path: nothing to read yet (do_nee)
-                    do_nee<K>(b, c, crd, event_args().P);
+                    do_nee<K, ColdT, kShleInRegs>(b, c, crd, event_args().P);
                     hs.save(b, bs);
                 }
+                if (kShleInRegs) shle_park(banks, stage, lane, bs >= 0, bs, b.shle);      // all lanes: the light samples go to their slots' home lanes
                 cnt_nee -= n;
                 VR_ROUTE_B(bs);
                 VR_STAT_END(ST_NEE);

@@ -20,6 +20,11 @@
 #define VR_PT_SUFFIX
 #endif
 
+#if VR_PT_VARIANT == 3 && !defined(VR_BATCH_REGS)
+// the everything-at-run-time variant needs every register it can get: its event batches reuse the marching path's registers (the
+// marching path waits in its LDS slot meanwhile) instead of a second set -- no scratch, at the price of an LDS round trip per batch
+#define VR_BATCH_REGS 0
+#endif
 #include "vr_pathtrace.h"
 
 namespace vr {

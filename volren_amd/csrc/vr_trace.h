@@ -74,6 +74,9 @@ struct Hot {
     // segment -- every tentative collision there adds emitted light to L -- loaded when the path is resumed, L stored back when it
     // is parked; the same additions in the same order as on the cold line, without a load-load-store per collision
     v3 ethr, eL;
+    // radiance of the pending light sample, do_nee -> do_postnee, for the schedulers that park it in vector registers
+    // (SHLE_IN_HOT, vr_pathtrace.h ShleBanks); otherwise it goes through the side array (C_SHLE)
+    v3 shle;
 };
 // A new path needs nothing of its cold line until its first event: position = the camera's, throughput 1, radiance 0, no
 // scatter yet.  What it does need there -- its world direction and its slot in the sample buffer -- waits in the path's hot
@@ -90,16 +93,17 @@ struct FirstStash { v3 dir; uint32_t item; };
 // which the L2 writes a dirty line back) sorted by WHO WRITES them; adjacent accesses fuse into dwordx4:
 //   sector 0 (the collision event, NEE):    (pos, sh_pdf) (thr, f_p of the light sample)
 //   sector 1 (the scatter event, POSTNEE):  (L, n_paths) (dir, f_p of the scattered direction)
-// The radiance of the pending light sample (3 floats, collision event -> scatter event; in the transfer-function kernels also the
-// colour of the collision, collide -> NEE) lives in a separate compact array ("side", fields >= C_SIDE: 16 bytes per path, with
-// the path's slot in the sample buffer, which only its first collision writes and its end reads): Cold types map the two ranges to
-// their storage.  The weight thr * mis * f_p of that sample is recomputed by the scatter event from thr, sh_pdf and f_p
-// (same operations on the same values as when the collision event stored it).  History: one 128-byte line per path with all 24
-// floats (c4: 2.11x the algorithmic bytes moved), fields ordered by writer (1.80x), this layout (profiles/r2y_*).
+// A separate compact array ("side", fields >= C_SIDE: 16 bytes per path; Cold types map the two ranges to their storage) holds the
+// path's slot in the sample buffer, which only its first collision writes and its end reads, and has room for the radiance of the
+// pending light sample (Hot::shle, 3 floats, collision event -> scatter event) for the schedulers that park it in memory.  The
+// weight thr * mis * f_p of that sample is recomputed by the scatter event from thr, sh_pdf and f_p (same operations on the same
+// values as when the collision event stored it).  History: one 128-byte line per path with all 24 floats (c4: 2.11x the
+// algorithmic bytes moved), fields ordered by writer (1.80x), 64-byte slots (profiles/r2y_*).
 enum ColdField : int32_t {
     C_POS = 0, C_SHPDF = 3, C_THR = 4, C_FPL = 7, C_L = 8, C_NPATHS = 11, C_DIR = 12, C_FP = 15,
     C_SIDE = 16, C_SHLE = 16, C_ITEM = 19,
-    C_COUNT = 20, C_STRIDE = 16, C_SIDE_STRIDE = 4
+    C_COL = 20,                 // transfer-function kernels: colour of the real collision, collide_finish -> do_nee (device: the parked path's LDS slot)
+    C_COUNT = 23, C_STRIDE = 16, C_SIDE_STRIDE = 4
 };
 template <class Cold> VR_HD v3 ld3(const Cold& c, int32_t f) { return v3{ c.ld(f), c.ld(f + 1), c.ld(f + 2) }; }
 template <class Cold> VR_HD void st3(Cold& c, int32_t f, v3 v) { c.st(f, v.x); c.st(f + 1, v.y); c.st(f + 2, v.z); }
@@ -613,7 +617,7 @@ VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
 
 VR_HD void hot_init(Hot& h) {
     h.seed = 0u;
-    h.ipos = h.idir = h.ri = h.ethr = h.eL = v3{ 0, 0, 0 };
+    h.ipos = h.idir = h.ri = h.ethr = h.eL = h.shle = v3{ 0, 0, 0 };
     h.t = h.far = h.tau = h.majorant = h.Tr = 0.0f;
     h.mipq = 0;
     h.shadow = 0;
@@ -909,8 +913,8 @@ VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO
         }
         if (global ? rng(h.seed) < P_real : rng(h.seed) * h.majorant < d) {
             // real collision.  "throughput *= albedo [* rgba.rgb]" is applied by do_nee (the one event that follows): the
-            // hot pair then never touches the path's cold state; a transfer-function colour travels there in C_SHLE
-            if (USE_TF) st3(c, C_SHLE, v3{ rgba[0], rgba[1], rgba[2] });
+            // hot pair then never touches the path's cold state in global memory; a transfer-function colour travels there in C_COL
+            if (USE_TF) st3(c, C_COL, v3{ rgba[0], rgba[1], rgba[2] });
             h.state = ST_NEE;
             return;
         }
@@ -954,7 +958,8 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
 // loads are discarded -- any line that is cheap to read (the scheduler passes one that the whole batch shares).  The loads stay
 // unconditional, followed by component-wise selects: a conditional block makes the compiler select between addresses and put
 // the path state into scratch memory.
-template <class K, class Cold>
+// SHLE_IN_HOT: the radiance of the light sample goes to h.shle (the scheduler parks it in registers) instead of the side array
+template <class K, class Cold, bool SHLE_IN_HOT = false>
 VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     const bool first = h.first != 0;
     v3 dir = ld3(crd, C_DIR), pos0 = ld3(crd, C_POS), thr = ld3(crd, C_THR);
@@ -966,8 +971,8 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     // the real collision that led here: throughput *= albedo [* rgba.rgb] (common.glsl:383-388, 491-495; see collide_finish)
     {
         const v3 alb = v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };
-        if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) thr = K::tf ? thr * (ld3(c, C_SHLE) * alb) : thr * alb;
-        else { thr = thr * alb; if (K::tf) thr = thr * ld3(c, C_SHLE); }
+        if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) thr = K::tf ? thr * (ld3(c, C_COL) * alb) : thr * alb;
+        else { thr = thr * alb; if (K::tf) thr = thr * ld3(c, C_COL); }
         st3(c, C_THR, thr);
     }
     if (first) {
@@ -985,7 +990,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     if (pdf > 0.0f) {
         const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
         c.st(C_FPL, f_p);               // with sh_pdf and thr: what do_postnee needs for the sample's weight (thr * mis) * f_p
-        st3(c, C_SHLE, Le);
+        if (SHLE_IN_HOT) h.shle = Le; else st3(c, C_SHLE, Le);
         begin_segment<K>(h, P, pos, w_i, 1);
     } else {
         c.st(C_SHPDF, 0.0f);           // marks "no next-event estimate" for do_postnee (pdf <= 0 or NaN)
@@ -995,7 +1000,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
 }
 
 // common.glsl:625-641, then the head of the next sample_volumeDDA call
-template <class K, class Cold>
+template <class K, class Cold, bool SHLE_IN_HOT = false>
 VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
     v3 L = ld3(c, C_L);
     const float sh_pdf = c.ld(C_SHPDF);
@@ -1004,7 +1009,7 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
         // common.glsl:620-626: L += throughput * mis * f_p * Tr * Le / pdf, the factors of the light sample do_nee drew
         const float f_p = c.ld(C_FPL);
         const float mis = P.u.show_environment > 0 ? power_heuristic(sh_pdf, f_p) : 1.0f;
-        L = L + ((((thr * mis) * f_p) * h.Tr) * ld3(c, C_SHLE)) / sh_pdf;
+        L = L + ((((thr * mis) * f_p) * h.Tr) * (SHLE_IN_HOT ? h.shle : ld3(c, C_SHLE))) / sh_pdf;
         st3(c, C_L, L);
     }
     const uint32_t n_paths = ldu(c, C_NPATHS) + 1u;
