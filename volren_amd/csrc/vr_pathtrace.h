@@ -201,32 +201,42 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
 // with ds_bpermute; the scatter-event batch pulls them back from the home lanes.  Both run with all 64 lanes active.
 // What this replaces: a 12-byte store and load per bounce in a global side array (one 32-byte sector written back and a 64-byte
 // fetch each): profiles/r2z_*.
-struct ShleBanks { v3 b[3]; };
-__device__ __forceinline__ float lane_pull(uint32_t src_lane, float v) { return u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)f2u(v))); }
-// valid: this lane's batch path (slot bs) carries a value to park
-__device__ __forceinline__ void shle_park(ShleBanks& B, uint32_t* stage, int32_t lane, bool valid, int32_t bs, v3 val) {
+struct ShleBanks { v3 b[3]; uint32_t item[3]; };       // item: the paths' slots in the sample buffer, parked by a path's first collision event
+__device__ __forceinline__ uint32_t lane_pull_u(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+__device__ __forceinline__ float lane_pull(uint32_t src_lane, float v) { return u2f(lane_pull_u(src_lane, f2u(v))); }
+// valid: this lane's batch path (slot bs) carries a light sample to park; with_item: also its sample-buffer slot (first collision)
+template <bool ITEMS>
+__device__ __forceinline__ void shle_park(ShleBanks& B, uint32_t* stage, int32_t lane, bool valid, int32_t bs, v3 val, bool with_item, uint32_t item) {
     // the row is how the lanes talk to each other: the fences keep a lane's read from being satisfied from its own earlier store
     // (wavefront scope: no instruction, the LDS executes a wavefront's accesses in order)
     stage[lane] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if (valid) reinterpret_cast<uint8_t*>(stage)[((bs & 63) << 2) + (bs >> 6)] = (uint8_t)(lane + 1);
+    if (valid) reinterpret_cast<uint8_t*>(stage)[((bs & 63) << 2) + (bs >> 6)] = (uint8_t)((lane + 1) | (ITEMS && with_item ? 0x80 : 0));
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const uint32_t w = stage[lane];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const uint32_t src = (w >> (8 * k)) & 0xFFu;                 // 1 + the batch lane that holds slot 64 k + lane, or 0
+        const uint32_t byte = (w >> (8 * k)) & 0xFFu, src = byte & 0x7Fu;      // src: 1 + the batch lane that holds slot 64 k + lane, or 0
         const uint32_t from = src ? src - 1u : (uint32_t)lane;
         const float x = lane_pull(from, val.x), y = lane_pull(from, val.y), z = lane_pull(from, val.z);
         B.b[k] = v3{ src ? x : B.b[k].x, src ? y : B.b[k].y, src ? z : B.b[k].z };
+        if (ITEMS) { const uint32_t it = lane_pull_u(from, item); B.item[k] = (byte & 0x80u) ? it : B.item[k]; }
     }
 }
+__device__ __forceinline__ uint32_t bank_home(int32_t lane, int32_t bs) { return bs >= 0 ? (uint32_t)(bs & 63) : (uint32_t)lane; }
 __device__ __forceinline__ v3 shle_fetch(const ShleBanks& B, int32_t lane, int32_t bs) {
-    const uint32_t home = bs >= 0 ? (uint32_t)(bs & 63) : (uint32_t)lane;
+    const uint32_t home = bank_home(lane, bs);
     const int32_t k = bs >> 6;
     v3 r[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) r[j] = v3{ lane_pull(home, B.b[j].x), lane_pull(home, B.b[j].y), lane_pull(home, B.b[j].z) };
     return v3{ k == 0 ? r[0].x : (k == 1 ? r[1].x : r[2].x), k == 0 ? r[0].y : (k == 1 ? r[1].y : r[2].y), k == 0 ? r[0].z : (k == 1 ? r[1].z : r[2].z) };
+}
+__device__ __forceinline__ uint32_t item_fetch(const ShleBanks& B, int32_t lane, int32_t bs) {
+    const uint32_t home = bank_home(lane, bs);
+    const int32_t k = bs >> 6;
+    const uint32_t r0 = lane_pull_u(home, B.item[0]), r1 = lane_pull_u(home, B.item[1]), r2 = lane_pull_u(home, B.item[2]);
+    return k == 0 ? r0 : (k == 1 ? r1 : r2);
 }
 
 // All kernel arguments travel as ONE struct so that the event code can address any of them through the kernarg pointer.
@@ -268,11 +278,16 @@ pathtrace_kernel(const KernelArgs A) {
     // where the radiance of a parked path's pending light sample waits: vector registers (ShleBanks), or -- in the emission
     // and transfer-function variants, which have no registers to spare -- the side array
     constexpr bool kShleInRegs = K::emission == 0 && !K::tf;
+    // the sample-buffer slot joins it there in the dense-grid kernel, where nearly every path scatters (c4 +1.3 %, memory-side traffic
+    // 1.59x -> 1.52x); on smoke.brick two thirds of the escaping paths never scattered and the three extra ds_bpermute of every
+    // escape batch cost more than the side-array accesses they save (c2 -0.7 %): profiles/r2z_*
+    constexpr bool kItemInRegs = kShleInRegs && K::dense == 1;
     static_assert(NS <= 192, "ShleBanks holds 3 x 64 slots");
     __shared__ uint32_t lds_stage[kShleInRegs ? 4 * 64 : 4];
     uint32_t* const stage = lds_stage + (kShleInRegs ? wave * 64 : 0);
     ShleBanks banks;
     banks.b[0] = banks.b[1] = banks.b[2] = v3{ 0, 0, 0 };
+    banks.item[0] = banks.item[1] = banks.item[2] = 0u;
     __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NS];
     HotStore hs;
     hs.base = lds_hot + wave * (HOT_STRIDE * NS);
@@ -480,14 +495,14 @@ pathtrace_kernel(const KernelArgs A) {
                 n = min(64, cnt_esc);
                 VR_STAT(ST_ESCAPE, n);
                 int32_t bs = -1;
+                if (lane < n) { bs = q[Q_ESC * NS + cnt_esc - 1 - lane]; hs.load(b, bs); }
+                if (kItemInRegs) b.item = item_fetch(banks, lane, bs);                      // all lanes
                 if (lane < n) {
-                    bs = q[Q_ESC * NS + cnt_esc - 1 - lane];
-                    hs.load(b, bs);
                     // a path that never scattered carries what it needs in its stash (FirstStash): its loads go to slot 0's line, shared by the batch
                     const ColdT c = VR_COLD(b.first ? 0 : bs);
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
-                    do_escape(b, c, E.P, w);                              // writes the sample; the slot becomes free
+                    do_escape<ColdT, kItemInRegs>(b, c, E.P, w);          // writes the sample; the slot becomes free
                 }
                 cnt_esc -= n;
                 VR_ROUTE_B(bs);                                            // ST_NEW: the slot is free again
@@ -499,11 +514,12 @@ pathtrace_kernel(const KernelArgs A) {
                 int32_t bs = -1;
                 if (lane < n) { bs = q[Q_POST * NS + cnt_post - 1 - lane]; hs.load(b, bs); }
                 if (kShleInRegs) b.shle = shle_fetch(banks, lane, bs);                     // all lanes: the values come from their home lanes
+                if (kItemInRegs) b.item = item_fetch(banks, lane, bs);
                 if (lane < n) {
                     ColdT c = VR_COLD(bs);
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
-                    do_postnee<K, ColdT, kShleInRegs>(b, c, E.P, w);
+                    do_postnee<K, ColdT, kShleInRegs, kItemInRegs>(b, c, E.P, w);
                     hs.save(b, bs);
                 }
                 cnt_post -= n;
@@ -546,15 +562,18 @@ pathtrace_kernel(const KernelArgs A) {
                 n = min(64, cnt_nee);
                 VR_STAT(ST_NEE, n);
                 int32_t bs = -1;
+                bool was_first = false;
+                uint32_t first_item = 0u;
                 if (lane < n) {
                     bs = q[Q_NEE * NS + cnt_nee - 1 - lane];
                     hs.load(b, bs);
+                    was_first = b.first != 0; first_item = f2u(b.Tr);      // a path's first collision: its sample-buffer slot is in the stash
                     ColdT c = VR_COLD(bs);
                     const ColdT crd = VR_COLD(b.first ? 0 : bs);      // first scatter of a path: nothing to read yet (do_nee)
-                    do_nee<K, ColdT, kShleInRegs>(b, c, crd, event_args().P);
+                    do_nee<K, ColdT, kShleInRegs, kItemInRegs>(b, c, crd, event_args().P);
                     hs.save(b, bs);
                 }
-                if (kShleInRegs) shle_park(banks, stage, lane, bs >= 0, bs, b.shle);      // all lanes: the light samples go to their slots' home lanes
+                if (kShleInRegs) shle_park<kItemInRegs>(banks, stage, lane, bs >= 0, bs, b.shle, was_first, first_item);      // all lanes: the light samples go to their slots' home lanes
                 cnt_nee -= n;
                 VR_ROUTE_B(bs);
                 VR_STAT_END(ST_NEE);

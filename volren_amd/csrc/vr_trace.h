@@ -77,6 +77,7 @@ struct Hot {
     // radiance of the pending light sample, do_nee -> do_postnee, for the schedulers that park it in vector registers
     // (SHLE_IN_HOT, vr_pathtrace.h ShleBanks); otherwise it goes through the side array (C_SHLE)
     v3 shle;
+    uint32_t item;           // same schedulers: the path's slot in the sample buffer (otherwise C_ITEM of the side array)
 };
 // A new path needs nothing of its cold line until its first event: position = the camera's, throughput 1, radiance 0, no
 // scatter yet.  What it does need there -- its world direction and its slot in the sample buffer -- waits in the path's hot
@@ -616,7 +617,7 @@ VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
 // state bodies
 
 VR_HD void hot_init(Hot& h) {
-    h.seed = 0u;
+    h.seed = 0u; h.item = 0u;
     h.ipos = h.idir = h.ri = h.ethr = h.eL = h.shle = v3{ 0, 0, 0 };
     h.t = h.far = h.tau = h.majorant = h.Tr = 0.0f;
     h.mipq = 0;
@@ -958,8 +959,9 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
 // loads are discarded -- any line that is cheap to read (the scheduler passes one that the whole batch shares).  The loads stay
 // unconditional, followed by component-wise selects: a conditional block makes the compiler select between addresses and put
 // the path state into scratch memory.
-// SHLE_IN_HOT: the radiance of the light sample goes to h.shle (the scheduler parks it in registers) instead of the side array
-template <class K, class Cold, bool SHLE_IN_HOT = false>
+// SHLE_IN_HOT: the radiance of the light sample goes to h.shle (the scheduler parks it in registers) instead of the side array;
+// ITEM_IN_HOT: likewise the path's slot in the sample buffer (h.item)
+template <class K, class Cold, bool SHLE_IN_HOT = false, bool ITEM_IN_HOT = false>
 VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     const bool first = h.first != 0;
     v3 dir = ld3(crd, C_DIR), pos0 = ld3(crd, C_POS), thr = ld3(crd, C_THR);
@@ -978,7 +980,8 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     if (first) {
         // what do_new left unwritten
         st3(c, C_DIR, dir); stu(c, C_NPATHS, 0u);
-        st3(c, C_L, v3{ 0, 0, 0 }); stu(c, C_ITEM, f2u(h.Tr));
+        st3(c, C_L, v3{ 0, 0, 0 });
+        if (!ITEM_IN_HOT) stu(c, C_ITEM, f2u(h.Tr));       // else the scheduler takes it from the stash (h.Tr) before this call
         c.st(C_FP, 0.0f);
     }
     h.first = 0;
@@ -1000,7 +1003,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
 }
 
 // common.glsl:625-641, then the head of the next sample_volumeDDA call
-template <class K, class Cold, bool SHLE_IN_HOT = false>
+template <class K, class Cold, bool SHLE_IN_HOT = false, bool ITEM_IN_HOT = false>
 VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
     v3 L = ld3(c, C_L);
     const float sh_pdf = c.ld(C_SHPDF);
@@ -1013,11 +1016,11 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
         st3(c, C_L, L);
     }
     const uint32_t n_paths = ldu(c, C_NPATHS) + 1u;
-    if (n_paths >= (uint32_t)P.u.bounces) { write_sample(wu, ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
+    if (n_paths >= (uint32_t)P.u.bounces) { write_sample(wu, ITEM_IN_HOT ? h.item : ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
     const float rr = luma(thr);
     if (rr < 0.1f) {
         const float prob = 1.0f - rr;
-        if (rng(h.seed) < prob) { write_sample(wu, ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
+        if (rng(h.seed) < prob) { write_sample(wu, ITEM_IN_HOT ? h.item : ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
         thr = thr / (1.0f - prob);
         st3(c, C_THR, thr);
     }
@@ -1033,11 +1036,11 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
 // common.glsl:644-651
 // `c` of a `first` path (never scattered: L = 0, throughput 1; direction and sample slot in the stash) is only read and the
 // values discarded: the scheduler points it at a line the batch shares (see do_nee)
-template <class Cold>
+template <class Cold, bool ITEM_IN_HOT = false>
 VR_HD void do_escape(Hot& h, const Cold& c, const SceneParams& P, const WorkUnit& wu) {
     const bool first = h.first != 0;
     v3 L = ld3(c, C_L), thr = ld3(c, C_THR), dir = ld3(c, C_DIR);
-    uint32_t n_paths = ldu(c, C_NPATHS), item = ldu(c, C_ITEM);
+    uint32_t n_paths = ldu(c, C_NPATHS), item = ITEM_IN_HOT ? h.item : ldu(c, C_ITEM);
     const float f_p = c.ld(C_FP);
     L = v3{ first ? 0.0f : L.x, first ? 0.0f : L.y, first ? 0.0f : L.z };
     thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
