@@ -77,7 +77,7 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 // A wavefront owns NSLOT path slots, more than it has lanes.  The 64 lanes hold, in registers, the hot state of the
 // paths that are currently marching; every other path of the pool is parked: its hot state (NHOT dwords) sits in LDS
 // and its slot id in one of the wave's LDS stacks -- READY (may march), NEE / POSTNEE / ESCAPE (wait for that event),
-// FREE.  Cold path state lives in global memory (one 128-byte line per slot, L2 / Infinity Cache resident); only the
+// FREE.  Cold path state lives in global memory (a 64-byte slot per path, see ColdGlobal) and in vector registers (ShleBanks); only the
 // events touch it.
 //   * a lane whose path reaches an event parks it (ds_write2 pairs + a stack push) and immediately resumes a READY path,
 //     so the march/collide code runs with most lanes holding a path;
