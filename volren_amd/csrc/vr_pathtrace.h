@@ -275,9 +275,9 @@ pathtrace_kernel(const KernelArgs A) {
     float* const cold_base = A.cold_ws + (size_t)wave_index * (size_t)kColdWaveFloats;
     float* const side_base = A.cold_ws + kColdMainFloats + (size_t)wave_index * (size_t)kColdSideWaveFloats;
 #define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE, reinterpret_cast<float*>(hs.base + (SLOT) * HOT_STRIDE + 12) }
-    // where the radiance of a parked path's pending light sample waits: vector registers (ShleBanks), or -- in the emission
-    // and transfer-function variants, which have no registers to spare -- the side array
-    constexpr bool kShleInRegs = K::emission == 0 && !K::tf;
+    // where the radiance of a parked path's pending light sample waits: vector registers (ShleBanks), or -- in the transfer-function
+    // variants, which have no registers to spare (126 of 128) -- the side array
+    constexpr bool kShleInRegs = !K::tf;
     // the sample-buffer slot joins it there in the dense-grid kernel, where nearly every path scatters (c4 +1.3 %, memory-side traffic
     // 1.59x -> 1.52x); on smoke.brick two thirds of the escaping paths never scattered and the three extra ds_bpermute of every
     // escape batch cost more than the side-array accesses they save (c2 -0.7 %): profiles/r2z_*
