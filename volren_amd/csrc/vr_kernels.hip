@@ -82,11 +82,15 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
 // non-empty batch runs), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
 static SchedParams g_sched = { { 64, 0, 56, 2, 60, 60, 64, 0 }, 0u };
 static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
-static int32_t g_samples_per_unit = 8;
+static int32_t g_samples_per_unit = 0;              // samples of a work unit; 0 = per kernel variant (samples_per_unit)
 static int32_t g_blocks_per_cu = 0;                 // 0 = from the occupancy query
 
 void set_stats_buffer(unsigned long long* dev) { g_stats = dev; }
 void set_samples_per_unit(int32_t n) { g_samples_per_unit = n < 1 ? 1 : n; }
+// Units of 8 samples x 64 pixels, except on the dense-grid kernel, whose long paths (128 bounces, every camera ray scatters) fill
+// the pools better from units of 4: c4 +1.3 %, c2 +-0, c3 -1 % (profiles/r2x_occupancy_recheck.txt)
+constexpr int32_t kMaxSamplesPerUnit = 8;
+static int32_t samples_per_unit(int variant) { return g_samples_per_unit > 0 ? g_samples_per_unit : (variant == 1 ? 4 : kMaxSamplesPerUnit); }
 
 void set_sched_thresholds(const int32_t thr[ST_COUNT]) {
     for (int i = 0; i < ST_COUNT; ++i) g_sched.thr[i] = thr[i];
@@ -102,9 +106,13 @@ static void tuning_from_env() {
 
 size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples) {
     tuning_from_env();
-    const int32_t spu = n_samples < g_samples_per_unit ? n_samples : g_samples_per_unit;
-    const int32_t chunks = (n_samples + spu - 1) / spu;
-    return (size_t)chunks * (size_t)n_tiles * 4u * (size_t)spu * 64u * 4u;
+    // the samples are rounded up to whole units: sized for whichever unit size a variant may use (samples_per_unit)
+    size_t padded = 0;
+    for (int variant = 0; variant < 4; ++variant) {
+        const int32_t spu = std::min(n_samples, samples_per_unit(variant));
+        padded = std::max(padded, (size_t)((n_samples + spu - 1) / spu) * (size_t)spu);
+    }
+    return padded * (size_t)n_tiles * 4u * 64u * 4u;
 }
 
 // the kernel variants live in vr_pathtrace.hip, one compilation each, in two arithmetic modes (bit-exact / tolerance)
@@ -146,14 +154,14 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     SchedParams S = g_sched;
     LaunchDesc D;
     D.tiles = tiles; D.n_tiles = n_tiles; D.first_sample = first_sample; D.n_samples = n_samples;
-    D.spu = n_samples < g_samples_per_unit ? n_samples : g_samples_per_unit;
+    const int variant = pathtrace_variant(P);
+    D.spu = std::min(n_samples, samples_per_unit(variant));
     const int32_t chunks = (n_samples + D.spu - 1) / D.spu;
     D.n_units = (uint32_t)chunks * (uint32_t)n_tiles * 4u;
     D.chunks = (uint32_t)chunks;
     D.seg_len = (D.n_units + kQueueSegments - 1u) / kQueueSegments;
     D.unit_counter = unit_counter;
     S.max_iters = kMaxIters;
-    const int variant = pathtrace_variant(P);
     const bool tf = P.u.use_tf != 0, stats = g_stats != nullptr;
     const int mode = fast_math ? 1 : 0;
     static int blocks_cache[2][4][4] = {};
