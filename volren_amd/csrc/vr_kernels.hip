@@ -79,8 +79,8 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
 }
 
 // thr[]: NEW (free slots that trigger a NEW batch), diagnostic cap on the slots in use (0 = all NSLOT), MARCH (= low-water mark of live paths: below it every
-// non-empty batch runs), COLLIDE (= march steps per pass), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
-static SchedParams g_sched = { { 64, 0, 56, 2, 60, 60, 64, 0 }, 0u };
+// non-empty batch runs), COLLIDE (= lanes that must stand at a tentative collision before the collision code runs while others still march), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
+static SchedParams g_sched = { { 64, 0, 56, 0, 60, 60, 64, 0 }, 0u };       // COLLIDE 0 = per kernel (launch_pathtrace)
 static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
 static int32_t g_samples_per_unit = 0;              // samples of a work unit; 0 = per kernel variant (samples_per_unit)
 static int32_t g_blocks_per_cu = 0;                 // 0 = from the occupancy query
@@ -162,6 +162,10 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     D.seg_len = (D.n_units + kQueueSegments - 1u) / kQueueSegments;
     D.unit_counter = unit_counter;
     S.max_iters = kMaxIters;
+    // lanes that must stand at a tentative collision before the collision code runs while others still march (vr_pathtrace.h):
+    // measured optimum 24 (smoke.brick +0.5 %, dense +0.7 %, sparse + emission +2...3.5 %), 32 with a transfer function, whose
+    // collision code (8 corner taps + LUT) is the dearest (+4.4 %); profiles/r2ab_collide_threshold.txt
+    if (S.thr[ST_COLLIDE] <= 0) S.thr[ST_COLLIDE] = P.u.use_tf ? 32 : 24;
     const bool tf = P.u.use_tf != 0, stats = g_stats != nullptr;
     const int mode = fast_math ? 1 : 0;
     static int blocks_cache[2][4][4] = {};

@@ -312,13 +312,14 @@ pathtrace_kernel(const KernelArgs A) {
     // mark of live paths ("hungry"), the slots in use (diagnostic cap)
     const int32_t pool = (A.S.thr[ST_BEGIN] > 0 && A.S.thr[ST_BEGIN] < NS) ? A.S.thr[ST_BEGIN] : NS;
     const uint32_t thr_a = (uint32_t)(A.S.thr[ST_NEW] & 255) | ((uint32_t)(A.S.thr[ST_NEE] & 255) << 8) | ((uint32_t)(A.S.thr[ST_POSTNEE] & 255) << 16) | ((uint32_t)(A.S.thr[ST_ESCAPE] & 255) << 24);
-    const uint32_t thr_b = (uint32_t)(A.S.thr[ST_MARCH] & 255) | ((uint32_t)pool << 8);
+    const uint32_t thr_b = (uint32_t)(A.S.thr[ST_MARCH] & 255) | ((uint32_t)pool << 8) | ((uint32_t)(A.S.thr[ST_COLLIDE] & 255) << 16);
 #define VR_THR_NEW ((int32_t)(thr_a & 255u))
 #define VR_THR_NEE ((int32_t)((thr_a >> 8) & 255u))
 #define VR_THR_POST ((int32_t)((thr_a >> 16) & 255u))
 #define VR_THR_ESC ((int32_t)(thr_a >> 24))
 #define VR_THR_HUNGRY ((int32_t)(thr_b & 255u))
-#define VR_POOL ((int32_t)(thr_b >> 8))
+#define VR_POOL ((int32_t)((thr_b >> 8) & 255u))
+#define VR_THR_COLLIDE ((int32_t)(thr_b >> 16))
     int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = pool;     // stack heights (wave-uniform)
     for (int32_t i = lane; i < pool; i += 64) q[Q_FREE * NS + i] = (uint8_t)i;
     __builtin_amdgcn_wave_barrier();
@@ -434,20 +435,29 @@ pathtrace_kernel(const KernelArgs A) {
 #if VR_DIAG_PAD_SLEEP > 0
             __builtin_amdgcn_s_sleep(VR_DIAG_PAD_SLEEP);       // diagnostic: 64 * n idle cycles per pass -> how latency-bound is the wavefront?
 #endif
+            // The collision code runs when enough lanes stand at a tentative collision -- or when no lane is left marching.  In a
+            // dense medium two DDA steps take most marching lanes to one (smoke.brick: 43 of 59); in a sparse grid (c5: 7.6 steps per
+            // collision) a pass would otherwise run the collision code, the most expensive block of the loop, for a dozen lanes.
+            // Lanes that wait keep their path; the marching lanes of the next pass join them.
             const bool is_c = slot >= 0 && l.state == ST_COLLIDE;
-            CollideIO<K> cio;
-            collide_idle<K>(cio);
-            if (is_c) collide_prep<K>(l, P, cio);
-            collide_load<K>(P, cio);
-            if (is_c) {
-                ColdT c = VR_COLD(slot);
-                if (lut_in_lds) collide_finish<K, ColdT, true>(l, c, P, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
-                else collide_finish<K, ColdT, true>(l, c, P, cio, P.tf_lut);
+            const int32_t n_c = popc(wave_ballot(is_c));
+            const bool still_marching = wave_ballot(slot >= 0 && l.state == ST_MARCH) != 0ull;
+            if (n_c >= VR_THR_COLLIDE || (n_c > 0 && !still_marching)) {
+                CollideIO<K> cio;
+                collide_idle<K>(cio);
+                if (is_c) collide_prep<K>(l, P, cio);
+                collide_load<K>(P, cio);
+                if (is_c) {
+                    ColdT c = VR_COLD(slot);
+                    if (lut_in_lds) collide_finish<K, ColdT, true>(l, c, P, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
+                    else collide_finish<K, ColdT, true>(l, c, P, cio, P.tf_lut);
+                }
+                if (STATS) { st_exec[ST_COLLIDE] += 1u; st_lanes[ST_COLLIDE] += (uint32_t)n_c; }
             }
             // every load of the pass has been consumed or belongs to a lane that left early: say so, or the compiler carries
             // "possibly outstanding" around the loop and waits where nothing is pending
             __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0)
-            if (STATS) { const int32_t nc = popc(wave_ballot(is_c)); if (nc) { st_exec[ST_COLLIDE] += 1u; st_lanes[ST_COLLIDE] += (uint32_t)nc; } st_cyc[ST_COLLIDE] += __builtin_readcyclecounter() - t_blk; }
+            if (STATS) st_cyc[ST_COLLIDE] += __builtin_readcyclecounter() - t_blk;
         }
         // (3) park paths that reached an event
         {
@@ -605,6 +615,7 @@ pathtrace_kernel(const KernelArgs A) {
 #undef VR_THR_ESC
 #undef VR_THR_HUNGRY
 #undef VR_POOL
+#undef VR_THR_COLLIDE
 #undef VR_STAT_END
 #undef VR_PUSH
 #undef VR_ROUTE
