@@ -924,3 +924,54 @@ def test_no_path_depends_on_stale_cold_state(config, monkeypatch):
     r.render(4)                                   # the workspace is allocated (and poisoned) by the first launch
     monkeypatch.delenv("VR_TEST_POISON_WORKSPACE")
     _assert_same(r.framebuffer(), o.render(4), "poisoned workspace, " + config)
+
+
+@pytest.mark.parametrize("config", ["c2", "c3", "c4:64", "c5:32"])
+def test_results_do_not_depend_on_the_scheduler(config):
+    """Which lane runs which path when -- event-batch thresholds, the number of lanes that must stand at a collision before the
+    collision code runs, the size of the path pool, the samples per work unit -- never changes a result: every setting below gives
+    the image the default gives, bit for bit (and that one is the oracle's, asserted by the other tests)."""
+    import volren_amd
+    w, h, spp = 72, 56, 6
+    r = scenes.hip_scene(config, w, h)
+    r.render(spp)
+    want = r.framebuffer().copy()
+    # NEW, pool cap, hungry, collide threshold, NEE, POSTNEE, ESCAPE
+    settings = [[64, 0, 56, 1, 60, 60, 64, 0], [64, 0, 56, 64, 60, 60, 64, 0], [8, 0, 8, 40, 8, 8, 8, 0], [64, 70, 56, 24, 64, 64, 64, 0],
+                [1, 66, 1, 1, 1, 1, 1, 0], [64, 0, 64, 63, 64, 64, 64, 0]]
+    try:
+        for s in settings:
+            volren_amd.set_sched(s)
+            r.reset()
+            r.render(spp)
+            got = r.framebuffer()
+            assert np.array_equal(_bits(got), _bits(want)), ("scheduler setting", s)
+    finally:
+        volren_amd.set_sched([64, 0, 56, 0, 60, 60, 64, 0])        # the defaults (vr_kernels.hip g_sched)
+
+
+def test_random_parameter_sets_match_oracle():
+    """Seeded random combinations of the renderer's fields (resolution, samples, bounces, albedo, phase, density scale, environment
+    strength / rotation / visibility, camera, transfer function on / off) on smoke.brick: HIP == oracle bit for bit."""
+    rs = np.random.RandomState(20260)
+    for i in range(10):
+        base = "c3" if rs.rand() < 0.4 else "c2"
+        w, h, spp = int(rs.randint(3, 70)), int(rs.randint(3, 60)), int(rs.randint(1, 8))
+        fields = dict(bounces=int(rs.randint(1, 24)), albedo=tuple(float(x) for x in rs.uniform(0.0, 1.0, 3)), phase=float(rs.uniform(-0.9, 0.9)),
+                      density_scale=float(10.0 ** rs.uniform(0.0, 3.0)), env_strength=float(rs.uniform(0.1, 5.0)), show_environment=bool(rs.rand() < 0.7),
+                      cam_fov=float(rs.uniform(15.0, 110.0)), seed=int(rs.randint(-1000, 1000)))
+        d = rs.normal(size=3)
+        d /= np.linalg.norm(d)
+        dist = float(rs.uniform(0.2, 2.5))
+        fields["cam_pos"] = tuple(float(x) for x in (-d * dist))
+        fields["cam_dir"] = tuple(float(x) for x in (d + rs.normal(scale=0.15, size=3)))
+        o = scenes.oracle_scene(base, w, h)
+        r = scenes.hip_scene(base, w, h)
+        rot = float(rs.uniform(0.0, 360.0))
+        o.set_env_rot(rot)
+        r.env_rot = rot
+        for k, v in fields.items():
+            setattr(o, k, v)
+            setattr(r, k, v)
+        r.render(spp)
+        _assert_same(r.framebuffer(), o.render(spp), "random set %d: %s %dx%d %d spp %s" % (i, base, w, h, spp, fields))
