@@ -282,6 +282,7 @@ pathtrace_kernel(const KernelArgs A) {
     // 1.59x -> 1.52x); on smoke.brick two thirds of the escaping paths never scattered and the three extra ds_bpermute of every
     // escape batch cost more than the side-array accesses they save (c2 -0.7 %): profiles/r2z_*
     constexpr bool kItemInRegs = kShleInRegs && K::dense == 1;
+    static_assert(!kItemInRegs || K::emission == 0, "with an emission grid do_new writes the sample-buffer slot to the side array (no stash to park it from)");
     static_assert(NS <= 192, "ShleBanks holds 3 x 64 slots");
     __shared__ uint32_t lds_stage[kShleInRegs ? 4 * 64 : 4];
     uint32_t* const stage = lds_stage + (kShleInRegs ? wave * 64 : 0);
