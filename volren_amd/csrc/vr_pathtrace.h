@@ -91,10 +91,10 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #define VR_NSLOT 152
 #endif
 constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
-// The transfer-function kernels stage the LUT (up to kLutLdsEntries vec4 = 4 KiB) in LDS and give up 16 path slots for it:
-// 4 workgroups x (136 slots x 65 B x 4 wavefronts + 4 KiB) = 154.1 KiB of the CU's 160 KiB.
+// The transfer-function kernels stage the LUT (up to kLutLdsEntries vec4 = 4 KiB) in LDS and give up 12 path slots for it:
+// 4 workgroups x (140 slots x 65 B x 4 wavefronts + 4 KiB) = 158.2 KiB of the CU's 160 KiB.
 #ifndef VR_NSLOT_TF
-#define VR_NSLOT_TF (VR_NSLOT >= 152 ? VR_NSLOT - 16 : VR_NSLOT)
+#define VR_NSLOT_TF (VR_NSLOT >= 152 ? VR_NSLOT - 12 : VR_NSLOT)
 #endif
 constexpr int32_t kLutLdsEntries = 256;
 template <class K> constexpr int32_t pool_slots() { return K::tf ? VR_NSLOT_TF : VR_NSLOT; }
