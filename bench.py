@@ -373,10 +373,10 @@ def main():
         for name in [x for x in extra.split(",") if x]:
             try:
                 bx = Bench(name, w, h, spp, 1, 0, local_rank, None)
-                mx = bx.measure(2, 1)
+                mx = bx.measure(3, 1)
                 _, cx = cpu_baseline_and_counters(name, 0.5, aspect=w / h)
                 out["configs"].append({"name": name, "workload": workload_name(name, w, h, spp), "value": mx["value"], "unit": "Msamples/s",
-                                       "ms_per_step": mx["ms_per_step"], "steps": 2, "warmup": 1, "roofline": bx.roofline(mx, cx)})
+                                       "ms_per_step": mx["ms_per_step"], "steps": 3, "warmup": 1, "roofline": bx.roofline(mx, cx)})
                 del bx
             except Exception as e:                             # noqa: BLE001
                 out["configs"].append({"name": name, "error": str(e)})
