@@ -191,6 +191,8 @@ class Bench:
 
     def measure(self, steps, warmup):
         torch, dist = self.torch, self.dist
+        import gc
+        gc.collect()                                                            # destructors of earlier renderers (16 GiB pools) run now, not inside the timed region
         for _ in range(warmup):
             self.step()
         self.barrier()
