@@ -440,10 +440,12 @@ pathtrace_kernel(const KernelArgs A) {
             // dense medium two DDA steps take most marching lanes to one (smoke.brick: 43 of 59); in a sparse grid (c5: 7.6 steps per
             // collision) a pass would otherwise run the collision code, the most expensive block of the loop, for a dozen lanes.
             // Lanes that wait keep their path; the marching lanes of the next pass join them.
+            // A wavefront that is running dry (end of the launch: a handful of deep paths) must not make them wait for each other:
+            // the threshold is at most half the lanes that hold a marching or colliding path.
             const bool is_c = slot >= 0 && l.state == ST_COLLIDE;
             const int32_t n_c = popc(wave_ballot(is_c));
-            const bool still_marching = wave_ballot(slot >= 0 && l.state == ST_MARCH) != 0ull;
-            if (n_c >= VR_THR_COLLIDE || (n_c > 0 && !still_marching)) {
+            const int32_t n_m = popc(wave_ballot(slot >= 0 && l.state == ST_MARCH));
+            if (n_c > 0 && n_c >= min(VR_THR_COLLIDE, (n_c + n_m + 1) >> 1)) {
                 CollideIO<K> cio;
                 collide_idle<K>(cio);
                 if (is_c) collide_prep<K>(l, P, cio);
