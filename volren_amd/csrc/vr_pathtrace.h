@@ -97,7 +97,19 @@ constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
 #define VR_NSLOT_TF (VR_NSLOT >= 152 ? VR_NSLOT - 12 : VR_NSLOT)
 #endif
 constexpr int32_t kLutLdsEntries = 256;
-template <class K> constexpr int32_t pool_slots() { return K::tf ? VR_NSLOT_TF : VR_NSLOT; }
+// Build-time experiment (round 3, -DVR_COLD_REGS=1; profiles/r3a_cold_state_in_registers.txt): cold path state in VECTOR REGISTERS
+// (ColdBanks below) instead of global memory, for the dense-grid kernel, whose paths scatter 3.2 times per sample (c4) and spend a
+// third of their memory-side traffic on the 64-byte cold slots.  Three wavefronts per SIMD instead of four leave each 168 registers:
+// the fourth wavefront's share of the register file holds the cold state of all 192 slots of the other three (3 banks x 20 fields =
+// 60 registers), its share of the LDS makes the pools 192 slots instead of 152.  No cold workspace, no cold traffic, bit-identical
+// images.  Measured on c4: +7 % against the same 3 x 192 configuration with the cold state in memory, but the fourth wavefront is
+// worth 10 %: 1.906 against 1.972 Gsamples/s for the default (4 x 152, cold state in memory).  Off by default.
+#ifndef VR_COLD_REGS
+#define VR_COLD_REGS 0
+#endif
+template <class K> constexpr bool cold_in_regs() { return VR_COLD_REGS != 0 && !K::tf && K::dense == 1 && K::emission == 0; }
+template <class K> constexpr int32_t pool_slots() { return cold_in_regs<K>() ? 192 : (K::tf ? VR_NSLOT_TF : VR_NSLOT); }
+template <class K> constexpr int32_t waves_per_simd() { return cold_in_regs<K>() ? 3 : VR_WAVES_PER_SIMD; }
 
 enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
 
@@ -239,6 +251,72 @@ __device__ __forceinline__ uint32_t item_fetch(const ShleBanks& B, int32_t lane,
     return k == 0 ? r0 : (k == 1 ? r1 : r2);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The whole cold state of a wavefront's paths in vector registers (cold_in_regs kernels): field f of slot s lives in lane s & 63 of
+// register v[s >> 6][f] -- the 16 floats of a cold slot (ColdField, vr_trace.h) followed by the radiance of the pending light
+// sample and the path's slot in the sample buffer.  An event batch (lane i works on slot bs_i) pulls the fields its event reads
+// into a per-lane working copy (ColdLocal: the `Cold` the lane code of vr_trace.h is written against) with ds_bpermute -- one
+// per bank, the lane's own bank selected afterwards -- and the home lanes pull the fields the event wrote back the same way,
+// told by the LDS row of shle_park which batch lane holds "their" slot of each bank.  All of it runs with all 64 lanes active.
+constexpr int32_t kBankFields = 20;
+static_assert(C_SIDE == 16 && C_SHLE == 16 && C_ITEM == 19 && C_COL == kBankFields, "ColdLocal maps field f to v[f]");
+struct ColdBanks { float v[3][kBankFields]; };
+struct ColdLocal {
+    float v[kBankFields];
+    float* col;                        // C_COL (transfer-function kernels): the parked path's LDS slot, as in ColdGlobal
+    __device__ __forceinline__ float ld(int32_t f) const { return f >= C_COL ? col[f - C_COL] : v[f]; }      // f is a compile-time constant at every call
+    __device__ __forceinline__ void st(int32_t f, float x) { if (f >= C_COL) col[f - C_COL] = x; else v[f] = x; }
+};
+constexpr uint32_t cold_bits(int32_t first, int32_t n) { return ((1u << n) - 1u) << first; }
+// what each event reads and writes (do_nee / do_postnee / do_escape, vr_trace.h)
+constexpr uint32_t kColdNeeR = cold_bits(C_POS, 3) | cold_bits(C_THR, 3) | cold_bits(C_DIR, 3);
+constexpr uint32_t kColdNeeW = cold_bits(C_POS, 8) | cold_bits(C_SHLE, 3);                                                // pos, sh_pdf, thr, f_p of the light sample, its radiance
+constexpr uint32_t kColdNeeWFirst = cold_bits(C_L, 8) | cold_bits(C_ITEM, 1);                                             // a path's first collision: L, n_paths, dir, f_p, sample slot
+constexpr uint32_t kColdPostR = cold_bits(C_POS, 15) | cold_bits(C_SHLE, 4);                                              // everything but C_FP
+constexpr uint32_t kColdPostW = cold_bits(C_THR, 3) | cold_bits(C_L, 8);                                                  // thr (roulette), L, n_paths, dir, f_p
+constexpr uint32_t kColdEscR = cold_bits(C_THR, 3) | cold_bits(C_L, 8) | cold_bits(C_ITEM, 1);
+__device__ __forceinline__ void cold_clear(ColdLocal& c) {
+#pragma unroll
+    for (int f = 0; f < kBankFields; ++f) c.v[f] = 0.0f;
+    c.col = nullptr;
+}
+template <uint32_t MASK>
+__device__ __forceinline__ void cold_fetch(ColdLocal& c, const ColdBanks& B, int32_t lane, int32_t bs) {
+    const uint32_t home = bank_home(lane, bs);
+    const int32_t k = bs >> 6;
+#pragma unroll
+    for (int f = 0; f < kBankFields; ++f)
+        if ((MASK >> f) & 1u) {
+            const float r0 = lane_pull(home, B.v[0][f]), r1 = lane_pull(home, B.v[1][f]), r2 = lane_pull(home, B.v[2][f]);
+            c.v[f] = k == 0 ? r0 : (k == 1 ? r1 : r2);
+        }
+}
+// the row through which the home lanes learn who works on their slots: byte k of word d = 1 + the batch lane that holds slot 64 k + d
+// (bit 7: that lane's `flag`), 0 = nobody.  The fences keep a lane's read from being satisfied from its own earlier store.
+__device__ __forceinline__ uint32_t cold_stage(uint32_t* stage, int32_t lane, int32_t bs, bool flag) {
+    stage[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (bs >= 0) reinterpret_cast<uint8_t*>(stage)[((bs & 63) << 2) + (bs >> 6)] = (uint8_t)((lane + 1) | (flag ? 0x80 : 0));
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    return stage[lane];
+}
+// FLAGGED: only from batch lanes that raised their flag
+template <uint32_t MASK, bool FLAGGED>
+__device__ __forceinline__ void cold_store(ColdBanks& B, uint32_t w, int32_t lane, const ColdLocal& c) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t byte = (w >> (8 * k)) & 0xFFu, src = byte & 0x7Fu;
+        const uint32_t from = src ? src - 1u : (uint32_t)lane;
+        const bool take = FLAGGED ? byte > 0x80u : src != 0u;
+#pragma unroll
+        for (int f = 0; f < kBankFields; ++f)
+            if ((MASK >> f) & 1u) {
+                const float x = lane_pull(from, c.v[f]);
+                B.v[k][f] = take ? x : B.v[k][f];
+            }
+    }
+}
+
 // All kernel arguments travel as ONE struct so that the event code can address any of them through the kernarg pointer.
 // The scene parameters alone are ~1 KiB of uniforms.  The hot pair (march / collide) reads its few fields from the by-value
 // argument, which the compiler keeps in SGPRs; the event code (new sample, NEE, scatter, escape) reads everything else --
@@ -262,7 +340,7 @@ __device__ __forceinline__ const KernelArgs& event_args() {
 }
 
 template <class K, bool STATS>
-__global__ void __launch_bounds__(256, VR_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(256, waves_per_simd<K>())
 pathtrace_kernel(const KernelArgs A) {
     const SceneParams& P = A.P;           // hot pair only; events use event_args()
     const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -277,18 +355,27 @@ pathtrace_kernel(const KernelArgs A) {
 #define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE, reinterpret_cast<float*>(hs.base + (SLOT) * HOT_STRIDE + 12) }
     // where the radiance of a parked path's pending light sample waits: vector registers (ShleBanks), or -- in the transfer-function
     // variants, which have no registers to spare (126 of 128) -- the side array
-    constexpr bool kShleInRegs = !K::tf;
+    constexpr bool kColdRegs = cold_in_regs<K>();            // the whole cold state in registers (ColdBanks); else:
+    constexpr bool kShleInRegs = !K::tf && !kColdRegs;
     // the sample-buffer slot joins it there in the dense-grid kernel, where nearly every path scatters (c4 +1.3 %, memory-side traffic
     // 1.59x -> 1.52x); on smoke.brick two thirds of the escaping paths never scattered and the three extra ds_bpermute of every
     // escape batch cost more than the side-array accesses they save (c2 -0.7 %): profiles/r2z_*
     constexpr bool kItemInRegs = kShleInRegs && K::dense == 1;
     static_assert(!kItemInRegs || K::emission == 0, "with an emission grid do_new writes the sample-buffer slot to the side array (no stash to park it from)");
     static_assert(NS <= 192, "ShleBanks holds 3 x 64 slots");
-    __shared__ uint32_t lds_stage[kShleInRegs ? 4 * 64 : 4];
-    uint32_t* const stage = lds_stage + (kShleInRegs ? wave * 64 : 0);
+    static_assert(!kColdRegs || (K::emission == 0 && !K::tf), "ColdBanks: no marching-path access to the cold state (EmissionCache), C_COL not wired");
+    __shared__ uint32_t lds_stage[kShleInRegs || kColdRegs ? 4 * 64 : 4];
+    uint32_t* const stage = lds_stage + (kShleInRegs || kColdRegs ? wave * 64 : 0);
     ShleBanks banks;
     banks.b[0] = banks.b[1] = banks.b[2] = v3{ 0, 0, 0 };
     banks.item[0] = banks.item[1] = banks.item[2] = 0u;
+    ColdBanks cb;
+    if (kColdRegs) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int f = 0; f < kBankFields; ++f) cb.v[k][f] = 0.0f;
+    }
     __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NS];
     HotStore hs;
     hs.base = lds_hot + wave * (HOT_STRIDE * NS);
@@ -510,6 +597,16 @@ pathtrace_kernel(const KernelArgs A) {
                 int32_t bs = -1;
                 if (lane < n) { bs = q[Q_ESC * NS + cnt_esc - 1 - lane]; hs.load(b, bs); }
                 if (kItemInRegs) b.item = item_fetch(banks, lane, bs);                      // all lanes
+                if constexpr (kColdRegs) {
+                    ColdLocal c;
+                    cold_clear(c);
+                    cold_fetch<kColdEscR>(c, cb, lane, bs);                                  // all lanes (a path that never scattered reads its slot's leftovers and discards them)
+                    if (lane < n) {
+                        const KernelArgs& E = event_args();
+                        WorkUnit w; w.out = E.sbuf;
+                        do_escape<ColdLocal, false>(b, c, E.P, w);
+                    }
+                } else
                 if (lane < n) {
                     // a path that never scattered carries what it needs in its stash (FirstStash): its loads go to slot 0's line, shared by the batch
                     const ColdT c = VR_COLD(b.first ? 0 : bs);
@@ -528,6 +625,18 @@ pathtrace_kernel(const KernelArgs A) {
                 if (lane < n) { bs = q[Q_POST * NS + cnt_post - 1 - lane]; hs.load(b, bs); }
                 if (kShleInRegs) b.shle = shle_fetch(banks, lane, bs);                     // all lanes: the values come from their home lanes
                 if (kItemInRegs) b.item = item_fetch(banks, lane, bs);
+                if constexpr (kColdRegs) {
+                    ColdLocal c;
+                    cold_clear(c);
+                    cold_fetch<kColdPostR>(c, cb, lane, bs);
+                    if (lane < n) {
+                        const KernelArgs& E = event_args();
+                        WorkUnit w; w.out = E.sbuf;
+                        do_postnee<K, ColdLocal, false, false>(b, c, E.P, w);
+                        hs.save(b, bs);
+                    }
+                    cold_store<kColdPostW, false>(cb, cold_stage(stage, lane, bs, false), lane, c);      // a path that has ended leaves leftovers in a free slot: harmless
+                } else
                 if (lane < n) {
                     ColdT c = VR_COLD(bs);
                     const KernelArgs& E = event_args();
@@ -577,9 +686,21 @@ pathtrace_kernel(const KernelArgs A) {
                 int32_t bs = -1;
                 bool was_first = false;
                 uint32_t first_item = 0u;
+                if (lane < n) { bs = q[Q_NEE * NS + cnt_nee - 1 - lane]; hs.load(b, bs); }
+                if constexpr (kColdRegs) {
+                    ColdLocal c;
+                    cold_clear(c);
+                    cold_fetch<kColdNeeR>(c, cb, lane, bs);
+                    if (lane < n) {
+                        was_first = b.first != 0;
+                        do_nee<K, ColdLocal, false, false>(b, c, c, event_args().P);        // a first collision writes every field (its reads are discarded)
+                        hs.save(b, bs);
+                    }
+                    const uint32_t w = cold_stage(stage, lane, bs, was_first);
+                    cold_store<kColdNeeW, false>(cb, w, lane, c);
+                    if (wave_ballot(was_first)) cold_store<kColdNeeWFirst, true>(cb, w, lane, c);
+                } else
                 if (lane < n) {
-                    bs = q[Q_NEE * NS + cnt_nee - 1 - lane];
-                    hs.load(b, bs);
                     was_first = b.first != 0; first_item = f2u(b.Tr);      // a path's first collision: its sample-buffer slot is in the stash
                     ColdT c = VR_COLD(bs);
                     const ColdT crd = VR_COLD(b.first ? 0 : bs);      // first scatter of a path: nothing to read yet (do_nee)

@@ -152,6 +152,11 @@ VR_HD TapAddr tap_addr(const GridView& g, int32_t x, int32_t y, int32_t z) {
     const bool nonneg = (x | y | z) >= 0;
     if (grid_is_dense<DENSE>(g)) {          // dense fp16 grid: one 2-byte load, no indirection
         a.in = nonneg && (uint32_t)x < (uint32_t)g.dim[0] && (uint32_t)y < (uint32_t)g.dim[1] && (uint32_t)z < (uint32_t)g.dim[2];
+#if defined(VR_WHATIF_WRAP)
+        // diagnostic build (tests/tools_whatif_wrap.py): the grid holds a field of period VR_WHATIF_WRAP voxels and the taps read its
+        // first period only -- same values, a working set that fits a cache level: what would voxel taps cost if they never missed?
+        x &= VR_WHATIF_WRAP - 1; y &= VR_WHATIF_WRAP - 1; z &= VR_WHATIF_WRAP - 1;
+#endif
         // 4x4x4 blocks (vr_scene.h): neighbouring rays and the +-2-voxel stochastic taps share 128-byte lines; block counts < 2^14 per axis
         a.cell = (mul24((uint32_t)z >> 2, (uint32_t)g.dblk[1]) + ((uint32_t)y >> 2)) * (uint32_t)g.dblk[0] + ((uint32_t)x >> 2);
         a.off = (((uint32_t)z & 3u) << 4) | (((uint32_t)y & 3u) << 2) | ((uint32_t)x & 3u);
