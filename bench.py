@@ -17,7 +17,9 @@ Adds to the JSON line:
   cpu_baseline -- the CPU oracle ("port") timed on the host cores on a bounded sample of the same workload, plus
                   cpu_baseline_raymarch: the 64-step ray marcher (common.glsl:506-566) SURVEY 8d names.
   configs      -- (N=1, headline config only) the same measurement for BASELINE configs[2] (c3) and configs[3]'s grid (c4,
-                  512^3 dense fp16) at 1024x1024 / 1024 spp, the resolution north_star quotes its 40 % target at.
+                  512^3 dense fp16) at 1024x1024 / 1024 spp, the resolution north_star quotes its 40 % target at, and for
+                  configs[3] / configs[4] at their own frames (c4 at 1920x1080 x 4096 spp; c5full = 1024^3 sparse brick grid +
+                  emission at 2048x2048 x 4096 spp), two timed frames each.
   fast_math    -- (when built) the tolerance-mode kernels: speed and relative L2 against the bit-exact default.
 """
 import argparse
@@ -130,6 +132,31 @@ def profile_json(name):
     return json.load(open(path)) if os.path.exists(path) else None
 
 
+KERNEL_SOURCES = ("vr_pathtrace.h", "vr_trace.h", "vr_math.h", "vr_scene.h", "vr_pathtrace.hip")
+
+
+def kernel_source_sha():
+    """Fingerprint of the path-tracing kernel's sources: the PMC profile (tests/tools_collect_profiles.sh) records it, and a bench
+    line that quotes the profile's counters for kernels built from other sources says so (`stale`)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "volren_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_profile(cfg):
+    """(entry, file, stale) of the newest committed PMC profile that has this config, or (None, None, None)."""
+    key = cfg.split("@")[0]
+    key = {"c4:512": "c4"}.get(key, key)
+    for name in ("r3_hbm_traffic.json", "r2_hbm_traffic.json"):
+        tj = profile_json(name)
+        if tj and key in tj.get("configs", {}):
+            return tj["configs"][key], "profiles/" + name, tj.get("kernel_source_sha") != kernel_source_sha()
+    return None, None, None
+
+
 class Bench:
     """One configuration on this rank's GPU: scene resident, tile shard set up, step() = one frame."""
 
@@ -210,7 +237,7 @@ class Bench:
             self.step()
             self.barrier()
         last_r = self.slots[(self.frame - 1) % len(self.slots)]["r"]
-        pt_ms = last_r.last_pathtrace_ms()                                      # HIP events around the path-tracing kernel alone (last sub-launch)
+        pt_ms = last_r.last_pathtrace_ms()                                      # HIP events around the path-tracing kernels alone, summed over the frame's sub-launches
         last_ms = last_r.last_kernel_ms()                                       # HIP events on the renderer's stream around the last frame's launches
         if self.world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if not self.staged else "cpu")
@@ -219,7 +246,9 @@ class Bench:
         samples = float(self.w) * self.h * self.spp
         launches = max(1, self.slots[(self.frame - 1) % len(self.slots)]["r"].last_launches)                                 # a frame is split so that a sub-launch fits the sample pool
         my_samples = len(self.shard.mine) * 256.0 * self.spp if self.world > 1 else samples
-        return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=pt_ms if pt_ms > 0 else last_ms / launches, frame_gpu_ms=last_ms,
+        # pt_ms is the sum over the frame's sub-launches (HIP events around each path-tracing kernel): kernel_ms = its AVERAGE launch duration,
+        # samples_per_launch = the average samples of a launch -- what the rocprofv3 kernel statistics of the same run report
+        return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=(pt_ms if pt_ms > 0 else last_ms) / launches, frame_gpu_ms=last_ms,
                     launches=launches, samples_per_launch=my_samples / launches)
 
     def roofline(self, m, counters):
@@ -228,16 +257,19 @@ class Bench:
         b_sample, events = algorithmic_bytes_per_sample(counters, use_tf, cfg.startswith("c5"), dense=cfg.startswith("c4"))
         achieved = b_sample * m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        tj = profile_json("r2_hbm_traffic.json")                                # PMC passes (FETCH_SIZE / WRITE_SIZE), collected separately
-        if tj and cfg in tj.get("configs", {}):
-            traffic = tj["configs"][cfg]["hbm_bytes_per_sample"] * m["samples_per_launch"]
-            traffic_src = {"from_profile": "profiles/r2_hbm_traffic.json", "note": "not measured by this run: rocprofv3 --pmc passes of %s, scaled to this launch's samples" % tj["configs"][cfg].get("command", "?")}
-        variant = "dense" if cfg.startswith("c4") else ("emission" if cfg.startswith("c5") else "brick")
+        tp, tp_file, stale = traffic_profile(cfg)                               # PMC passes (FETCH_SIZE / WRITE_SIZE), collected separately
+        if tp and "hbm_bytes_per_sample" in tp:
+            traffic = tp["hbm_bytes_per_sample"] * m["samples_per_launch"]
+            traffic_src = {"from_profile": tp_file, "stale": bool(stale),
+                           "note": "not measured by this run: rocprofv3 --pmc passes of %s, scaled to this launch's samples%s" % (
+                               tp.get("command", "?"), "; the kernel sources have changed since that profile was taken" if stale else "")}
+        use_em = cfg.startswith("c5")
+        variant = "dense" if cfg.startswith("c4") else ("emission" if use_em else "brick")
         # second yardstick: the path tracer's loads are per-lane gathers, priced here at the throughput this GPU sustains for fully
         # divergent wave-level loads served by L1 / L2 / beyond L2 (tests/tools_gather_rate.hip, profiles/r2_gather_rate.txt)
         gather = None
-        if tj and cfg in tj.get("configs", {}):
-            ps, hit = tj["configs"][cfg]["per_sample"], tj["configs"][cfg]["l2_hit_rate"]
+        if tp and "per_sample" in tp:
+            ps, hit = tp["per_sample"], tp["l2_hit_rate"]
             acc, miss = ps["l1_accesses"], ps["l1_misses_to_l2"]
             beyond = miss * (1.0 - hit)
             ns = (acc - miss) / GATHER_CEILINGS["l1"] + (miss - beyond) / GATHER_CEILINGS["l2"] + beyond / GATHER_CEILINGS["beyond_l2"]
@@ -245,20 +277,21 @@ class Bench:
             kernel_rate = m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e6
             gather = {"model": "additive: per-lane accesses x the measured cost of a fully divergent gather at the level that serves it",
                       "ceilings_G_lane_accesses_per_s": GATHER_CEILINGS, "ceilings_source": "profiles/r2_gather_rate.txt",
-                      "per_sample": {"l1_accesses": acc, "l1_misses": miss, "beyond_l2": beyond}, "counts_source": "profiles/r2_hbm_traffic.json",
+                      "per_sample": {"l1_accesses": acc, "l1_misses": miss, "beyond_l2": beyond}, "counts_source": tp_file, "stale": bool(stale),
                       "model_Msamples_s": model, "kernel_Msamples_s": kernel_rate, "kernel_over_model": kernel_rate / model}
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "pathtrace_kernel<TraceCfg<tf=%s, %s>, false>" % ("true" if use_tf else "false", variant),
                 "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "samples_per_launch": m["samples_per_launch"],
                 "bytes_per_sample": b_sample, "events_per_sample": events, "gather": gather,
-                "note": "bytes = algorithmic (SURVEY 8d); the kernel runs at the rate the vector memory path sustains for its scattered per-lane gathers (`gather`, DESIGN.md 7), not at HBM bandwidth: 2-9 useful bytes per 128-byte line"}
+                "note": "bytes = algorithmic (SURVEY 8d); the kernel is limited by its work per sample (vector instructions and fully divergent vector-memory accesses at ~73 % lane utilisation), not by HBM bandwidth nor by where its gathers hit (DESIGN.md 7, profiles/r3c_whatif_voxel_taps_in_cache.txt): 2-9 useful bytes per 128-byte line"}
 
 
 def workload_name(config, w, h, spp):
     what = "synthetic dense fp16 grid" if config.startswith("c4") else ("synthetic sparse brick grid + temperature grid (emission)" if config.startswith("c5") else "smoke.brick")
     tf = " + lut.txt" if config == "c3" else (", no transfer function" if not config.startswith(("c4", "c5")) else "")
-    return "BASELINE configs[%d] '%s': %s%s, %dx%d, %d spp, seed 42, fov 40" % (CONFIG_INDEX.get(config[:2], -1), config, what, tf, w, h, spp)
+    size = " (1024^3 voxels, brick-form generator)" if config.startswith("c5full") else (" (512^3 voxels)" if config in ("c4", "c4:512") else "")
+    return "BASELINE configs[%d] '%s': %s%s%s, %dx%d, %d spp, seed 42, fov 40" % (CONFIG_INDEX.get(config[:2], -1), config, what, size, tf, w, h, spp)
 
 
 def main():
@@ -343,6 +376,8 @@ def main():
             "config": {"workload": workload_name(args.config, w, h, spp),
                        "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, ", consecutive frames pipelined over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, %d fused launch(es)/frame (16 GiB sample pool)" % m["launches"]},
             "roofline": b.roofline(m, counters),
+            "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1,
+            "dist_backend": (dist.get_backend() if world > 1 else None),
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -368,20 +403,23 @@ def main():
     # the other single-GPU BASELINE configs at the resolution north_star quotes (driver-run, not builder-only)
     extra = args.extra_configs
     if extra is None:
-        extra = "c3,c4" if (args.config == "c2" and world == 1) else "none"
+        extra = "c3,c4,c4@1920x1080x4096,c5full@2048x2048x4096" if (args.config == "c2" and world == 1) else "none"
     if rank == 0 and world == 1 and extra != "none":
         del b
         out["configs"] = []
-        for name in [x for x in extra.split(",") if x]:
+        for spec in [x for x in extra.split(",") if x]:
+            name, _, frame = spec.partition("@")                # name[@WxHxSPP]: a config at its own frame (BASELINE configs[3..4])
+            fw, fh, fspp = (int(v) for v in frame.split("x")) if frame else (w, h, spp)
+            steps_x = 2 if frame else 3
             try:
-                bx = Bench(name, w, h, spp, 1, 0, local_rank, None)
-                mx = bx.measure(3, 1)
-                _, cx = cpu_baseline_and_counters(name, 0.5, aspect=w / h)
-                out["configs"].append({"name": name, "workload": workload_name(name, w, h, spp), "value": mx["value"], "unit": "Msamples/s",
-                                       "ms_per_step": mx["ms_per_step"], "steps": 3, "warmup": 1, "roofline": bx.roofline(mx, cx)})
+                bx = Bench(name, fw, fh, fspp, 1, 0, local_rank, None)
+                mx = bx.measure(steps_x, 1)
+                _, cx = cpu_baseline_and_counters(name, 0.5, aspect=fw / fh)
+                out["configs"].append({"name": spec, "workload": workload_name(name, fw, fh, fspp), "value": mx["value"], "unit": "Msamples/s",
+                                       "ms_per_step": mx["ms_per_step"], "steps": steps_x, "warmup": 1, "roofline": bx.roofline(mx, cx)})
                 del bx
             except Exception as e:                             # noqa: BLE001
-                out["configs"].append({"name": name, "error": str(e)})
+                out["configs"].append({"name": spec, "error": str(e)})
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

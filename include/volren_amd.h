@@ -79,7 +79,12 @@ int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
 /* --- public fields of RendererOpenGL / Environment / TransferFunction / camera (src/renderer.h:30-62, environment.h:20-21,
  *     transferfunc.h:39, src/main.cpp:360-435).  Names: "sample" "sppx" "seed" "bounces" "show_environment" "tonemapping"
  *     "gpu_encoder" (dense grids are bricked on the device, default 1)
- *     "integrator" (0 DDA tracking, 1 global-majorant tracking, 2 direct volume rendering) "grid_frame_counter"
+ *     "integrator" (0 DDA tracking = both reference kernels, 1 global-majorant tracking = common.glsl:333-394, 2 direct volume rendering
+ *     = common.glsl:571-591, needs a transfer function, 3 trace_path around the 64-step ray-marching trackers = common.glsl:506-566)
+ *     "fast_math" (0 = the specified, bit-reproducible arithmetic; 1 = opt-in tolerance mode: hardware log/sin/cos/rcp, within 1e-3
+ *     relative L2 of the default -- refused with VR_ERR while a transfer function is bound, where it misses that bound)
+ *     "tf_float_atlas" (default 1: transfer-function renders of brick grids decode the atlas to floats once, 4x its size; 0 = read the bytes)
+ *     "grid_frame_counter"
  *     "sample_pool_mb" (HBM budget of the per-sample radiance pool, default 16384) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
  *     "emission_scale" "vol_clip_min"(3) "vol_clip_max"(3) "env_strength" "env_transform"(9) "env_rot"(1, degrees about +y,
  *     main.cpp:382) "tf_window_left" "tf_window_width" "cam_pos"(3) "cam_dir"(3) "cam_up"(3) "cam_fov" "volume_transform"(16) (float) */
@@ -102,7 +107,8 @@ int vr_render(vr_renderer* r, int spp);
 int vr_synchronize(vr_renderer* r);
 /* duration of the last path-tracing launch in ms, measured with HIP events on the renderer's stream (waits for it) */
 int vr_last_kernel_ms(vr_renderer* r, double* ms);
-/* duration of the path-tracing kernel alone (last sub-launch of the last vr_trace / vr_render; without the accumulation pass) */
+/* duration of the path-tracing kernel alone, summed over the sub-launches of the last vr_trace / vr_render (without the accumulation
+ * passes); 0 if that call launched none (integrators 2 and 3 run their own kernels) */
 int vr_last_pathtrace_ms(vr_renderer* r, double* ms);
 
 /* --- results.  vr_framebuffer = fbo_data() without the alpha drop (src/bindings.cpp:141-148): W*H*4 floats, row 0 bottom.
@@ -128,14 +134,16 @@ int vr_uniforms_size(void);
 /* importance pyramid of the current environment (floats, level 0 first); count from vr_impmap_floats */
 int vr_impmap_floats(vr_renderer* r);
 int vr_get_impmap(vr_renderer* r, float* out, int count);
-/* scheduler thresholds of the path-tracing kernel (8 ints, see volren_amd/csrc/vr_kernels.hip) */
-int vr_set_sched(const int32_t thresholds[8]);
+/* scheduler thresholds of THIS renderer's path-tracing launches (8 ints, vr::PathtraceTuning::thr in volren_amd/csrc/vr_device.h);
+ * tuning state is per renderer: two renderers in one process, on one device or two, never share it */
+int vr_set_sched(vr_renderer* r, const int32_t thresholds[8]);
 /* FNV-1a checksums of the committed density grid's device arrays: [0] brick records, [1] atlas, [2] range words (tests: the
  * device encoder and the host encoder must agree) */
 int vr_grid_checksums(vr_renderer* r, uint64_t out[3]);
-/* scheduler statistics (diagnostics): enable != 0 starts counting; out (32 x uint64, may be NULL) receives, per state,
- * [block executions, active lanes], then [16] wave iterations, [17] waves, [18..24] cycles per state, [25] summed wave lifetime */
-int vr_sched_stats(int enable, unsigned long long* out);
+/* scheduler statistics of this renderer's launches (diagnostics): enable != 0 starts counting (instrumented kernels); out (32 x uint64,
+ * may be NULL) receives, per state, [block executions, active lanes], then [16] wave iterations, [17] waves, [18..24] cycles per
+ * state, [25] summed wave lifetime, [26..31] summed pool occupancy */
+int vr_sched_stats(vr_renderer* r, int enable, unsigned long long* out);
 /* unit-test probe of the device math (volren_amd/csrc/vr_math.h): host arrays in/out */
 int vr_math_probe(int fn, const float* a, const float* b, float* out, int n);
 /* voldata::Volume::to_brick_grid + BrickGrid serialisation: encode a dense float grid (x fastest) and write it as a .brick

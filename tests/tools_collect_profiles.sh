@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the profiles that DESIGN.md / bench.py cite, on the GPU box (one gpurun call):
 #   1. rocprofv3 --kernel-trace --stats of the bench command            -> gpurun_out/prof/bench_kernel_stats.csv, bench line
-#   2. rocprofv3 --pmc passes (separate runs, counters only) of tests/tools_profile_run.py for c2 / c4:512 / c3
+#   2. rocprofv3 --pmc passes (separate runs, counters only) of tests/tools_profile_run.py for c2 / c4:512 / c3 / c5full
 #      -> gpurun_out/prof/pmc_<tag>_<first counter>/out_counter_collection.csv, condensed by tests/tools_pmc_summary.py
 # usage: bash tests/tools_collect_profiles.sh [bench|pmc|all]
 set -o pipefail
@@ -25,7 +25,7 @@ if [ "$what" = pmc ] || [ "$what" = all ]; then
         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU"
         "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
         "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum")
-  for spec in "c2 c2 1024 128" "c4_512 c4:512 1024 32" "c3 c3 1024 128"; do
+  for spec in "c2 c2 1024 128" "c4_512 c4:512 1024 32" "c3 c3 1024 128" "c5full c5full 2048 16"; do
     set -- $spec; tag=$1; cfg=$2; size=$3; spp=$4
     for s in "${SETS[@]}"; do
       first=${s%% *}
@@ -38,7 +38,9 @@ if [ "$what" = pmc ] || [ "$what" = all ]; then
     done
   done
   # tools_profile_run.py renders twice (warm-up + measured): 2 dispatches of the path-tracing kernel per pass
-  python3 $ROOT/tests/tools_pmc_summary.py $OUT c2=$((2*1024*1024*128)) c4_512=$((2*1024*1024*32)) c3=$((2*1024*1024*128)) > $OUT/pmc_summary.json
+  python3 $ROOT/tests/tools_pmc_summary.py $OUT c2=$((2*1024*1024*128)) c4_512=$((2*1024*1024*32)) c3=$((2*1024*1024*128)) c5full=$((2*2048*2048*16)) > $OUT/pmc_summary.json
+  cp $ROOT/profiles/r3_hbm_traffic.json $OUT/r3_hbm_traffic.json
+  python3 $ROOT/tests/tools_pmc_summary.py --merge $OUT/pmc_summary.json $OUT/r3_hbm_traffic.json c2=c2 c4=c4_512 c3=c3 c5full=c5full
   python3 - <<EOF
 import json
 s = json.load(open("$OUT/pmc_summary.json"))

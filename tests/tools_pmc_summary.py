@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: condenses rocprofv3 --pmc passes of tests/tools_profile_run.py into the per-sample figures of
-profiles/r2_hbm_traffic.json (memory-side traffic, L1/L2 request counts, instruction mix).
+profiles/r3_hbm_traffic.json (memory-side traffic, L1/L2 request counts, instruction mix).
 
     python3 tests/tools_pmc_summary.py <dir> <tag>=<samples> [...]  > summary.json
-    python3 tests/tools_pmc_summary.py --merge summary.json profiles/r2_hbm_traffic.json c2=c2 c4=c4_512 c3=c3
+    python3 tests/tools_pmc_summary.py --merge summary.json profiles/r3_hbm_traffic.json c2=c2 c4=c4_512 c3=c3
 
 <dir> holds one sub-directory per pass, pmc_<tag>_<first counter of the set>/out_counter_collection.csv (the layout the
 collection scripts under build/ write); <samples> = pixel-samples traced by ALL path-tracing dispatches of one pass.
@@ -27,10 +27,18 @@ def sums(path):
 
 
 def merge(summary, target, names):
-    """--merge <profiles/r2_hbm_traffic.json> c2=c2 c4=c4_512 ...: refresh the measured fields of the committed profile"""
+    """--merge <profiles/r3_hbm_traffic.json> c2=c2 c4=c4_512 ...: refresh the measured fields of the committed profile"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha
     old = json.load(open(target))
+    old["kernel_source_sha"] = kernel_source_sha()          # bench.py marks the profile stale once the kernel sources differ
     for cfg, tag in names.items():
+        if tag not in summary:
+            continue
         o, n = old["configs"][cfg], summary[tag]
+        o["samples"] = n["samples"]
         for f in ("fetch_bytes_per_sample", "write_bytes_per_sample", "hbm_bytes_per_sample", "l2_hit_rate", "per_sample", "lane_utilisation", "wave_cycles_share"):
             o[f] = n[f]
         o["traffic_over_algorithmic"] = round(n["hbm_bytes_per_sample"] / o["algorithmic_bytes_per_sample"], 2)

@@ -9,9 +9,8 @@ size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 r = scenes.hip_scene(cfg, size, size)
 if len(sys.argv) > 4:
-    import volren_amd
     t = [int(x) for x in sys.argv[4].split(",")]
-    volren_amd.set_sched(t + [0] * (8 - len(t)))
+    r.set_sched(t + [0] * (8 - len(t)))
 r.render(spp)
 r.reset()
 r.render(spp)

@@ -6,11 +6,11 @@ w=h=int(sys.argv[2]) if len(sys.argv)>2 else 512
 spp=int(sys.argv[3]) if len(sys.argv)>3 else 64
 thr = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv)>4 else None
 r = scenes.hip_scene(cfg,w,h)
-if thr: va.set_sched(thr+[0]*(8-len(thr)))
+if thr: r.set_sched(thr+[0]*(8-len(thr)))
 r.render(spp); r.reset()
-va.sched_stats(True)
+r.sched_stats(True)
 r.render(spp); ms=r.last_kernel_ms()
-st = va.sched_stats(False, read=True)
+st = r.sched_stats(False, read=True)
 print(cfg,w,h,spp,"thr",thr,"ms %.2f  Msamples/s %.1f"%(ms, w*h*spp/ms/1e3))
 ns = w*h*spp
 tot_exec=0

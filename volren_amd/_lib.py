@@ -78,8 +78,8 @@ def load():
     L.vr_uniforms_size.restype = ci
     L.vr_impmap_floats.argtypes = [vp]
     L.vr_get_impmap.argtypes = [vp, vp, ci]
-    L.vr_set_sched.argtypes = [vp]
-    L.vr_sched_stats.argtypes = [ci, vp]
+    L.vr_set_sched.argtypes = [vp, vp]
+    L.vr_sched_stats.argtypes = [vp, ci, vp]
     L.vr_grid_checksums.argtypes = [vp, vp]
     L.vr_math_probe.argtypes = [ci, vp, vp, vp, ci]
     L.vr_write_brick_from_dense.argtypes = [vp, ci, ci, ci, vp, C.c_char_p]

@@ -12,8 +12,6 @@
 #include "renderer.h"
 #include "vr_device.h"
 
-namespace vr { void set_sched_thresholds(const int32_t thr[8]); void set_stats_buffer(unsigned long long* dev); }
-
 struct vr_renderer {
     vr::RendererHIP impl;
     int device = 0;
@@ -453,26 +451,19 @@ int vr_get_impmap(vr_renderer* r, float* out, int count) {
     return guard([&] { use_device(r); const auto v = r->impl.environment->download_impmap(); memcpy(out, v.data(), v.size() * sizeof(float)); });
 }
 
-int vr_set_sched(const int32_t thr[8]) {
+int vr_set_sched(vr_renderer* r, const int32_t thr[8]) {
+    NEED(r);
     if (!thr) return fail(VR_ERR_ARG, "null argument");
-    vr::set_sched_thresholds(thr);
+    for (int i = 0; i < 8; ++i) r->impl.tuning.thr[i] = thr[i];
+    g_last_error.clear();
     return VR_OK;
 }
 
-// scheduler statistics of the path-tracing kernel: enable != 0 allocates/zeros 18 device counters; out (18 x u64, may be
-// NULL) receives [executions, active lanes] x 7 states, then [14],[15] unused, [16] wave iterations, [17] waves
-int vr_sched_stats(int enable, unsigned long long* out) {
-    static unsigned long long* dev = nullptr;
-    return guard([&] {
-        if (out && dev) { VR_HIP(hipDeviceSynchronize()); VR_HIP(hipMemcpy(out, dev, 32 * 8, hipMemcpyDeviceToHost)); }
-        if (enable) {
-            if (!dev) VR_HIP(hipMalloc((void**)&dev, 32 * 8));
-            VR_HIP(hipMemset(dev, 0, 32 * 8));
-            vr::set_stats_buffer(dev);
-        } else {
-            vr::set_stats_buffer(nullptr);
-        }
-    });
+// scheduler statistics of this renderer's path-tracing launches: enable != 0 zeroes its 32 device counters and switches its launches to the
+// instrumented kernels; out (32 x u64, may be NULL) receives what was counted so far (layout: include/volren_amd.h)
+int vr_sched_stats(vr_renderer* r, int enable, unsigned long long* out) {
+    NEED(r);
+    return guard([&] { use_device(r); r->impl.sched_stats(enable != 0, out); });
 }
 
 int vr_math_probe(int fn, const float* a, const float* b, float* out, int n) {

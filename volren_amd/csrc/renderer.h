@@ -16,6 +16,7 @@
 #include "environment.h"
 #include "grids.h"
 #include "transferfunc.h"
+#include "vr_device.h"
 #include "vr_scene.h"
 
 namespace vr {
@@ -38,6 +39,7 @@ struct BrickGridHIP {
     DeviceBufferPtr majorant16;    // raw fp16 range maxima in the same layout (read by the kernels without a transfer function)
     DeviceBufferPtr rng;           // compact (rmin, rdiff) float pairs, same index as `bricks` (what a tap reads)
     DeviceBufferPtr atlas_f32;     // decoded float atlas, built on the first render with a transfer function (4x the atlas; dropped by commit())
+    bool atlas_f32_failed = false; // its allocation failed once: not retried until commit() or a tf_float_atlas toggle (the byte atlas serves)
     DeviceBufferPtr dense;         // dense fp16 voxels in 4x4x4 blocks (DenseGridF16), then bricks/atlas are empty
     int32_t dim[3] = { 0, 0, 0 };
     int32_t dblk[2] = { 0, 0 };            // 4x4x4 blocks per axis (x, y) of the dense layout
@@ -114,7 +116,9 @@ struct RendererHIP {
                                                       // 2: direct volume rendering (:571-591, needs a LUT), 3: 64-step ray-marching trackers (:506-566)
     bool tf_float_atlas = true;                       // transfer-function renders decode the brick atlas to floats once (4x its size): one load per corner tap
     bool fast_math = false;                           // opt-in tolerance mode: hardware log/sin/cos/rcp instead of the specified arithmetic
-                                                      // (within 1e-3 relative L2 of the default, not bit-reproducible)
+                                                      // (not bit-reproducible; without a transfer function within 1e-3 relative L2 of the default --
+                                                      // with one bound the renderer refuses it: DESIGN.md 3)
+    PathtraceTuning tuning = default_tuning();        // scheduler thresholds, work-unit size, statistics buffer of THIS renderer's launches
     int last_launches = 0;                            // path-tracing sub-launches of the last trace()/render()
     size_t sample_pool_bytes = (size_t)16 << 30;      // HBM budget of the per-sample radiance pool (16 B per pixel-sample; sized for 288 GB HBM3E, allocated on demand)
 
@@ -124,7 +128,9 @@ struct RendererHIP {
     void download_display(float* rgba) const;
     void synchronize() const;
     double last_kernel_ms();                                    // HIP-event time of the last trace()/render(): all sub-launches, path tracing + accumulation (waits for it)
-    double last_pathtrace_ms();                                 // HIP-event time of the path-tracing kernel of the last sub-launch alone (0 for integrators 2 / 3)
+    double last_pathtrace_ms();                                 // HIP-event time of the path-tracing kernel alone, summed over the sub-launches of the last trace()/render()
+                                                                // (0 when that call launched none: integrators 2 / 3)
+    void sched_stats(bool enable, unsigned long long out[32]);  // diagnostics: out (may be null) receives the counters gathered so far; enable starts (zeroed) or stops counting
     uint32_t watchdog_status();
     ~RendererHIP();
 
@@ -136,7 +142,10 @@ private:
     DeviceBufferPtr status_;
     DeviceBufferPtr pool_;
     DeviceBufferPtr workspace_;
-    hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev2_ = nullptr, ev3_ = nullptr;
+    DeviceBufferPtr stats_;                            // 32 counters of the instrumented kernels (sched_stats)
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    std::vector<hipEvent_t> pt_events_;                // (begin, end) around the path-tracing kernel of every sub-launch
+    size_t pt_events_used_ = 0;
     double last_ms_ = 0.0, last_pathtrace_ms_ = 0.0;
     bool timing_pending_ = false;
     // majorant cache key

@@ -13,9 +13,20 @@ namespace vr {
 // sample order into the RGBA32F running mean `fb` (kernel 2; W*H texels, row 0 at the bottom).
 // tiles == nullptr: all tiles of the frame (n_tiles = their count).  sample_pool must hold
 // pathtrace_pool_floats(n_tiles, n_samples) floats; unit_counter is 8 device words (the work queue heads, one per XCD segment).  status[0] is set non-zero if a wavefront trips the watchdog.
-size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples);
+// Tuning state of ONE renderer (nothing about a launch is process-global: two renderers, on one device or two, never share it).
+struct PathtraceTuning {
+    // scheduler thresholds, indexed like LaneState (vr_trace.h): NEW (free slots that trigger a NEW batch), [1] diagnostic cap on the slots in use
+    // (0 = all), MARCH (= low-water mark of live paths: below it every non-empty batch runs), COLLIDE (lanes that must stand at a tentative
+    // collision before the collision code runs while others still march; 0 = per kernel), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
+    int32_t thr[8] = { 64, 0, 56, 0, 60, 60, 64, 0 };
+    unsigned long long* stats = nullptr;      // device buffer of 32 counters: the launch uses the instrumented (STATS) kernels; or null
+    int32_t samples_per_unit = 0;             // samples of a work unit; 0 = per kernel variant
+    int32_t blocks_per_cu = 0;                // resident workgroups per CU; 0 = from the occupancy query (cached per device)
+};
+PathtraceTuning default_tuning();             // the defaults, with the diagnostic overrides VR_SPU / VR_BLOCKS_PER_CU of the environment (read once)
+size_t pathtrace_pool_floats(const PathtraceTuning& T, int32_t n_tiles, int32_t n_samples);
 size_t pathtrace_workspace_floats();      // cold path state of all resident wavefronts
-void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
+void launch_pathtrace(const PathtraceTuning& T, const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math = false,
                       hipEvent_t ev_kernel_begin = nullptr, hipEvent_t ev_kernel_end = nullptr);      // optional: bracket the path-tracing kernel alone
 // fast_math: the opt-in tolerance-mode kernels (hardware transcendentals, reciprocal division; vr_math.h VR_FAST_MATH); the default

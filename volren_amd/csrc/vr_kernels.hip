@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "vr_device.h"
 #include "vr_pathtrace.h"
@@ -78,38 +80,29 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
     *texel = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
-// thr[]: NEW (free slots that trigger a NEW batch), diagnostic cap on the slots in use (0 = all NSLOT), MARCH (= low-water mark of live paths: below it every
-// non-empty batch runs), COLLIDE (= lanes that must stand at a tentative collision before the collision code runs while others still march), NEE, POSTNEE, ESCAPE (batch sizes that trigger the event)
-static SchedParams g_sched = { { 64, 0, 56, 0, 60, 60, 64, 0 }, 0u };       // COLLIDE 0 = per kernel (launch_pathtrace)
-static unsigned long long* g_stats = nullptr;      // device buffer of 26 counters, or null
-static int32_t g_samples_per_unit = 0;              // samples of a work unit; 0 = per kernel variant (samples_per_unit)
-static int32_t g_blocks_per_cu = 0;                 // 0 = from the occupancy query
-
-void set_stats_buffer(unsigned long long* dev) { g_stats = dev; }
-void set_samples_per_unit(int32_t n) { g_samples_per_unit = n < 1 ? 1 : n; }
 // Units of 8 samples x 64 pixels, except on the dense-grid kernel, whose long paths (128 bounces, every camera ray scatters) fill
 // the pools better from units of 4: c4 +1.3 %, c2 +-0, c3 -1 % (profiles/r2x_occupancy_recheck.txt)
 constexpr int32_t kMaxSamplesPerUnit = 8;
-static int32_t samples_per_unit(int variant) { return g_samples_per_unit > 0 ? g_samples_per_unit : (variant == 1 ? 4 : kMaxSamplesPerUnit); }
+static int32_t samples_per_unit(const PathtraceTuning& T, int variant) { return T.samples_per_unit > 0 ? T.samples_per_unit : (variant == 1 ? 4 : kMaxSamplesPerUnit); }
 
-void set_sched_thresholds(const int32_t thr[ST_COUNT]) {
-    for (int i = 0; i < ST_COUNT; ++i) g_sched.thr[i] = thr[i];
+PathtraceTuning default_tuning() {
+    static std::once_flag once;
+    static int32_t env_spu = 0, env_blocks = 0;       // diagnostics only
+    std::call_once(once, [] {
+        if (const char* e = getenv("VR_SPU")) env_spu = std::max(1, atoi(e));
+        if (const char* e = getenv("VR_BLOCKS_PER_CU")) env_blocks = std::max(0, atoi(e));
+    });
+    PathtraceTuning T;
+    T.samples_per_unit = env_spu;
+    T.blocks_per_cu = env_blocks;
+    return T;
 }
 
-static void tuning_from_env() {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    if (const char* e = getenv("VR_SPU")) set_samples_per_unit(atoi(e));      // diagnostics only
-    if (const char* e = getenv("VR_BLOCKS_PER_CU")) g_blocks_per_cu = atoi(e);
-}
-
-size_t pathtrace_pool_floats(int32_t n_tiles, int32_t n_samples) {
-    tuning_from_env();
+size_t pathtrace_pool_floats(const PathtraceTuning& T, int32_t n_tiles, int32_t n_samples) {
     // the samples are rounded up to whole units: sized for whichever unit size a variant may use (samples_per_unit)
     size_t padded = 0;
     for (int variant = 0; variant < 4; ++variant) {
-        const int32_t spu = std::min(n_samples, samples_per_unit(variant));
+        const int32_t spu = std::min(n_samples, samples_per_unit(T, variant));
         padded = std::max(padded, (size_t)((n_samples + spu - 1) / spu) * (size_t)spu);
     }
     return padded * (size_t)n_tiles * 4u * 64u * 4u;
@@ -133,29 +126,42 @@ static const PtLaunch kPtLaunch[2][4] = { { vr_pt_launch_0, vr_pt_launch_1, vr_p
 // which compiled variant serves a scene (see vr_pathtrace.hip)
 static int pathtrace_variant(const SceneParams& P) {
     if (P.u.integrator != 0) return 3;
-    if (P.u.has_emission) return 2;
+    if (P.u.has_emission) return (P.density.dense || P.emission.dense) ? 3 : 2;      // variant 2: both grids in brick form
     return P.density.dense ? 1 : 0;
 }
 
-static int resident_blocks(int mode, int variant, bool tf, bool stats) {
-    int dev = 0, cus = 0, per_cu = 0;
+// resident workgroups of a kernel instance on the CURRENT device: occupancy query x CU count, cached per (device, instance)
+static int resident_blocks(const PathtraceTuning& T, int mode, int variant, bool tf, bool stats) {
+    int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    per_cu = g_blocks_per_cu > 0 ? g_blocks_per_cu : kPtOccupancy[mode][variant](tf, stats);
-    return std::min(cus * per_cu, kMaxWorkgroups);
+    static std::mutex mu;
+    static std::map<uint32_t, std::pair<int, int>> cache;            // key -> (CUs, workgroups per CU)
+    const uint32_t key = ((uint32_t)dev << 8) | ((uint32_t)mode << 5) | ((uint32_t)variant << 2) | (tf ? 2u : 0u) | (stats ? 1u : 0u);
+    std::pair<int, int> v;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            it = cache.emplace(key, std::make_pair(cus, kPtOccupancy[mode][variant](tf, stats))).first;
+        }
+        v = it->second;
+    }
+    const int per_cu = T.blocks_per_cu > 0 ? T.blocks_per_cu : v.second;
+    return std::min(v.first * per_cu, kMaxWorkgroups);
 }
 
 size_t pathtrace_workspace_floats() { return kColdMainFloats + (size_t)kMaxWorkgroups * 4u * (size_t)kColdSideWaveFloats; }      // cold state of 4 wavefronts per resident workgroup: main slots, then the side array
 
-void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
+void launch_pathtrace(const PathtraceTuning& T, const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math, hipEvent_t ev_kernel_begin, hipEvent_t ev_kernel_end) {
     if (n_tiles <= 0 || n_samples <= 0) return;
-    tuning_from_env();
-    SchedParams S = g_sched;
+    SchedParams S;
+    for (int i = 0; i < ST_COUNT; ++i) S.thr[i] = T.thr[i];
     LaunchDesc D;
     D.tiles = tiles; D.n_tiles = n_tiles; D.first_sample = first_sample; D.n_samples = n_samples;
     const int variant = pathtrace_variant(P);
-    D.spu = std::min(n_samples, samples_per_unit(variant));
+    D.spu = std::min(n_samples, samples_per_unit(T, variant));
     const int32_t chunks = (n_samples + D.spu - 1) / D.spu;
     D.n_units = (uint32_t)chunks * (uint32_t)n_tiles * 4u;
     D.chunks = (uint32_t)chunks;
@@ -166,11 +172,9 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     // measured optimum 24 (smoke.brick +0.5 %, dense +0.7 %, sparse + emission +2...3.5 %), 32 with a transfer function, whose
     // collision code (8 corner taps + LUT) is the dearest (+4.4 %); profiles/r2ab_collide_threshold.txt
     if (S.thr[ST_COLLIDE] <= 0) S.thr[ST_COLLIDE] = P.u.use_tf ? 32 : 24;
-    const bool tf = P.u.use_tf != 0, stats = g_stats != nullptr;
+    const bool tf = P.u.use_tf != 0, stats = T.stats != nullptr;
     const int mode = fast_math ? 1 : 0;
-    static int blocks_cache[2][4][4] = {};
-    int& blocks = blocks_cache[mode][variant][(tf ? 2 : 0) + (stats ? 1 : 0)];
-    if (blocks == 0 || g_blocks_per_cu > 0) blocks = resident_blocks(mode, variant, tf, stats);
+    const int blocks = resident_blocks(T, mode, variant, tf, stats);
     const uint32_t waves_needed = (D.n_units + 3u) / 4u;
     const dim3 grid((unsigned)std::min<uint32_t>((uint32_t)blocks, waves_needed > 0 ? waves_needed : 1u)), block(256);
     if (P.u.integrator == 2 && P.u.use_tf) {
@@ -182,7 +186,7 @@ void launch_pathtrace(const SceneParams& P, float* fb, float* sample_pool, float
     } else {
         (void)hipMemsetAsync(unit_counter, 0, kQueueSegments * sizeof(uint32_t), stream);
         if (ev_kernel_begin) (void)hipEventRecord(ev_kernel_begin, stream);
-        kPtLaunch[mode][variant](tf, stats, grid.x, stream, &P, sample_pool, workspace, &D, &S, status, g_stats);
+        kPtLaunch[mode][variant](tf, stats, grid.x, stream, &P, sample_pool, workspace, &D, &S, status, T.stats);
         if (ev_kernel_end) (void)hipEventRecord(ev_kernel_end, stream);
     }
     hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)n_tiles), block, 0, stream, sample_pool, fb, tiles, n_tiles,

@@ -22,8 +22,9 @@
 
 // VR_FAST_MATH (device code of the opt-in tolerance-mode kernels only; vr_pathtrace.hip): the elementary functions map to
 // the gfx950 transcendental unit (v_log_f32, v_sin_f32, v_cos_f32, v_rcp_f32) and the compiler may contract and use
-// reciprocal-based division.  Results are no longer reproducible bit for bit on a host; they stay within the north star's
-// 1e-3 relative L2 of the bit-exact kernels (measured in bench.py and tests/test_gpu_parity.py).
+// reciprocal-based division.  Results are no longer reproducible bit for bit on a host.  Measured against the reference's kernels
+// at 64x48x1024 spp (tests/test_gpu_parity.py): within the north star's 1e-3 relative L2 without a transfer function, 1.9e-3
+// with one -- which is why RendererHIP::launch refuses the mode while a transfer function is bound.
 #if defined(VR_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
 #define VR_FAST_DEVICE 1
 #else

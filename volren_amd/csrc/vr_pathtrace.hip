@@ -2,8 +2,9 @@
 // build in parallel and each kernel only carries the code and registers of what its scenes use:
 //   0  DDA trackers, brick density grid, no emission grid      (BASELINE configs c1, c2, c3)
 //   1  DDA trackers, dense fp16 density grid, no emission grid (c4)
-//   2  DDA trackers, emission grid bound                       (c5; density bricks or dense, decided at run time)
-//   3  global-majorant trackers (common.glsl:333-394, the code the reference compiles out with USE_DDA); everything else at run time
+//   2  DDA trackers, brick density grid, emission grid bound   (c5)
+//   3  everything decided at run time: the global-majorant trackers (common.glsl:333-394, the code the reference compiles out with
+//      USE_DDA) and the one remaining combination, a dense fp16 density grid with an emission grid
 // Each is built twice: bit-exact arithmetic (the default and the parity target) and, with -DVR_FAST_MATH=1, the opt-in
 // tolerance mode (hardware transcendentals, reciprocal division, contraction; vr_math.h).  A compilation exports two C symbols,
 // vr_pt_occupancy_<variant>[_fast] and vr_pt_launch_<variant>[_fast], for {no TF, TF} x {plain, STATS}.
@@ -34,9 +35,9 @@ template <bool TF> using Cfg = TraceCfg<TF, 0, 0, 0>;
 #elif VR_PT_VARIANT == 1
 template <bool TF> using Cfg = TraceCfg<TF, 0, 0, 1>;
 #elif VR_PT_VARIANT == 2
-template <bool TF> using Cfg = TraceCfg<TF, 0, 1, 2>;
+template <bool TF> using Cfg = TraceCfg<TF, 0, 1, 0>;
 #else
-template <bool TF> using Cfg = TraceCfg<TF, 1, 2, 2>;
+template <bool TF> using Cfg = TraceCfg<TF, 2, 2, 2>;
 #endif
 
 typedef void (*PtKernel)(const KernelArgs);

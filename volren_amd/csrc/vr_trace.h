@@ -43,7 +43,11 @@ enum LaneState : int32_t {
 //   EMISSION  0: no emission grid bound (the 9 draws of lookup_emission are still consumed)  1: bound  2: run time
 //   DENSE     0: density grid = bricks  1: dense fp16 voxels  2: run time
 template <bool TF, int GLOBAL, int EMISSION, int DENSE>
-struct TraceCfg { static constexpr bool tf = TF; static constexpr int global = GLOBAL, emission = EMISSION, dense = DENSE; };
+struct TraceCfg {
+    static constexpr bool tf = TF;
+    static constexpr int global = GLOBAL, emission = EMISSION, dense = DENSE;
+    static constexpr int edense = EMISSION == 1 ? DENSE : 2;      // a kernel with a compiled-in emission grid takes it in the same form as the density grid
+};
 
 // the pool of work items of one wavefront: pixel p = item & 63 of the 8x8 tile at (px0, py0), sample
 // first_sample + (item >> 6) (1-based like the reference's current_sample)
@@ -872,7 +876,7 @@ VR_HD void collide_prep(Hot& h, const SceneParams& P, CollideIO<K>& io) {
             const v3 ie = mat4_point(P.emission_from_density, ip);
             int32_t ex, ey, ez;
             tricubic_tap(ie, h.seed, ex, ey, ez);
-            io.ea = tap_addr<2>(P.emission, ex, ey, ez);
+            io.ea = tap_addr<K::edense>(P.emission, ex, ey, ez);
         } else {
             rng_skip9(h.seed);
         }
@@ -888,7 +892,7 @@ template <class K>
 VR_HD void collide_load(const SceneParams& P, CollideIO<K>& io) {      // unconditional, like march_load
     if (K::tf) trilinear_load<K::dense>(P.density, io.tri);
     else io.d = tap_load<K::dense>(P.density, io.a);
-    if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) io.ed = tap_load<2>(P.emission, io.ea);
+    if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) io.ed = tap_load<K::edense>(P.emission, io.ea);
 }
 // CACHED: throughput and radiance of the marching path are in h.ethr / h.eL (device scheduler, see Hot); otherwise on the cold line
 template <class K, class Cold, bool CACHED = false>
@@ -908,7 +912,7 @@ VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO
         const float P_real = d * u.vol_inv_majorant;                 // global trackers only
         if (K::emission == 2 ? u.has_emission != 0 : K::emission == 1) {
             // Le += throughput * (1 - albedo) * lookup_emission(...) * d * vol_inv_majorant
-            const float tt = tap_value<2>(P.emission, io.ed, io.ea.in) * u.vol_emission_norm;
+            const float tt = tap_value<K::edense>(P.emission, io.ed, io.ea.in) * u.vol_emission_norm;
             const v3 e3 = v3{ tt, sqr(tt), sqr(sqr(tt)) };
             const v3 em = v3{ u.vol_emission_scale * sqr(e3.x), u.vol_emission_scale * sqr(e3.y), u.vol_emission_scale * sqr(e3.z) };
             const v3 oma = v3{ 1.0f - u.vol_albedo[0], 1.0f - u.vol_albedo[1], 1.0f - u.vol_albedo[2] };

@@ -224,6 +224,26 @@ class Renderer:
         _lib.check(self._L.vr_get_uniforms(self._h, buf, n))
         return bytes(buf)
 
+    def set_sched(self, thresholds):
+        """Scheduler thresholds of THIS renderer's launches (8 ints: vr::PathtraceTuning::thr, csrc/vr_device.h)."""
+        t = np.ascontiguousarray(thresholds, np.int32)
+        assert t.size == 8
+        _lib.check(self._L.vr_set_sched(self._h, t.ctypes.data))
+
+    def sched_stats(self, enable=True, read=False):
+        """Scheduler diagnostics of this renderer's path-tracing launches. Returns {state: (executions, active_lanes)} when read."""
+        out = np.zeros(32, np.uint64) if read else None
+        _lib.check(self._L.vr_sched_stats(self._h, 1 if enable else 0, out.ctypes.data if read else None))
+        if not read:
+            return None
+        d = {n: (int(out[2 * i]), int(out[2 * i + 1])) for i, n in enumerate(STATE_NAMES)}
+        d["iterations"] = int(out[16])
+        d["waves"] = int(out[17])
+        d["cycles"] = {n: int(out[18 + i]) for i, n in enumerate(STATE_NAMES)}     # shader-clock ticks inside each state's block
+        d["wave_cycles"] = int(out[25])                                            # summed lifetime of all wavefronts
+        d["occupancy"] = {n: int(out[26 + i]) / max(1, int(out[16])) for i, n in enumerate(("marching", "ready", "nee", "postnee", "escape", "free"))}
+        return d
+
     def grid_checksums(self):
         out = (C.c_uint64 * 3)()
         _lib.check(self._L.vr_grid_checksums(self._h, out))
@@ -236,12 +256,6 @@ class Renderer:
         return out
 
 
-def set_sched(thresholds):
-    t = np.ascontiguousarray(thresholds, np.int32)
-    assert t.size == 8
-    _lib.check(_lib.load().vr_set_sched(t.ctypes.data))
-
-
 def math_probe(fn, a, b=None):
     a = _f32(a).reshape(-1)
     b = _f32(b).reshape(-1) if b is not None else np.zeros_like(a)
@@ -251,18 +265,3 @@ def math_probe(fn, a, b=None):
 
 
 STATE_NAMES = ("new", "begin", "march", "collide", "nee", "postnee", "escape")
-
-
-def sched_stats(enable=True, read=False):
-    """Scheduler diagnostics of the path-tracing kernel. Returns {state: (executions, active_lanes)} when read."""
-    out = np.zeros(32, np.uint64) if read else None
-    _lib.check(_lib.load().vr_sched_stats(1 if enable else 0, out.ctypes.data if read else None))
-    if not read:
-        return None
-    d = {n: (int(out[2 * i]), int(out[2 * i + 1])) for i, n in enumerate(STATE_NAMES)}
-    d["iterations"] = int(out[16])
-    d["waves"] = int(out[17])
-    d["cycles"] = {n: int(out[18 + i]) for i, n in enumerate(STATE_NAMES)}     # s_memtime ticks inside each state's block
-    d["wave_cycles"] = int(out[25])
-    d["occupancy"] = {n: int(out[26 + i]) / max(1, int(out[16])) for i, n in enumerate(("marching", "ready", "nee", "postnee", "escape", "free"))}                                             # summed lifetime of all wavefronts
-    return d
