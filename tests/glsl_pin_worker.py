@@ -209,6 +209,14 @@ def main():
                 o.set_envmap(np.ones((1, 1, 3), np.float32))
         o.integrator = m.get("integrator", 0)
         res["r2"][name] = image_metrics(G2[name], o.render(m["spp"]))
+    # round-3 goldens: the scenes pinned so far only with the specification's log / acos / atan spliced in, rendered from the reference's
+    # UNMODIFIED kernel text (the driver's built-ins), 8 and 1024 spp (make_golden_glsl.py --r3)
+    G3 = np.load(os.path.join(HERE, "golden", "glsl_golden_r3.npz"))
+    M3 = json.load(open(os.path.join(HERE, "golden", "glsl_golden_r3.json")))
+    res["r3"] = {}
+    for name, m in M3["images"].items():
+        o = emission_scene(W, H) if m["config"] == "emission" else scenes.oracle_scene(m["config"], W, H)
+        res["r3"][name] = image_metrics(G3[name], o.render(m["spp"]))
     print(json.dumps(res))
 
 

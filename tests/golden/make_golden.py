@@ -5,6 +5,9 @@
 
 * example_64.npy      -- the reference's only output artefact, imgs/example.jpg (README.md:72-77),
                          box-downsampled to 64x64 RGB uint8.  Data, not source.
+* example_256.npy     -- the same image box-downsampled 4x4 to 256x256 RGB uint8 (round 3): the size at which a wrong field of view,
+                         camera matrix, unit-cube placement or environment rotation shows (tests/test_gpu_parity.py renders the
+                         README command on the GPU at the reference's 1024x1024 x 4096 spp and compares).
 * known_answers.json  -- structural known-answers on the reference's data files,
                          recomputed here with numpy directly from the files (not through the oracle).
 """
@@ -73,6 +76,8 @@ def main():
     json.dump(ka, open(os.path.join(HERE, "known_answers.json"), "w"), indent=1)
     ex = Image.open(os.path.join(REF, "imgs/example.jpg")).convert("RGB").resize((64, 64), Image.BOX)
     np.save(os.path.join(HERE, "example_64.npy"), np.asarray(ex, np.uint8))
+    ex256 = Image.open(os.path.join(REF, "imgs/example.jpg")).convert("RGB").resize((256, 256), Image.BOX)
+    np.save(os.path.join(HERE, "example_256.npy"), np.asarray(ex256, np.uint8))
     print("golden fixtures written")
 
 

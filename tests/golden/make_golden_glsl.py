@@ -156,8 +156,37 @@ def main_r2():
     print("wrote glsl_golden_r2.npz (%d arrays)" % len(out))
 
 
+R3_IMAGES = {      # name -> config: the reference's kernel text AS IT STANDS (no spec_math splice), the driver's log / acos / atan
+    "c3_tf_driver": "c3",            # shader/pathtracer_brick_tf.glsl
+    "c1_hdr_driver": "c1",
+    "readme_hdr_driver": "readme",
+    "emission_driver": None,          # emission_scene(): common.glsl:314-328
+}
+
+
+def main_r3():
+    """Round-3 additions, written to glsl_golden_r3.npz (the earlier files stay byte-identical): the scenes that rounds 1-2 pinned
+    only with the specification's log/acos/atan spliced into the reference's text, now rendered from the UNMODIFIED kernel text
+    (only binding._portable's one NVIDIA-only `bvec || bvec` rewrite, without which Mesa does not compile it), at 8 and 1024 spp."""
+    out = {}
+    meta = {"width": W, "height": H, "spp": SPP, "hi_spp": HI_SPP, "images": {}}
+    for name, cfg in R3_IMAGES.items():
+        for tag, spp in (("img_", SPP), ("hi_", HI_SPP)):
+            o = emission_scene(W, H) if cfg is None else scenes.oracle_scene(cfg, W, H)
+            g = gb.GLSLReference(o, spec_math=False)
+            meta["gl"] = g.info
+            out[tag + name] = g.render(spp)
+            meta["images"][tag + name] = dict(config=cfg or "emission", white_env=False, spec_math=False, spp=spp)
+            print(tag + name, "done", flush=True)
+    np.savez_compressed(os.path.join(HERE, "glsl_golden_r3.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "glsl_golden_r3.json"), "w"), indent=1)
+    print("wrote glsl_golden_r3.npz (%d arrays)" % len(out))
+
+
 if __name__ == "__main__":
-    if "--r2" in sys.argv:
+    if "--r3" in sys.argv:
+        main_r3()
+    elif "--r2" in sys.argv:
         main_r2()
     else:
         main()

@@ -110,6 +110,25 @@ def test_north_star_tolerance_at_1024_spp(standard, unfused):
     assert standard["r2"]["hi_c2_hdr_driver"]["rel_l2"] <= 2e-3, standard["r2"]["hi_c2_hdr_driver"]      # the driver's own acos/atan: 2e-4 relative
 
 
+def test_unmodified_kernel_text(standard, unfused):
+    """Round 3 (glsl_golden_r3.npz): the transfer-function kernel (pathtracer_brick_tf.glsl), config c1, the README scene and the
+    emission path rendered from the reference's kernel text AS IT STANDS -- the driver's log / acos / atan instead of the
+    specification's spliced in.  llvmpipe's acos / atan are 2e-4 / 2e-5 relative, which is what the environment lookups of the three
+    HDR scenes then differ by (measured 3.4e-4 ... 4.4e-4, at 8 and at 1024 spp alike: a systematic offset, not noise); the
+    transfer-function scene (no environment lookups: show_environment = 0) agrees to 7e-6.  At 1024 spp every image is inside the
+    north star's 1e-3, for the build without multiply-add fusion and for the standard oracle, which the HIP kernels equal bit for bit."""
+    for res in (standard, unfused):
+        for name in ("hi_c3_tf_driver", "hi_c1_hdr_driver", "hi_readme_hdr_driver", "hi_emission_driver"):
+            assert res["r3"][name]["rel_l2"] <= 1e-3, (name, res["r3"][name])
+    u = unfused["r3"]
+    assert u["img_c3_tf_driver"]["rel_l2"] < 5e-5 and u["img_c3_tf_driver"]["within_1e5"] > 0.98, u["img_c3_tf_driver"]
+    for name in ("img_c1_hdr_driver", "img_readme_hdr_driver", "img_emission_driver"):
+        assert u[name]["rel_l2"] < 1e-3 and u[name]["within_1e3"] > 0.9 and abs(u[name]["mean_ratio"] - 1.0) < 5e-4, (name, u[name])
+    s = standard["r3"]
+    for name in ("img_c3_tf_driver", "img_c1_hdr_driver", "img_readme_hdr_driver", "img_emission_driver"):
+        assert s[name]["within_1e3"] > 0.9 and s[name]["rel_l2"] < 5e-2 and abs(s[name]["mean_ratio"] - 1.0) < 1e-3, (name, s[name])      # 8 spp: a flipped path is a pixel
+
+
 def test_raymarch_trackers_reproduce_reference_text(standard, unfused):
     """trace_path with sample_volume_raymarch / transmittance_raymarch (common.glsl:506-566, integrator 3) against the
     reference's text run on llvmpipe."""
