@@ -29,6 +29,20 @@ def test_tile_ownership_is_a_partition():
             assert sorted(t for t in s.unpack_ids if t >= 0) == flat
 
 
+def test_hashed_deal_is_a_balanced_partition():
+    """The alternative tile deal (tiles in the order of a hash of their id, dealt round robin): a partition with counts within one.
+    Measured load balance (profiles/r3_rank_balance.txt): diagonal max/mean <= 1.021, hashed 1.05-1.06 -- the diagonal deal is the default."""
+    for w, h in ((1024, 1024), (1920, 1080), (70, 52)):
+        tx, ty = (w + 15) // 16, (h + 15) // 16
+        for n in (2, 4, 8):
+            lists = tile_owner_lists(w, h, n, "hashed")
+            assert sorted(sum(lists, [])) == list(range(tx * ty))
+            sizes = [len(t) for t in lists]
+            assert max(sizes) - min(sizes) <= 1
+            s = TileShard(w, h, n, 0, scheme="hashed")
+            assert sorted(t for t in s.unpack_ids if t >= 0) == list(range(tx * ty))
+
+
 def test_pack_unpack_roundtrip():
     rs = np.random.RandomState(0)
     fb = rs.rand(H, W, 4).astype(np.float32)

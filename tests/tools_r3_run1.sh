@@ -1,3 +1,3 @@
 set -o pipefail
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -s -k "readme_command or unmodified_reference or 1e3_of_reference or tuning_state" > gpurun_out/r3j_tests.log 2>&1; echo "pytest rc $?"
-grep -E "PSNR|passed|failed|Error|assert" gpurun_out/r3j_tests.log | head -20
+( python tests/tools_rank_balance.py c2 1024 1024 1024; python tests/tools_rank_balance.py c4 1920 1080 4096; python tests/tools_rank_balance.py c5full 2048 2048 4096 ) 2>&1 | grep -v "^/opt\|Preparing\|load volume" > gpurun_out/r3k_rank_balance.txt
+cat gpurun_out/r3k_rank_balance.txt

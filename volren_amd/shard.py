@@ -20,10 +20,31 @@ def tile_grid(w, h):
     return (w + TILE - 1) // TILE, (h + TILE - 1) // TILE
 
 
-def tile_owner_lists(w, h, n_ranks):
-    """Raster tile ids (row 0 = bottom, like the framebuffer) owned by each rank."""
+def _hash32(i):
+    """Avalanching 32-bit integer hash (the finaliser of MurmurHash3)."""
+    i = (int(i) + 0x9E3779B9) & 0xFFFFFFFF
+    i = ((i ^ (i >> 16)) * 0x85EBCA6B) & 0xFFFFFFFF
+    i = ((i ^ (i >> 13)) * 0xC2B2AE35) & 0xFFFFFFFF
+    return i ^ (i >> 16)
+
+
+DEFAULT_SCHEME = "diagonal"
+
+
+def tile_owner_lists(w, h, n_ranks, scheme=None):
+    """Raster tile ids (row 0 = bottom, like the framebuffer) owned by each rank.
+    scheme "diagonal": owner(tx, ty) = (tx + ty) mod N.  "hashed": the tiles in the order of a 32-bit hash of their id, dealt round
+    robin (counts differ by at most one; no correlation with any direction of the image)."""
+    scheme = scheme or DEFAULT_SCHEME
     tiles_x, tiles_y = tile_grid(w, h)
     lists = [[] for _ in range(n_ranks)]
+    if scheme == "hashed":
+        order = sorted(range(tiles_x * tiles_y), key=lambda t: (_hash32(t), t))
+        for i, t in enumerate(order):
+            lists[i % n_ranks].append(t)
+        return [sorted(t) for t in lists]
+    if scheme != "diagonal":
+        raise ValueError("unknown tile deal %r" % scheme)
     for ty in range(tiles_y):
         for tx in range(tiles_x):
             lists[(tx + ty) % n_ranks].append(ty * tiles_x + tx)
@@ -33,9 +54,9 @@ def tile_owner_lists(w, h, n_ranks):
 class TileShard:
     """Tile ownership of one rank plus the padded layouts the all_gather needs."""
 
-    def __init__(self, w, h, world, rank):
+    def __init__(self, w, h, world, rank, scheme=None):
         self.w, self.h, self.world, self.rank = int(w), int(h), int(world), int(rank)
-        self.lists = tile_owner_lists(w, h, world)
+        self.lists = tile_owner_lists(w, h, world, scheme)
         self.mine = self.lists[rank]
         self.n_max = max(1, max(len(t) for t in self.lists))
         # pack list: own tiles, padded by repeating the last one (any valid tile; the slot is ignored on unpack)
