@@ -26,16 +26,14 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
     g.view.maj_blocked = blocked ? 1 : 0;
     const size_t n = (size_t)nb[0] * nb[1] * nb[2];
     const uint32_t sx = ad[0] / 8, sy = ad[1] / 8, sz = ad[2] / 8;
-    for (int i = 0; i < 2; ++i) g.view.bshift[i] = ceil_log2(nb[i]);
     for (int i = 0; i < 3; ++i) { g.view.mshift[i] = ceil_log2(nb[i]) < 3 ? 3 : ceil_log2(nb[i]); g.view.mlim[i] = (float)(8u << g.view.mshift[i]); }
-    g.recs.assign((size_t)nb[2] << (g.view.bshift[0] + g.view.bshift[1]), BrickRec{ 0u, 0.f, 0.f, 0u });
+    g.recs.assign(n, BrickRec{ 0u, 0.f, 0.f, 0u });
     g.atlas.assign(g.recs.size() * 512, 0);                                 // brick-linear blocks == brick_grid_to_device
     for (size_t i = 0; i < n; ++i) {
         const uint32_t ind = indirection[i], rg = range[i];
         const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
         const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
-        const size_t bx = i % nb[0], by = (i / nb[0]) % nb[1], bz = i / ((size_t)nb[0] * nb[1]);
-        const size_t idx = (((bz << g.view.bshift[1]) + by) << g.view.bshift[0]) + bx;
+        const size_t idx = i;
         BrickRec& r = g.recs[idx];
         r.slot = (uint32_t)idx; r.rmin = lo; r.rdiff = hi - lo; r.range = rg;
         if (r.rdiff != 0.f && px < sx && py < sy && pz < sz)

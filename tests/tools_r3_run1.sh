@@ -1,3 +1,5 @@
 set -o pipefail
-( python tests/tools_rank_balance.py c2 1024 1024 1024; python tests/tools_rank_balance.py c4 1920 1080 4096; python tests/tools_rank_balance.py c5full 2048 2048 4096 ) 2>&1 | grep -v "^/opt\|Preparing\|load volume" > gpurun_out/r3k_rank_balance.txt
-cat gpurun_out/r3k_rank_balance.txt
+python -m pytest tests -x -q -m gpu > gpurun_out/r3l_tests.log 2>&1; rc=$?; echo "pytest rc $rc"; tail -3 gpurun_out/r3l_tests.log
+[ $rc = 0 ] || exit $rc
+AB_CASES="c2:1024:256 c3:1024:256 c5full:2048:64" bash tests/tools_ab.sh default coldmem > gpurun_out/r3l_ab.log 2>&1
+cat gpurun_out/r3l_ab.log

@@ -87,17 +87,29 @@ BrickGridHIP RendererHIP::grid_to_device(const Volume::GridPtr& grid) {
     return brick_grid_to_device(Volume::to_brick_grid(grid));
 }
 
-// power-of-two pitches of the brick records and of the majorant levels (vr_scene.h)
+// HBM a grid may take on the device before the upload is refused with a clear message instead of an out-of-memory error from deep inside
+// (the brick-linear atlas is 512 bytes per brick of the grid's BOX, allocated or not: 1 GiB for 1024^3 voxels; the decoded float atlas of
+// a transfer-function render is four times that).  Default: what the device reports free, less a reserve for framebuffers and pools.
+static void check_grid_bytes(size_t bytes, const char* what, const int32_t nb[3]) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    const size_t reserve = (size_t)1 << 30;
+    if (bytes + reserve > free_b)
+        throw std::runtime_error(std::string("grid upload: ") + what + " of a grid of " + std::to_string(nb[0]) + " x " + std::to_string(nb[1]) + " x " + std::to_string(nb[2]) +
+                                 " bricks needs " + std::to_string(bytes >> 20) + " MiB of device memory, " + std::to_string(free_b >> 20) + " MiB are free");
+}
+// padded power-of-two extent of the majorant levels (vr_scene.h); brick records and atlas blocks have exact pitches
 static void set_layout(BrickGridHIP& out) {
-    for (int i = 0; i < 2; ++i) out.bshift[i] = ceil_log2((uint32_t)out.nb[i]);
     for (int i = 0; i < 3; ++i) out.mshift[i] = std::max(3, ceil_log2((uint32_t)out.nb[i]));
-    if (out.mshift[0] + out.mshift[1] + out.mshift[2] > 30 || out.bshift[0] + out.bshift[1] + ceil_log2((uint32_t)out.nb[2]) > 30)
-        throw std::runtime_error("grid upload: more than 2^30 bricks after padding");
+    if (out.mshift[0] + out.mshift[1] + out.mshift[2] > 30 || (uint64_t)out.nb[0] * out.nb[1] * out.nb[2] > (1ull << 30))
+        throw std::runtime_error("grid upload: more than 2^30 bricks");
+    if ((uint64_t)out.nb[1] * out.nb[2] >= (1ull << 24) || out.nb[0] >= (1 << 24))
+        throw std::runtime_error("grid upload: brick counts beyond the 24-bit index arithmetic of the kernels (n_bricks.y * n_bricks.z < 2^24)");
     const size_t cells = majorant_padded_cells((uint32_t)(out.mshift[0] + out.mshift[1] + out.mshift[2]));
     out.majorant = make_device_buffer(cells * sizeof(float));
     out.majorant16 = make_device_buffer(cells * sizeof(uint16_t));
 }
-static size_t padded_brick_records(const BrickGridHIP& g) { return (size_t)g.nb[2] << (g.bshift[0] + g.bshift[1]); }
+static size_t brick_records(const BrickGridHIP& g) { return (size_t)g.nb[0] * g.nb[1] * g.nb[2]; }
 
 static void upload_range_words(BrickGridHIP& out, const uvec3 nb, const Buf3D<uint32_t>& range, const std::vector<Buf3D<uint32_t>>& mips) {
     if (mips.size() > 3) throw std::runtime_error("grid upload: at most 3 range mips are supported");
@@ -143,13 +155,14 @@ BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseG
     uint32_t* words = out.range_words->as<uint32_t>();
     launch_encode_ranges(dense.as<float>(), dim, nb, words, flag.as<uint32_t>(), stream);
     VR_HIP(hipGetLastError());
-    out.atlas = make_device_buffer(padded_brick_records(out) * 512);        // brick-linear blocks (see brick_grid_to_device)
+    check_grid_bytes(brick_records(out) * (512 + sizeof(BrickRec) + 8), "the brick-linear atlas", out.nb);
+    out.atlas = make_device_buffer(brick_records(out) * 512);               // brick-linear blocks (see brick_grid_to_device)
     VR_HIP(hipMemsetAsync(out.atlas->get(), 0, out.atlas->size_bytes(), stream));
-    out.bricks = make_device_buffer(padded_brick_records(out) * sizeof(BrickRec));
+    out.bricks = make_device_buffer(brick_records(out) * sizeof(BrickRec));
     VR_HIP(hipMemsetAsync(out.bricks->get(), 0, out.bricks->size_bytes(), stream));
-    out.rng = make_device_buffer(padded_brick_records(out) * 2 * sizeof(float));
+    out.rng = make_device_buffer(brick_records(out) * 2 * sizeof(float));
     VR_HIP(hipMemsetAsync(out.rng->get(), 0, out.rng->size_bytes(), stream));
-    launch_encode_bricks(dense.as<float>(), dim, nb, out.bshift, words, flag.as<uint32_t>(), out.bricks->as<BrickRec>(), out.rng->as<float>(), out.atlas->as<uint8_t>(), stream);
+    launch_encode_bricks(dense.as<float>(), dim, nb, words, flag.as<uint32_t>(), out.bricks->as<BrickRec>(), out.rng->as<float>(), out.atlas->as<uint8_t>(), stream);
     for (int m = 1; m <= 3; ++m) launch_range_mip(words + out.mip_off[m - 1], mdim[m - 1], words + out.mip_off[m], mdim[m], stream);
     VR_HIP(hipGetLastError());
     VR_HIP(hipStreamSynchronize(stream));
@@ -208,15 +221,15 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
     // voxels never matter: rmin + u * 0), and so does a pointer outside the atlas (GL: undefined fetch).
     const uvec3 ad = g->atlas.stride;
     const uint32_t sx = ad.x / 8, sy = ad.y / 8, sz = ad.z / 8;
-    upload_range_words(out, nb, g->range, g->range_mipmaps);        // also fixes the padded layout (bshift, mshift)
-    std::vector<BrickRec> recs(padded_brick_records(out), BrickRec{ 0u, 0.f, 0.f, 0u });
+    upload_range_words(out, nb, g->range, g->range_mipmaps);        // also fixes the padded majorant layout (mshift)
+    check_grid_bytes(brick_records(out) * (512 + sizeof(BrickRec) + 8), "the brick-linear atlas", out.nb);
+    std::vector<BrickRec> recs(brick_records(out), BrickRec{ 0u, 0.f, 0.f, 0u });
     std::vector<uint8_t> atlas(recs.size() * 512, 0);
     for (size_t i = 0; i < n_bricks; ++i) {
         const uint32_t ind = g->indirection.data[i], rg = g->range.data[i];
         const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
         const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
-        const size_t bx = i % nb.x, by = (i / nb.x) % nb.y, bz = i / ((size_t)nb.x * nb.y);
-        const size_t idx = (((bz << out.bshift[1]) + by) << out.bshift[0]) + bx;
+        const size_t idx = i;                                        // record index = linear brick index (x fastest)
         BrickRec r;
         r.slot = (uint32_t)idx;
         r.rmin = lo;
@@ -273,7 +286,6 @@ static GridView make_view(const BrickGridHIP& g) {
     v.rng = g.rng ? g.rng->as<float>() : nullptr;
     v.atlas_f32 = g.atlas_f32 ? g.atlas_f32->as<float>() : nullptr;
     for (int i = 0; i < 3; ++i) v.nb[i] = g.nb[i];
-    for (int i = 0; i < 2; ++i) v.bshift[i] = g.bshift[i];
     for (int i = 0; i < 3; ++i) { v.mshift[i] = g.mshift[i]; v.mlim[i] = (float)(8u << g.mshift[i]); }
     v.n_mips = g.n_mips;
     v.maj_blocked = VR_MAJORANT_BLOCKED;        // build-time experiment (vr_scene.h), off
@@ -393,6 +405,8 @@ void RendererHIP::launch(int n) {
         BrickGridHIP& g = density_grids.at(volume->grid_frame_counter);
         if (transferfunc && tf_float_atlas && !g.dense && g.atlas && g.rng && !g.atlas_f32 && !g.atlas_f32_failed) {
             try {
+                for (BrickGridHIP& other : density_grids)               // one decoded atlas at a time: an animation does not keep 4x the atlas per rendered frame
+                    if (&other != &g) other.atlas_f32.reset();
                 g.atlas_f32 = make_device_buffer(g.atlas->size_bytes() * sizeof(float));
                 launch_decode_atlas(g.rng->as<float>(), g.atlas->as<uint8_t>(), g.atlas_f32->as<float>(), g.atlas->size_bytes() / 512, stream);
                 VR_HIP(hipGetLastError());

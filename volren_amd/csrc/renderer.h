@@ -47,8 +47,7 @@ struct BrickGridHIP {
     int32_t mip_off[4] = { 0, 0, 0, 0 };   // word offset of each level inside range_words (compact)
     int32_t n_mips = 0;
     int32_t n_cells = 0;                   // words in range_words
-    int32_t bshift[2] = { 0, 0 };          // power-of-two pitches of `bricks` and padded extent of `majorant` (vr_scene.h)
-    int32_t mshift[3] = { 3, 3, 3 };
+    int32_t mshift[3] = { 3, 3, 3 };       // padded power-of-two extent of `majorant` (vr_scene.h)
     mat4 transform;
 };
 

@@ -47,7 +47,7 @@ void launch_majorants(const SceneParams& P, const uint32_t* range_words_all_mips
 // Dense -> brick encoder on the device (Volume::to_brick_grid / commit(), src/renderer.cpp:63); see vr_kernels.hip.
 // ranges: range[nb] (fp16x2 words), flag[nb] (range is not a single value: the voxels matter)
 void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_t nb[3], uint32_t* range, uint32_t* flag, hipStream_t stream);
-void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const int32_t bshift[2], const uint32_t* range, const uint32_t* flag,
+void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const uint32_t* range, const uint32_t* flag,
                           BrickRec* recs, float* rng, uint8_t* atlas, hipStream_t stream);      // rng: compact (rmin, rdiff) pairs, same index as recs
 void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream);
 

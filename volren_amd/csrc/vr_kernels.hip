@@ -298,7 +298,7 @@ encode_range_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int
     }
 }
 __global__ void __launch_bounds__(64)
-encode_brick_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int32_t nz, int32_t nbx, int32_t nby, int32_t bsx, int32_t bsy,
+encode_brick_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int32_t nz, int32_t nbx, int32_t nby,
                     const uint32_t* __restrict__ range, const uint32_t* __restrict__ flag,
                     BrickRec* __restrict__ recs, float* __restrict__ rng, uint8_t* __restrict__ atlas) {
     const int32_t brick = blockIdx.x, lane = threadIdx.x;
@@ -306,7 +306,7 @@ encode_brick_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int
     const uint32_t rg = range[brick];
     const float lo = half2float(rg & 0xFFFFu), hi = half2float(rg >> 16);
     const bool alloc = flag[brick] != 0u;                    // a brick whose range is one value keeps its zeroed block
-    const size_t idx = ((((size_t)bz << bsy) + by) << bsx) + bx;      // brick-linear atlas: block index = record index
+    const size_t idx = ((size_t)bz * nby + by) * nbx + bx;            // brick-linear atlas: block index = record index = linear brick index
     if (lane == 0) { BrickRec r; r.slot = (uint32_t)idx; r.rmin = lo; r.rdiff = hi - lo; r.range = rg; recs[idx] = r; rng[2 * idx] = r.rmin; rng[2 * idx + 1] = r.rdiff; }
     if (!alloc) return;
     const float inv = 255.0f / (hi - lo);
@@ -341,10 +341,10 @@ void launch_encode_ranges(const float* dense, const int32_t dim[3], const int32_
     const int32_t n = nb[0] * nb[1] * nb[2];
     hipLaunchKernelGGL(encode_range_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], nb[2], range, flag);
 }
-void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const int32_t bshift[2], const uint32_t* range, const uint32_t* flag,
+void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_t nb[3], const uint32_t* range, const uint32_t* flag,
                           BrickRec* recs, float* rng, uint8_t* atlas, hipStream_t stream) {
     const int32_t n = nb[0] * nb[1] * nb[2];
-    hipLaunchKernelGGL(encode_brick_kernel, dim3(n), dim3(64), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], bshift[0], bshift[1], range, flag, recs, rng, atlas);
+    hipLaunchKernelGGL(encode_brick_kernel, dim3(n), dim3(64), 0, stream, dense, dim[0], dim[1], dim[2], nb[0], nb[1], range, flag, recs, rng, atlas);
 }
 void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream) {
     const int32_t n = ddim[0] * ddim[1] * ddim[2];

@@ -21,9 +21,10 @@ struct alignas(16) BrickRec { uint32_t slot; float rmin; float rdiff; uint32_t r
 #define VR_SCENE_HD inline
 #endif
 
-// Index arithmetic of the hot loops is shifts only: brick records and majorant cells are stored with power-of-two
-// pitches.
-//   brick record of brick (bx, by, bz):  (((bz << bshift[1]) + by) << bshift[0]) + bx,  2^bshift[i] >= nb[i]
+// Index arithmetic of the hot loops is shifts and 24-bit multiply-adds only (one instruction each on gfx950): brick records -- and with
+// them the 512-byte atlas blocks -- are stored with their EXACT pitches (a grid of 130^3 bricks takes 130^3 blocks, not the 256 x 256 x 130
+// that power-of-two pitches cost in round 2), majorant cells with power-of-two pitches.
+//   brick record of brick (bx, by, bz):  (bz * nb[1] + by) * nb[0] + bx  as two v_mad_u32_u24 (nb[1] * nb[2] < 2^24, checked at upload)
 //   majorant of cell (cx, cy, cz) of mip m:  level_offset(m) + (((cz << (mshift[1] - m)) + cy) << (mshift[0] - m)) + cx,
 //     level 0 has 2^mshift[i] >= max(nb[i], 8) cells per axis, every level half of that; cells beyond the real
 //     ceil(nb / 2^m) hold 0 (= "outside the grid reads 0"), so the whole padded extent may be indexed
@@ -95,7 +96,7 @@ VR_SCENE_HD size_t env_cdf_table_floats(int32_t top) {
 }
 
 struct GridView {
-    const BrickRec* bricks;      // nb[2] << (bshift[0] + bshift[1]) records, power-of-two pitches (see above)
+    const BrickRec* bricks;      // nb[0] * nb[1] * nb[2] records, x fastest (see above)
     const uint8_t* atlas;        // one 512-byte block per brick record (same index), voxel (x&7) + 8*(y&7) + 64*(z&7)
     const float* majorant;       // all mips, padded (see above): "effective" majorant = density_scale * range.y, TF-remapped when a LUT is bound
     const uint16_t* majorant16;  // the same cells as raw fp16 range.y (0 outside): what the kernels WITHOUT a transfer function read --
@@ -104,7 +105,6 @@ struct GridView {
                                  // renders -- their 8 corner taps then cost one 4-byte load each instead of record + byte; nullptr otherwise
     const float* rng;            // (rmin, rdiff) per brick record, 8 bytes, same padded index as `bricks`: the part of a record a tap needs
     int32_t nb[3];               // bricks per axis (mip 0); mip m has ceil(nb / 2^m) cells per axis
-    int32_t bshift[2];           // log2 of the brick-record pitches (x, y)
     int32_t mshift[3];           // log2 of the padded level-0 majorant extent per axis (each >= 3)
     float mlim[3];               // the same extent in voxels, (float)(8 << mshift[i]): the inside test of the DDA compares against it
     int32_t n_mips;              // range mips available above level 0 (reference: 3)

@@ -167,7 +167,7 @@ VR_HD TapAddr tap_addr(const GridView& g, int32_t x, int32_t y, int32_t z) {
     } else {
         const uint32_t bx = (uint32_t)x >> 3, by = (uint32_t)y >> 3, bz = (uint32_t)z >> 3;
         a.in = nonneg && bx < (uint32_t)g.nb[0] && by < (uint32_t)g.nb[1] && bz < (uint32_t)g.nb[2];
-        a.cell = (((bz << g.bshift[1]) + by) << g.bshift[0]) + bx;
+        a.cell = mul24(mul24(bz, (uint32_t)g.nb[1]) + by, (uint32_t)g.nb[0]) + bx;      // two v_mad_u32_u24
         a.off = (((uint32_t)z & 7u) << 6) | (((uint32_t)y & 7u) << 3) | ((uint32_t)x & 7u);
     }
     if (!a.in) { a.cell = 0u; a.off = 0u; }       // the loads are unconditional: an outside tap reads cell 0 and is discarded
@@ -269,7 +269,7 @@ VR_HD void trilinear_prep(const GridView& g, v3 ipos, TriIO& io) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint32_t row = dense ? (mul24(Z.c[k], (uint32_t)g.dblk[1]) + Y.c[j]) * (uint32_t)g.dblk[0]
-                                       : ((Z.c[k] << g.bshift[1]) + Y.c[j]) << g.bshift[0];
+                                       : mul24(mul24(Z.c[k], (uint32_t)g.nb[1]) + Y.c[j], (uint32_t)g.nb[0]);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 TapAddr& a = io.a[4 * k + 2 * j + i];
