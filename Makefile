@@ -10,7 +10,7 @@ HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 OBJDIR   := build
 SRCS_CPP := grids.cpp imageio.cpp environment.cpp transferfunc.cpp renderer.cpp capi.cpp
 PT_VARIANTS := 0 1 2 3
-OBJS     := $(OBJDIR)/vr_kernels.o $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_%.o) $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_fast_%.o) $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
+OBJS     := $(OBJDIR)/vr_kernels.o $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_%.o) $(PT_VARIANTS:%=$(OBJDIR)/vr_ptfast_%.o) $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
 # tolerance-mode kernels (opt-in, vr_math.h VR_FAST_MATH): hardware transcendentals, reciprocal division, contraction allowed
 FASTFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result -Iinclude -DVR_FAST_MATH=1
 # path-tracing kernels: no SLP vectorisation.  On gfx950 a packed fp32 instruction (v_pk_mul/add/fma_f32) occupies the SIMD for
@@ -30,9 +30,10 @@ $(OBJDIR)/vr_pathtrace_%.o: $(CSRC)/vr_pathtrace.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(PTFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_pathtrace_$*.resources.txt || (cat $(OBJDIR)/vr_pathtrace_$*.resources.txt; false)
 
-$(OBJDIR)/vr_pathtrace_fast_%.o: $(CSRC)/vr_pathtrace.hip $(HDRS)
+# (object names with disjoint patterns: vr_pathtrace_% must not also match the tolerance-mode objects)
+$(OBJDIR)/vr_ptfast_%.o: $(CSRC)/vr_pathtrace.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(FASTFLAGS) $(PTFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_pathtrace_fast_$*.resources.txt || (cat $(OBJDIR)/vr_pathtrace_fast_$*.resources.txt; false)
+	$(HIPCC) $(FASTFLAGS) $(PTFLAGS) -DVR_PT_VARIANT=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(OBJDIR)/vr_ptfast_$*.resources.txt || (cat $(OBJDIR)/vr_ptfast_$*.resources.txt; false)
 
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)

@@ -64,6 +64,12 @@ int vr_load_transferfunc(vr_renderer* r, const char* path);        /* "%f, %f, %
  *     transform: grid index->model, 16 floats column-major (NULL = identity).  name: "density" | "temperature" | "flame" | "flames".
  *     unit_cube != 0 applies load_volume's density_scale=1 + scale_and_move_to_unit_cube().  Follow with vr_commit(). */
 int vr_set_volume_dense(vr_renderer* r, const char* name, const float* voxels, int nx, int ny, int nz, const float* transform, int unit_cube);
+/* voldata::Volume::add_grid_frame / update_grid_frame / n_grid_frames (src/bindings.cpp:89-90; voldata is not vendored: call sites
+ * src/main.cpp:47, src/renderer.cpp:61-75): append an animation frame holding the dense float grid `name`, or replace grid `name` of frame
+ * `frame`.  Follow with vr_commit(); select the frame to render with vr_set_int "grid_frame_counter". */
+int vr_volume_add_grid_frame_dense(vr_renderer* r, const char* name, const float* voxels, int nx, int ny, int nz, const float* transform);
+int vr_volume_update_grid_frame_dense(vr_renderer* r, int frame, const char* name, const float* voxels, int nx, int ny, int nz, const float* transform);
+int vr_volume_n_grid_frames(vr_renderer* r, int* n);
 /* dense fp16 grid that STAYS dense on the device (no brick conversion; north_star "dense fp16 grid"): voxels are IEEE
  * binary16, x fastest.  No reference counterpart (the reference bricks every grid in commit(), src/renderer.cpp:63). */
 int vr_set_volume_dense_f16(vr_renderer* r, const char* name, const uint16_t* voxels, int nx, int ny, int nz, const float* transform, int unit_cube);
@@ -144,6 +150,9 @@ int vr_grid_checksums(vr_renderer* r, uint64_t out[3]);
  * may be NULL) receives, per state, [block executions, active lanes], then [16] wave iterations, [17] waves, [18..24] cycles per
  * state, [25] summed wave lifetime, [26..31] summed pool occupancy */
 int vr_sched_stats(vr_renderer* r, int enable, unsigned long long* out);
+/* test hook: device allocations above `mb` MiB fail as if the device were out of memory (the fall-back paths can then be exercised on a
+ * shared GPU); mb < 0 removes the cap.  Initial value: environment variable VR_TEST_MAX_ALLOC_MB, read once per process. */
+int vr_test_alloc_cap_mb(long long mb);
 /* unit-test probe of the device math (volren_amd/csrc/vr_math.h): host arrays in/out */
 int vr_math_probe(int fn, const float* a, const float* b, float* out, int n);
 /* voldata::Volume::to_brick_grid + BrickGrid serialisation: encode a dense float grid (x fastest) and write it as a .brick

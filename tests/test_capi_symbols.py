@@ -144,3 +144,20 @@ int drive(const char* vol, const char* env, const char* lut) {
 }
 ''')
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-x", "hip", "-I", os.path.join(root, "include"), str(src)])
+
+
+def test_volpy_value_types():
+    """glm value types of the reference's Python module (src/bindings.cpp:215-395): integer vectors and column-major matrices."""
+    import numpy as np
+    import volren_amd.volpy as vp
+    m = vp.mat3(vp.vec3(1, 2, 3), vp.vec3(4, 5, 6), vp.vec3(7, 8, 9))
+    assert m.column(1) == vp.vec3(4, 5, 6) and m.value(2, 0) == 7.0                    # m[i][j]: column i, row j
+    assert np.array(m).shape == (3, 3) and np.array(m)[0].tolist() == [1.0, 2.0, 3.0]    # buffer rows are glm columns
+    assert m * vp.mat3() == m and vp.mat3(2.0).value(1, 1) == 2.0 and (2 * m).value(0, 1) == 4.0
+    rot = vp.mat3(vp.vec3(0, 1, 0), vp.vec3(-1, 0, 0), vp.vec3(0, 0, 1))                # 90 degrees about z
+    assert rot * vp.vec3(1, 0, 0) == vp.vec3(0, 1, 0) and (rot * rot) * vp.vec3(1, 0, 0) == vp.vec3(-1, 0, 0)
+    assert (m + m) == 2 * m and (m - m) == vp.mat3(0.0) and (-m).value(0, 0) == -1.0
+    m4 = vp.mat4(vp.vec4(1, 0, 0, 0), vp.vec4(0, 1, 0, 0), vp.vec4(0, 0, 1, 0), vp.vec4(5, 6, 7, 1))
+    assert m4 * vp.vec4(1, 1, 1, 1) == vp.vec4(6, 7, 8, 1) and np.array(m4).shape == (4, 4)
+    assert vp.uvec3(1, 2, 3) + vp.uvec3(1) == vp.uvec3(2, 3, 4) and vp.ivec4(1, 2, 3, 4).w == 4 and repr(vp.ivec3(1, -2, 3)) == "ivec3(1, -2, 3)"
+    assert np.array(vp.uvec2(3, 4)).dtype == np.uint32 and np.array(vp.ivec2(3, 4)).dtype == np.int32

@@ -6,8 +6,8 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
-for path in sorted(glob.glob(os.path.join(ROOT, "build", "vr_pathtrace_*.resources.txt"))):
-    mode = "fast " if "_fast_" in os.path.basename(path) else "exact"
+for path in sorted(glob.glob(os.path.join(ROOT, "build", "vr_pathtrace_[0-9].resources.txt")) + glob.glob(os.path.join(ROOT, "build", "vr_ptfast_[0-9].resources.txt"))):
+    mode = "fast " if "ptfast" in os.path.basename(path) else "exact"
     cur = None
     for line in open(path):
         m = re.search(r"Function Name: (\S+)", line)

@@ -18,7 +18,7 @@ SYMBOLS = [
     "vr_commit", "vr_reset", "vr_scale_and_move_to_unit_cube", "vr_trace", "vr_render", "vr_synchronize",
     "vr_last_kernel_ms", "vr_last_pathtrace_ms", "vr_framebuffer", "vr_framebuffer_device", "vr_draw", "vr_display", "vr_save_png",
     "vr_set_tiles", "vr_set_stream", "vr_pack_tiles", "vr_unpack_tiles", "vr_get_uniforms", "vr_uniforms_size",
-    "vr_impmap_floats", "vr_get_impmap", "vr_set_sched", "vr_sched_stats", "vr_grid_checksums", "vr_math_probe", "vr_encode_dense_stats", "vr_write_brick_from_dense", "vr_write_dense",
+    "vr_volume_add_grid_frame_dense", "vr_volume_update_grid_frame_dense", "vr_volume_n_grid_frames", "vr_impmap_floats", "vr_get_impmap", "vr_test_alloc_cap_mb", "vr_set_sched", "vr_sched_stats", "vr_grid_checksums", "vr_math_probe", "vr_encode_dense_stats", "vr_write_brick_from_dense", "vr_write_dense",
 ]
 
 _lib = None
@@ -78,6 +78,10 @@ def load():
     L.vr_uniforms_size.restype = ci
     L.vr_impmap_floats.argtypes = [vp]
     L.vr_get_impmap.argtypes = [vp, vp, ci]
+    L.vr_volume_add_grid_frame_dense.argtypes = [vp, C.c_char_p, vp, ci, ci, ci, vp]
+    L.vr_volume_update_grid_frame_dense.argtypes = [vp, ci, C.c_char_p, vp, ci, ci, ci, vp]
+    L.vr_volume_n_grid_frames.argtypes = [vp, vp]
+    L.vr_test_alloc_cap_mb.argtypes = [C.c_longlong]
     L.vr_set_sched.argtypes = [vp, vp]
     L.vr_sched_stats.argtypes = [vp, ci, vp]
     L.vr_grid_checksums.argtypes = [vp, vp]

@@ -169,6 +169,37 @@ int vr_set_volume_dense(vr_renderer* r, const char* name, const float* voxels, i
     });
 }
 
+// voldata::Volume::add_grid_frame / update_grid_frame (src/bindings.cpp:89-90) for dense float grids: a further animation frame holding
+// `name`, or grid `name` of frame `frame` replaced.  Takes effect at the next vr_commit(), like every change of the volume.
+int vr_volume_add_grid_frame_dense(vr_renderer* r, const char* name, const float* voxels, int nx, int ny, int nz, const float* transform) {
+    NEED(r);
+    if (!voxels || nx <= 0 || ny <= 0 || nz <= 0) return fail(VR_ERR_ARG, "bad dense grid arguments");
+    return guard([&] {
+        auto g = std::make_shared<vr::DenseGrid>((uint32_t)nx, (uint32_t)ny, (uint32_t)nz, voxels);
+        if (transform) memcpy(g->transform.m, transform, 64);
+        if (!r->impl.volume) r->impl.volume = std::make_shared<vr::Volume>();
+        r->impl.volume->add_grid_frame(g, name ? name : "density");
+        r->impl.sample = 0;
+    });
+}
+int vr_volume_update_grid_frame_dense(vr_renderer* r, int frame, const char* name, const float* voxels, int nx, int ny, int nz, const float* transform) {
+    NEED(r);
+    if (!voxels || nx <= 0 || ny <= 0 || nz <= 0 || frame < 0) return fail(VR_ERR_ARG, "bad dense grid arguments");
+    return guard([&] {
+        if (!r->impl.volume || (size_t)frame >= r->impl.volume->n_grid_frames()) throw std::out_of_range("vr_volume_update_grid_frame_dense: no such frame");
+        auto g = std::make_shared<vr::DenseGrid>((uint32_t)nx, (uint32_t)ny, (uint32_t)nz, voxels);
+        if (transform) memcpy(g->transform.m, transform, 64);
+        r->impl.volume->update_grid_frame((size_t)frame, g, name ? name : "density");
+        r->impl.sample = 0;
+    });
+}
+int vr_volume_n_grid_frames(vr_renderer* r, int* n) {
+    NEED(r);
+    if (!n) return fail(VR_ERR_ARG, "null output");
+    *n = r->impl.volume ? (int)r->impl.volume->n_grid_frames() : 0;
+    return VR_OK;
+}
+
 int vr_set_volume_dense_f16(vr_renderer* r, const char* name, const uint16_t* voxels, int nx, int ny, int nz, const float* transform, int unit_cube) {
     NEED(r);
     if (!voxels || nx <= 0 || ny <= 0 || nz <= 0) return fail(VR_ERR_ARG, "bad dense grid arguments");
@@ -464,6 +495,12 @@ int vr_set_sched(vr_renderer* r, const int32_t thr[8]) {
 int vr_sched_stats(vr_renderer* r, int enable, unsigned long long* out) {
     NEED(r);
     return guard([&] { use_device(r); r->impl.sched_stats(enable != 0, out); });
+}
+
+// test hook (devmem.h): device allocations above `mb` MiB fail as if the device were out of memory; mb < 0 removes the cap
+int vr_test_alloc_cap_mb(long long mb) {
+    vr::test_alloc_cap().store(mb < 0 ? ~(size_t)0 : (size_t)mb << 20);
+    return VR_OK;
 }
 
 int vr_math_probe(int fn, const float* a, const float* b, float* out, int n) {

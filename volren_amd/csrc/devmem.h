@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdlib>
 #include <memory>
@@ -18,15 +19,26 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 #define VR_HIP(call) ::vr::hip_check((call), #call, __FILE__, __LINE__)
 
 // a hipMalloc allocation; shared handles mirror cppgl's ref-counted GL objects (renderer.h:9-14, environment.h:22)
+// Test hook: allocations larger than this fail as an exhausted device would, so that the out-of-memory paths can be exercised without
+// taking the HBM away from other users of the GPU.  Initial value from VR_TEST_MAX_ALLOC_MB (MiB), read ONCE per process (unset, empty
+// or not a number = no cap); changed at run time through vr_test_alloc_cap_mb() (include/volren_amd.h).
+inline std::atomic<size_t>& test_alloc_cap() {
+    static std::atomic<size_t> cap([] {
+        const char* e = getenv("VR_TEST_MAX_ALLOC_MB");
+        if (!e || !*e) return ~(size_t)0;
+        char* end = nullptr;
+        const unsigned long long mb = strtoull(e, &end, 10);
+        return (end == e || *end != '\0') ? ~(size_t)0 : (size_t)mb << 20;
+    }());
+    return cap;
+}
+
 class DeviceBuffer {
 public:
     DeviceBuffer() = default;
     explicit DeviceBuffer(size_t bytes) {
         if (!bytes) return;
-        // test hook: VR_TEST_MAX_ALLOC_MB makes larger allocations fail like an exhausted device would, so that the
-        // out-of-memory paths can be exercised without taking the HBM away from other users of the GPU
-        if (const char* cap = getenv("VR_TEST_MAX_ALLOC_MB"))
-            if (bytes > ((size_t)strtoull(cap, nullptr, 10) << 20)) hip_check(hipErrorOutOfMemory, "hipMalloc (VR_TEST_MAX_ALLOC_MB)", __FILE__, __LINE__);
+        if (bytes > test_alloc_cap().load(std::memory_order_relaxed)) hip_check(hipErrorOutOfMemory, "hipMalloc (test allocation cap)", __FILE__, __LINE__);
         VR_HIP(hipMalloc(&ptr_, bytes));
         bytes_ = bytes;
     }

@@ -22,42 +22,45 @@ using namespace vr;
 static std::shared_ptr<RendererHIP> renderer;
 static std::string out_filename = "output.png";
 
-static void load_volume(const std::string& path) {
-    try {
-        std::cout << "load volume: " << path << std::endl;
-        if (fs::is_directory(path)) renderer->volume = Volume::load_folder(path);
-        else renderer->volume = std::make_shared<Volume>(path);
-        renderer->density_scale = 1.f;
-        renderer->scale_and_move_to_unit_cube();
-        renderer->commit();
-        renderer->sample = 0;
-    } catch (std::exception& e) {
-        std::cerr << "Unable to load volume from " << path << ": " << e.what() << std::endl;
-    }
-}
-static void load_envmap(const std::string& path) {
-    try {
-        renderer->environment = std::make_shared<Environment>(path);
-        renderer->sample = 0;
-    } catch (std::exception& e) {
-        std::cerr << "Unable to load envmap from " << path << ": " << e.what() << std::endl;
-    }
-}
-static void load_transferfunc(const std::string& path) {
-    try {
-        renderer->transferfunc = std::make_shared<TransferFunction>(path);
-        renderer->show_environment = false;
-        renderer->sample = 0;
-    } catch (std::exception& e) {
-        std::cerr << "Unable to load transferfunc from " << path << ": " << e.what() << std::endl;
-    }
-}
+// A path on the command line is loaded the moment it is seen (src/main.cpp:37-81, 428-432): ".hdr" replaces the environment, ".txt" binds a
+// transfer function and hides the environment, anything else is a volume file or a folder of animation frames -- which also resets the density
+// scale, fits the volume into the unit cube and commits it.  Every kind restarts the accumulation; a loader that throws is reported on stderr
+// with the reference's wording and the render goes on with what was loaded before (the reference's catch blocks).
+struct PathKind {
+    const char* ext;       // file extension, or nullptr for "everything else"
+    const char* what;      // the noun of the reference's message: "Unable to load <what> from <path>: ..."
+    void (*load)(const std::string& path);
+};
+static const PathKind kPathKinds[] = {
+    { ".hdr", "envmap", [](const std::string& path) { renderer->environment = std::make_shared<Environment>(path); } },
+    { ".txt", "transferfunc", [](const std::string& path) {
+          renderer->transferfunc = std::make_shared<TransferFunction>(path);
+          renderer->show_environment = false;
+      } },
+    { nullptr, "volume", [](const std::string& path) {
+          std::cout << "load volume: " << path << std::endl;
+          renderer->volume = fs::is_directory(path) ? Volume::load_folder(path) : std::make_shared<Volume>(path);
+          renderer->density_scale = 1.f;
+          renderer->scale_and_move_to_unit_cube();
+          renderer->commit();
+      } },
+};
 static void handle_path(const std::string& path) {
     const std::string ext = fs::path(path).extension().string();
-    if (ext == ".py") std::cerr << "Python scripts are not supported by this build (" << path << "): use the volren_amd python package" << std::endl;
-    else if (ext == ".hdr") load_envmap(path);
-    else if (ext == ".txt") load_transferfunc(path);
-    else load_volume(path);
+    if (ext == ".py") {
+        std::cerr << "Python scripts are not supported by this build (" << path << "): use the volren_amd python package" << std::endl;
+        return;
+    }
+    for (const PathKind& kind : kPathKinds) {
+        if (kind.ext && ext != kind.ext) continue;
+        try {
+            kind.load(path);
+            renderer->sample = 0;
+        } catch (const std::exception& e) {
+            std::cerr << "Unable to load " << kind.what << " from " << path << ": " << e.what() << std::endl;
+        }
+        return;
+    }
 }
 
 struct Args {

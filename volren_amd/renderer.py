@@ -101,6 +101,25 @@ class Renderer:
         if commit:
             self.commit()
 
+    def volume_add_grid_frame(self, voxels_zyx, name="density", transform=None):
+        """voldata::Volume::add_grid_frame: one more animation frame holding the dense grid `name` (commit() afterwards)."""
+        v = _f32(voxels_zyx)
+        nz, ny, nx = v.shape
+        t = _f32(transform).reshape(16) if transform is not None else None
+        _lib.check(self._L.vr_volume_add_grid_frame_dense(self._h, name.encode(), v.ctypes.data, nx, ny, nz, t.ctypes.data if t is not None else None))
+
+    def volume_update_grid_frame(self, frame, voxels_zyx, name="density", transform=None):
+        """voldata::Volume::update_grid_frame: grid `name` of frame `frame` replaced (commit() afterwards)."""
+        v = _f32(voxels_zyx)
+        nz, ny, nx = v.shape
+        t = _f32(transform).reshape(16) if transform is not None else None
+        _lib.check(self._L.vr_volume_update_grid_frame_dense(self._h, int(frame), name.encode(), v.ctypes.data, nx, ny, nz, t.ctypes.data if t is not None else None))
+
+    def volume_n_grid_frames(self):
+        n = C.c_int()
+        _lib.check(self._L.vr_volume_n_grid_frames(self._h, C.byref(n)))
+        return n.value
+
     def set_volume_dense_f16(self, voxels_zyx, transform=None, name="density", unit_cube=True, commit=True):
         """Dense fp16 grid kept dense on the device (2 B/voxel, no brick indirection)."""
         v = np.ascontiguousarray(voxels_zyx, dtype=np.float16)

@@ -4,7 +4,7 @@
 `scripts/datagen_denoise.py`) the same classes, members and CALL PROTOCOL: assigning `renderer.volume` only replaces the
 volume; `scale_and_move_to_unit_cube()` multiplies the density scale the caller has set (renderer.cpp:227-242); `commit()`
 uploads the grids.  `vec2/vec3/vec4/quat` are small glm-like value types (`.x .y .z`, arithmetic, `.length()`,
-`.normalize()`, buffer access through `np.array(v)`), `Volume.AABB(name)` returns two of them, `resolution()` has `.x/.y`.
+`.normalize()`, buffer access through `np.array(v)`; also `ivec2/3/4`, `uvec2/3/4`, column-major `mat3` / `mat4` with `column(i)`, `value(i, j)`), `Volume.AABB(name)` returns two of them, `resolution()` has `.x/.y`.
 Differences, all forced by running without a GL window:
   * the resolution is a constructor argument (`Renderer(w, h)`, default 1024x1024; the reference takes the GL context's,
     i.e. `-w/-h` of the embedding executable),
@@ -93,7 +93,7 @@ class _Vec:
     def __setitem__(self, i, x): self.v[i] = x
     def __eq__(self, o): return isinstance(o, _Vec) and o._n == self._n and bool(np.array_equal(self.v, o.v))
     def __hash__(self): return hash(self.v.tobytes())
-    def __repr__(self): return "%s(%s)" % (type(self).__name__, ", ".join("%f" % c for c in self.v))
+    def __repr__(self): return "%s(%s)" % (type(self).__name__, ", ".join(("%d" if np.issubdtype(self._dtype, np.integer) else "%f") % c for c in self.v))
 
 
 def _component(i):
@@ -125,6 +125,104 @@ class ivec2(_Vec):
     x, y = _component(0), _component(1)
 
 
+class ivec3(_Vec):
+    __slots__ = ()
+    _n = 3
+    _dtype = np.int32
+    x, y, z = _component(0), _component(1), _component(2)
+
+
+class ivec4(_Vec):
+    __slots__ = ()
+    _n = 4
+    _dtype = np.int32
+    x, y, z, w = _component(0), _component(1), _component(2), _component(3)
+
+
+class uvec2(_Vec):
+    __slots__ = ()
+    _n = 2
+    _dtype = np.uint32
+    x, y = _component(0), _component(1)
+
+
+class uvec3(_Vec):
+    __slots__ = ()
+    _n = 3
+    _dtype = np.uint32
+    x, y, z = _component(0), _component(1), _component(2)
+
+
+class uvec4(_Vec):
+    __slots__ = ()
+    _n = 4
+    _dtype = np.uint32
+    x, y, z, w = _component(0), _component(1), _component(2), _component(3)
+
+
+class _Mat:
+    """glm::mat3 / glm::mat4 as bound by bindings.cpp:348-395: column-major, `column(i)`, `value(i, j)` = m[i][j] (column i, row j),
+    + - * with a matrix, * with a scalar, unary minus; `np.array(m)` has the bound buffer's shape (n, n) with row i = COLUMN i (glm memory)."""
+    __slots__ = ("m",)
+    _n = 0
+    _vec = None
+
+    def __init__(self, *args):
+        n = self._n
+        if len(args) == 0:
+            self.m = np.eye(n, dtype=np.float32)                  # glm's default constructor: identity
+        elif len(args) == 1 and np.ndim(args[0]) == 0:
+            self.m = np.eye(n, dtype=np.float32) * np.float32(args[0])
+        elif len(args) == n:
+            self.m = np.stack([np.asarray(c, np.float32).reshape(n) for c in args]).copy()      # the columns
+        elif len(args) == 1:
+            a = np.asarray(args[0].m if isinstance(args[0], _Mat) else args[0], np.float32)
+            if a.shape != (n, n):
+                raise TypeError("%s from shape %s" % (type(self).__name__, a.shape))
+            self.m = a.copy()
+        else:
+            raise TypeError("%s(): %d arguments" % (type(self).__name__, len(args)))
+
+    def _new(self, a):
+        r = type(self).__new__(type(self))
+        r.m = np.asarray(a, np.float32)
+        return r
+
+    def column(self, i): return self._vec(self.m[int(i)])
+    def value(self, i, j): return self.m[int(i), int(j)].item()
+    def __add__(self, o): return self._new(self.m + o.m)
+    def __sub__(self, o): return self._new(self.m - o.m)
+    def __neg__(self): return self._new(-self.m)
+
+    def __mul__(self, o):
+        if isinstance(o, _Mat):
+            return self._new((self.m.T @ o.m.T).T)                # rows of .m are columns: (A B) stored column-major
+        if isinstance(o, _Vec):
+            return self._vec((self.m.T @ o.v).astype(np.float32))
+        return self._new(self.m * np.float32(o))
+
+    def __rmul__(self, o): return self._new(self.m * np.float32(o))
+    def __iadd__(self, o): self.m = self.m + o.m; return self
+    def __isub__(self, o): self.m = self.m - o.m; return self
+    def __imul__(self, o): self.m = (self * o).m; return self
+    def __array__(self, dtype=None, copy=None): return self.m.astype(dtype) if dtype is not None else self.m.copy()
+    def __eq__(self, o): return isinstance(o, _Mat) and o._n == self._n and bool(np.array_equal(self.m, o.m))
+    def __hash__(self): return hash(self.m.tobytes())
+    def __repr__(self): return "%s(%s)" % (type(self).__name__, ", ".join("(%s)" % ", ".join("%f" % c for c in col) for col in self.m))
+
+
+class mat3(_Mat):
+    __slots__ = ()
+    _n = 3
+    _vec = vec3
+
+
+class mat4(_Mat):
+    __slots__ = ()
+    _n = 4
+    _vec = vec4
+
+
 class quat(_Vec):
     """glm::quat; memory order (x, y, z, w) like glm's default, so `np.array(q)[[3, 0, 1, 2]]` is (w, x, y, z)
     (datagen_colmap.py:94).  Constructor order (w, x, y, z) as in glm."""
@@ -152,6 +250,7 @@ class Volume:
         self.dense = None
         self._owner = None
         self._frame = 0
+        self._edits = []                 # add_grid_frame / update_grid_frame calls, replayed whenever the volume is (re)attached to a renderer
         if len(args) == 1:
             self.path = os.fspath(args[0])
         elif len(args) == 4:
@@ -177,6 +276,30 @@ class Volume:
 
     def clear(self):
         self.path, self.dense = None, None
+        self._edits = []
+
+    @staticmethod
+    def _dense_of(grid):
+        """A grid argument: a dense Volume(w, h, d, data) or an array [z][y][x] (the reference's Python has no Grid class of its own)."""
+        a = grid.dense if isinstance(grid, Volume) else np.asarray(grid, np.float32)
+        if a is None or a.ndim != 3:
+            raise TypeError("grid: a dense Volume(w, h, d, data) or a float array [z][y][x]")
+        return np.ascontiguousarray(a, np.float32)
+
+    def add_grid_frame(self, grid, name="density"):
+        """voldata::Volume::add_grid_frame (bindings.cpp:89): a further animation frame that holds `grid` as `name`."""
+        self._edits.append(("add", None, self._dense_of(grid), name))
+        if self._owner is not None:
+            self._owner._attach_volume(self)
+
+    def update_grid_frame(self, i, grid, name="density"):
+        """voldata::Volume::update_grid_frame (bindings.cpp:90): grid `name` of frame `i` replaced (or added to that frame)."""
+        self._edits.append(("update", int(i), self._dense_of(grid), name))
+        if self._owner is not None:
+            self._owner._attach_volume(self)
+
+    def n_grid_frames(self):
+        return self._need_owner("n_grid_frames").volume_n_grid_frames()
 
     def load_grid(self, path):
         """Replaces the volume by the grid file `path` (takes effect at the next assignment / commit)."""
@@ -288,12 +411,20 @@ class Renderer:
     def _attach_volume(self, v):
         # like `renderer->volume = ...` in the reference: replaces the volume object only.  density_scale, the unit-cube
         # transform and the device grids change in scale_and_move_to_unit_cube() / commit(), in the caller's order.
+        edits = list(v._edits)
         if v.path:
             self._r.set_volume_path(v.path)
         elif v.dense is not None:
             self._r.set_volume_dense(v.dense, unit_cube=False, commit=False)
+        elif edits and edits[0][0] == "add" and edits[0][3] == "density":
+            self._r.set_volume_dense(edits.pop(0)[2], unit_cube=False, commit=False)      # Volume() + add_grid_frame(...): the first frame
         else:
             raise RuntimeError("Renderer.volume: empty Volume")
+        for kind, i, dense, name in edits:
+            if kind == "add":
+                self._r.volume_add_grid_frame(dense, name)
+            else:
+                self._r.volume_update_grid_frame(i, dense, name)
         object.__setattr__(self, "_committed", False)
 
     def _set_volume(self, v):
