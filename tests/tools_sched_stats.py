@@ -22,3 +22,9 @@ print("  wave lifetime cycles/wave-sample %.0f ; unaccounted (scheduler) %.1f%%"
 print("  pool occupancy per iteration:", {k: round(v,1) for k,v in st.get("occupancy",{}).items()})
 print("  avg resident waves (at 2.4 GHz) %.0f  (waves launched %d)"%(st["wave_cycles"]/(ms*2.4e6), st["waves"]))
 print("  iterations/wave-sample %.1f  blocks/iter %.2f"%(st["iterations"]/(ns/64), tot_exec/st["iterations"]))
+if os.environ.get("VR_STAT_SECTIONS"):      # library built with -DVR_STAT_SCHED=1: the occupancy slots carry section cycles
+    sec = {k: v * st["iterations"] for k, v in st["occupancy"].items()}
+    names = {"marching": "resume", "ready": "hot pair", "nee": "park", "postnee": "decision + event batches", "escape": "loop tail/head", "free": "-"}
+    ev = sum(st["cycles"][k] for k in ("new", "begin", "nee", "postnee", "escape"))
+    print("  sections (share of wave lifetime):", {names[k]: round(100.0 * v / st["wave_cycles"], 1) for k, v in sec.items() if k != "free"},
+          " of which event code %.1f" % (100.0 * ev / st["wave_cycles"]))

@@ -426,6 +426,12 @@ pathtrace_kernel(const KernelArgs A) {
     uint32_t t_last = (uint32_t)__builtin_readcyclecounter(), t_elapsed = 0u;
     uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
+#ifndef VR_STAT_SCHED
+#define VR_STAT_SCHED 0
+#endif
+#if VR_STAT_SCHED
+    unsigned long long t_tail = 0ull;
+#endif
     unsigned long long occ[6] = { 0, 0, 0, 0, 0, 0 };      // summed per iteration: marching lanes, READY, NEE, POSTNEE, ESCAPE, FREE
 #define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
 #define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
@@ -468,6 +474,14 @@ pathtrace_kernel(const KernelArgs A) {
             if (lane == 0) atomicOr(event_args().status, 1u);
             break;
         }
+#if VR_STAT_SCHED
+        // diagnostic build: the occupancy counters carry the cycles of the scheduler's sections instead (tests/tools_sched_stats.py --sections)
+        unsigned long long t_sec = STATS ? __builtin_readcyclecounter() : 0ull;
+        if (STATS && t_tail) occ[4] += t_sec - t_tail;                   // loop tail + head (watchdog, exit test)
+#define VR_SECTION(K) do { if (STATS) { const unsigned long long n_ = __builtin_readcyclecounter(); occ[K] += n_ - t_sec; t_sec = n_; } } while (0)
+#else
+#define VR_SECTION(K) do { } while (0)
+#endif
         // (1) idle lanes resume READY paths
         {
             const uint64_t idle = wave_ballot(slot < 0);
@@ -486,7 +500,10 @@ pathtrace_kernel(const KernelArgs A) {
                 cnt_ready -= take;
             }
         }
+        VR_SECTION(0);                                                   // resume
+#if !VR_STAT_SCHED
         if (STATS) { occ[0] += (unsigned)popc(wave_ballot(slot >= 0)); occ[1] += (unsigned)cnt_ready; occ[2] += (unsigned)cnt_nee; occ[3] += (unsigned)cnt_post; occ[4] += (unsigned)cnt_esc; occ[5] += (unsigned)cnt_free; }
+#endif
         // (2) the hot pair: two DDA steps for the marching lanes, then the collision code for every lane that now stands at a
         // tentative collision (after two steps that is most of them, so both blocks run nearly full width).  Two memory round
         // trips per pass instead of four: both majorants are loaded together (the second step is prepared speculatively,
@@ -549,6 +566,7 @@ pathtrace_kernel(const KernelArgs A) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0)
             if (STATS) st_cyc[ST_COLLIDE] += __builtin_readcyclecounter() - t_blk;
         }
+        VR_SECTION(1);                                                   // hot pair (also in st_cyc[MARCH] + st_cyc[COLLIDE])
         // (3) park paths that reached an event
         {
             // the state of a lane's path if it has to be parked (the hot pair can only leave a path in NEE, POSTNEE or ESCAPE), else -1:
@@ -565,6 +583,7 @@ pathtrace_kernel(const KernelArgs A) {
                 if (ps >= 0) slot = -1;
             }
         }
+        VR_SECTION(2);                                                   // park
         // (4) event batches
         int32_t n;
         const int32_t n_live = popc(wave_ballot(slot >= 0)) + cnt_ready;
@@ -717,6 +736,10 @@ pathtrace_kernel(const KernelArgs A) {
             if (my_slot >= 0) { hs.load_resume(l, my_slot); if (emission_on && !l.shadow) { const ColdT c = VR_COLD(my_slot); l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L); } }
 #endif
         }
+        VR_SECTION(3);                                                   // batch decision + event batches (the events' own cycles are in st_cyc)
+#if VR_STAT_SCHED
+        t_tail = t_sec;
+#endif
         if (exhausted && cnt_free == VR_POOL) break;                        // every path of the pool has finished
     }
     unsigned long long* const stats = A.stats;
@@ -741,6 +764,7 @@ pathtrace_kernel(const KernelArgs A) {
 #undef VR_POOL
 #undef VR_THR_COLLIDE
 #undef VR_STAT_END
+#undef VR_SECTION
 #undef VR_PUSH
 #undef VR_ROUTE
 #undef VR_ROUTE_B
