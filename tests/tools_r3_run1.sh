@@ -1,2 +1,4 @@
-export VOLREN_AMD_LIB=$PWD/build/exp_statsched/libvolren_amd.so VR_STAT_SECTIONS=1
-for c in "c2 1024 128" "c4:512 1024 32" "c5full 2048 32" "c3 1024 128"; do python tests/tools_sched_stats.py $c 2>&1 | grep -E "sections|Msamples|unaccounted"; done
+set -o pipefail
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "render_matches or degenerate or scheduler or random_parameter or stale_cold or synthetic_baseline or transfer_function_lut or global_majorant or flags" > gpurun_out/r3n_tests.log 2>&1; echo "pytest rc $?"; tail -2 gpurun_out/r3n_tests.log
+AB_CASES="c2:1024:256 c3:1024:256 c4:512:1024:64 c5full:2048:64" bash tests/tools_ab.sh default hotri stride12 > gpurun_out/r3n_ab.log 2>&1
+cat gpurun_out/r3n_ab.log

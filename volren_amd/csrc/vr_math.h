@@ -54,6 +54,29 @@ VR_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 VR_HD float floor_(float x) { return __builtin_floorf(x); }
 VR_HD float sqrt_(float x) { return __builtin_sqrtf(x); }
 VR_HD float abs_(float x) { return __builtin_fabsf(x); }
+// 1.0f / x, correctly rounded.  On the device: v_rcp_f32 (1 ulp) + one Newton step + v_div_fixup_f32 -- 4 instructions instead of the 10 of
+// the IEEE division sequence -- which equals the correctly rounded quotient for EVERY x whose exponent field lies in [2, 252]
+// (tests/tools_rcp_exact.hip compares all 2^32 inputs on the GPU: 0 mismatches in that range); the others -- zeros, denormals, the two
+// smallest and the two largest binades, infinities, NaN -- take the division.  Up to three reciprocals share one range test.
+VR_HD bool rcp_in_fast_range(float x) { return ((f2u(x) >> 23) & 255u) - 2u <= 250u; }
+VR_HD float rcp_newton(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !VR_FAST_DEVICE
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+    return __builtin_amdgcn_div_fixupf(r1, x, 1.0f);
+#else
+    return 1.0f / x;
+#endif
+}
+VR_HD float rcp_exact(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !VR_FAST_DEVICE
+    float r = rcp_newton(x);
+    if (!rcp_in_fast_range(x)) r = 1.0f / x;
+    return r;
+#else
+    return 1.0f / x;
+#endif
+}
 VR_HD float inf_() { return u2f(0x7F800000u); }
 VR_HD float nan_() { return u2f(0x7FC00000u); }
 

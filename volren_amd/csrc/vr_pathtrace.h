@@ -87,14 +87,22 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 //     register set so the marching path stays put (VR_BATCH_REGS=0 swaps it through its LDS slot instead).
 // Everything is wave-synchronous (ballots, mbcnt ranks, scalar counters): no atomics, no barriers, no spinning; the only
 // global atomic is the work-queue head.  Which lane runs which path never changes a result.
+// 1 / dir of a parked path: kept in its LDS slot (15 dwords per slot, 152 slots), or recomputed when the path is resumed (12 dwords, 188
+// slots: three exact reciprocals per resume, vr_math.h rcp_exact, against 24 % more paths per wavefront)
+#ifndef VR_HOT_RI
+#define VR_HOT_RI 0
+#endif
+#ifndef VR_HOT_STRIDE
+#define VR_HOT_STRIDE (VR_HOT_RI ? 15 : 13)      /* odd: lanes with different slots spread over the LDS banks (12 fields + 1 pad) */
+#endif
 #ifndef VR_NSLOT
-#define VR_NSLOT 152
+#define VR_NSLOT (VR_HOT_RI ? 152 : (VR_HOT_STRIDE == 12 ? 188 : 175))
 #endif
 constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
 // The transfer-function kernels stage the LUT (up to kLutLdsEntries vec4 = 4 KiB) in LDS and give up 12 path slots for it:
 // 4 workgroups x (140 slots x 65 B x 4 wavefronts + 4 KiB) = 158.2 KiB of the CU's 160 KiB.
 #ifndef VR_NSLOT_TF
-#define VR_NSLOT_TF (VR_NSLOT >= 152 ? VR_NSLOT - 12 : VR_NSLOT)
+#define VR_NSLOT_TF (VR_NSLOT >= 152 ? VR_NSLOT - (VR_HOT_RI ? 12 : (VR_HOT_STRIDE == 12 ? 15 : 14)) : VR_NSLOT)
 #endif
 constexpr int32_t kLutLdsEntries = 256;
 // Build-time experiment (round 3, -DVR_COLD_REGS=1; profiles/r3a_cold_state_in_registers.txt): cold path state in VECTOR REGISTERS
@@ -113,7 +121,9 @@ template <class K> constexpr int32_t waves_per_simd() { return cold_in_regs<K>()
 
 enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
 
-constexpr int32_t HOT_STRIDE = 15;     // dwords per slot in LDS (= the parked fields): odd, so that lanes with different slots spread over the banks
+constexpr int32_t HOT_STRIDE = VR_HOT_STRIDE;           // dwords per slot in LDS (the parked fields, padded to an odd count)
+constexpr int32_t HOT_COL = VR_HOT_RI ? 12 : 4;         // where the transfer-function kernels keep the colour of a real collision until its event: in the place of
+                                                        // 1/dir (15-dword slots) or of dir (12-dword slots) -- both dead between the collision and the set-up of the next segment
 struct HotStore {                      // [slot][field]: a path's 15 parked dwords are adjacent (ds_read2/ds_write2 pairs)
     uint32_t* base;
     float cam_ipos[3];                 // index-space position of the camera (wave-uniform): ipos of every `first` path, see FirstStash
@@ -128,7 +138,7 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
         p[10] = f2u(h.Tr);
         p[11] = flags(h);
-        p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z);
+        if (VR_HOT_RI) { p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z); }
     }
     // any later store: a `first` path's stash stays where it is
     __device__ __forceinline__ void save(const Hot& h, int32_t slot) const {
@@ -138,7 +148,7 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         p[4] = f2u(h.idir.x); p[5] = f2u(h.idir.y); p[6] = f2u(h.idir.z);
         p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
         p[11] = flags(h);
-        p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z);
+        if (VR_HOT_RI) { p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z); }
     }
     // a path that leaves the hot pair for an event: the march / collision code only changes seed, t, tau, Tr and the flag word
     // (state, mip); ray, far and 1/dir are still in the slot from the store that preceded the path's resume
@@ -155,7 +165,7 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         h.seed = p[0];
         h.ipos = v3{ u2f(p[1]), u2f(p[2]), u2f(p[3]) };
         h.idir = v3{ u2f(p[4]), u2f(p[5]), u2f(p[6]) };
-        h.ri = v3{ u2f(p[12]), u2f(p[13]), u2f(p[14]) };
+        h.ri = VR_HOT_RI ? v3{ u2f(p[12 % HOT_STRIDE]), u2f(p[13 % HOT_STRIDE]), u2f(p[14 % HOT_STRIDE]) } : v3{ 0.0f, 0.0f, 0.0f };      // events do not read it (begin_segment sets it)
         h.t = u2f(p[7]); h.far = u2f(p[8]); h.tau = u2f(p[9]);
         h.Tr = u2f(p[10]);
         const uint32_t f = p[11];
@@ -169,6 +179,7 @@ struct HotStore {                      // [slot][field]: a path's 15 parked dwor
         const bool first = h.first != 0;
         h.ipos = v3{ first ? cam_ipos[0] : h.ipos.x, first ? cam_ipos[1] : h.ipos.y, first ? cam_ipos[2] : h.ipos.z };
         h.Tr = first ? 1.0f : h.Tr;
+        if (!VR_HOT_RI) h.ri = rcp3_exact(h.idir);             // as begin_segment computed it
     }
 };
 // Cold path state of one wavefront in global memory (vr_trace.h ColdField): a 64-byte slot per path -- half a cache line: the 16
@@ -352,7 +363,7 @@ pathtrace_kernel(const KernelArgs A) {
     const uint32_t wave_index = blockIdx.x * 4u + (uint32_t)wave;
     float* const cold_base = A.cold_ws + (size_t)wave_index * (size_t)kColdWaveFloats;
     float* const side_base = A.cold_ws + kColdMainFloats + (size_t)wave_index * (size_t)kColdSideWaveFloats;
-#define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE, reinterpret_cast<float*>(hs.base + (SLOT) * HOT_STRIDE + 12) }
+#define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE, reinterpret_cast<float*>(hs.base + (SLOT) * HOT_STRIDE + HOT_COL) }
     // where the radiance of a parked path's pending light sample waits: vector registers (ShleBanks), or -- in the transfer-function
     // variants, which have no registers to spare (126 of 128) -- the side array
     constexpr bool kColdRegs = cold_in_regs<K>();            // the whole cold state in registers (ColdBanks); else:

@@ -597,9 +597,20 @@ VR_HD v3 sample_phase_hg(v3 dir, float g, float r0, float r1) {
 }
 VR_HD float power_heuristic(float a, float b) { return sqr(a) / (sqr(a) + sqr(b)); }
 
+// (1 / v.x, 1 / v.y, 1 / v.z), each the correctly rounded quotient (vr_math.h rcp_exact); one range test for the three
+VR_HD v3 rcp3_exact(v3 v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !VR_FAST_DEVICE
+    v3 r = v3{ rcp_newton(v.x), rcp_newton(v.y), rcp_newton(v.z) };
+    if (!(rcp_in_fast_range(v.x) & rcp_in_fast_range(v.y) & rcp_in_fast_range(v.z))) r = v3{ 1.0f / v.x, 1.0f / v.y, 1.0f / v.z };
+    return r;
+#else
+    return v3{ 1.0f / v.x, 1.0f / v.y, 1.0f / v.z };
+#endif
+}
+
 // box clip (common.glsl:157-165)
 VR_HD bool intersect_box(v3 pos, v3 dir, const float* bmin, const float* bmax, float& tnear, float& tfar) {
-    const v3 inv = v3{ 1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z };
+    const v3 inv = rcp3_exact(dir);
     const v3 lo = (v3{ bmin[0], bmin[1], bmin[2] } - pos) * inv;
     const v3 hi = (v3{ bmax[0], bmax[1], bmax[2] } - pos) * inv;
     const v3 tmin = v3{ min_(lo.x, hi.x), min_(lo.y, hi.y), min_(lo.z, hi.z) };
@@ -679,7 +690,7 @@ VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
         else h.state = segment_end_state(shadow);
         return true;
     }
-    h.ri = v3{ 1.0f / h.idir.x, 1.0f / h.idir.y, 1.0f / h.idir.z };
+    h.ri = rcp3_exact(h.idir);
     h.t = tnear + 1e-6f;
     h.tau = neg_log_1m(rng(h.seed));
     h.state = ST_MARCH;
