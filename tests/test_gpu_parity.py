@@ -62,6 +62,19 @@ def test_device_math_bit_exact():
     assert same.all(), "half2float differs at %d codes" % (~same).sum()
     u8 = np.arange(256, dtype=np.float32)
     assert np.array_equal(_bits(volren_amd.math_probe(12, u8, u8)), _bits(u8 / np.float32(255)))
+    # rcp_exact / rcp3_exact (v_rcp_f32 + Newton step + fix-up inside the verified exponent range, IEEE division outside it) == 1 / x:
+    # random bit patterns of every class, every exponent's extreme mantissas, zeros, denormals, infinities, NaN.  The full 2^32 sweep is
+    # tests/tools_rcp_exact.hip (profiles/r3f_*).
+    bits = np.concatenate([rs.randint(0, 1 << 32, 200000, dtype=np.uint64).astype(np.uint32),
+                           (np.arange(256, dtype=np.uint32)[:, None] << 23 | np.array([0, 1, 0x400000, 0x7FFFFE, 0x7FFFFF], np.uint32)[None, :]).reshape(-1),
+                           (np.arange(256, dtype=np.uint32)[:, None] << 23 | np.array([0, 1, 0x7FFFFF], np.uint32)[None, :]).reshape(-1) | np.uint32(0x80000000)])
+    x = bits.view(np.float32)
+    with np.errstate(all="ignore"):
+        want = (np.float32(1.0) / x).astype(np.float32)
+    for fn, args in ((16, (x, x)), (17, (np.full_like(x, 3.0), x)), (17, (np.full_like(x, 1e-42), x))):
+        dev = volren_amd.math_probe(fn, *args)
+        same = (_bits(dev) == _bits(want)) | (np.isnan(dev) & np.isnan(want))
+        assert same.all(), "rcp (probe %d) differs at %d inputs, e.g. %r" % (fn, (~same).sum(), x[~same][:4])
 
 
 def test_impmap_matches_oracle():

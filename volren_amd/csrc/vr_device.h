@@ -62,7 +62,8 @@ void launch_pack_tiles(const float* fb, int32_t w, int32_t h, const int32_t* til
 void launch_unpack_tiles(const float* packed, const int32_t* tiles, int32_t n_tiles, float* fb, int32_t w, int32_t h, hipStream_t stream);
 
 // unit-test probe: out[i] = f(a[i], b[i]) with the device build of vr_math.h
-// fn: 0 log 1 sin 2 cos 3 tan 4 acos 5 atan2 6 exp 7 pow 8 asin 9 a/b 10 sqrt 11 fma(a,b,a) 12 float(u8)/255
+// fn: 0 log 1 sin 2 cos 3 tan 4 acos 5 atan2 6 exp 7 pow 8 asin 9 a/b 10 sqrt 11 fma(a,b,a) 12 float(u8)/255 13 sincos 14 a*b+a 15 half->float
+//     16 rcp_exact(a) 17 rcp3_exact((a, b, a)).y
 void launch_math_probe(int32_t fn, const float* a, const float* b, float* out, int32_t n, hipStream_t stream);
 
 }  // namespace vr

@@ -490,6 +490,8 @@ math_probe_kernel(int32_t fn, const float* __restrict__ a, const float* __restri
     case 13: { float s, c; sincos_(x, s, c); r = s * y + c; break; }
     case 14: r = x * y + x; break;     // must stay two roundings (-ffp-contract=off)
     case 15: r = half2float(f2u(x)); break;     // bit pattern of x: low 16 bits = binary16
+    case 16: r = rcp_exact(x); break;
+    case 17: { const v3 q = rcp3_exact(v3{ x, y, x }); r = q.y; break; }      // the three-at-once form: y's reciprocal, range test shared with x
     default: r = nan_(); break;
     }
     out[i] = r;
