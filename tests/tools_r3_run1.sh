@@ -1,4 +1,4 @@
 set -o pipefail
-python -m pytest tests -x -q -m gpu > gpurun_out/r3p_tests.log 2>&1; rc=$?; echo "pytest rc $rc"; tail -3 gpurun_out/r3p_tests.log
-[ $rc = 0 ] || exit $rc
-bash tests/tools_collect_profiles.sh all > gpurun_out/r3p_collect.log 2>&1; echo "collect rc $?"; tail -12 gpurun_out/r3p_collect.log
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "emission or c5 or synthetic_baseline or global_majorant or scheduler or stale_cold or flags or grid_frames" > gpurun_out/r3q_tests.log 2>&1; echo "pytest rc $?"; tail -2 gpurun_out/r3q_tests.log
+AB_CASES="c5full:2048:64 c5:512:1024:64" bash tests/tools_ab.sh default noempt > gpurun_out/r3q_ab.log 2>&1
+cat gpurun_out/r3q_ab.log

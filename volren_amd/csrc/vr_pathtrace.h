@@ -70,6 +70,9 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #ifndef VR_BATCH_REGS
 #define VR_BATCH_REGS 1
 #endif
+#ifndef VR_EMISSION_BY_POINTER
+#define VR_EMISSION_BY_POINTER 1
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Wave-private path pool.
@@ -563,12 +566,13 @@ pathtrace_kernel(const KernelArgs A) {
             if (n_c > 0 && n_c >= min(VR_THR_COLLIDE, (n_c + n_m + 1) >> 1)) {
                 CollideIO<K> cio;
                 collide_idle<K>(cio);
-                if (is_c) collide_prep<K>(l, P, cio);
-                collide_load<K>(P, cio);
+                const SceneParams& PE = VR_EMISSION_BY_POINTER && K::emission != 0 ? event_args().P : P;      // see collide_prep
+                if (is_c) collide_prep<K>(l, P, PE, cio);
+                collide_load<K>(P, PE, cio);
                 if (is_c) {
                     ColdT c = VR_COLD(slot);
-                    if (lut_in_lds) collide_finish<K, ColdT, true>(l, c, P, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
-                    else collide_finish<K, ColdT, true>(l, c, P, cio, P.tf_lut);
+                    if (lut_in_lds) collide_finish<K, ColdT, true>(l, c, P, PE, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
+                    else collide_finish<K, ColdT, true>(l, c, P, PE, cio, P.tf_lut);
                 }
                 if (STATS) { st_exec[ST_COLLIDE] += 1u; st_lanes[ST_COLLIDE] += (uint32_t)n_c; }
             }

@@ -870,8 +870,11 @@ template <class K> struct CollideIO {
     TriIO tri;                   // transfer function: the 8 trilinear corners
     TapAddr ea; TapData ed;      // emission tap (camera/scatter segments with an emission grid)
 };
+// PE: where the emission grid's view and transform are read from.  The scheduler passes the kernel arguments behind a pointer there
+// (event_args(), vr_pathtrace.h): ~45 uniform dwords that only the emission tap needs are then fetched by scalar loads inside the collision
+// code instead of living in scalar registers through the whole scheduler loop (the emission kernels were the ones spilling them).
 template <class K>
-VR_HD void collide_prep(Hot& h, const SceneParams& P, CollideIO<K>& io) {
+VR_HD void collide_prep(Hot& h, const SceneParams& P, const SceneParams& PE, CollideIO<K>& io) {
     const v3 ip = axpy(h.ipos, h.t, h.idir);
     if (K::tf) {
         trilinear_prep<K::dense>(P.density, ip, io.tri);
@@ -884,10 +887,10 @@ VR_HD void collide_prep(Hot& h, const SceneParams& P, CollideIO<K>& io) {
     if (!h.shadow) {
         // lookup_emission's filter draws its 9 numbers whether or not an emission grid is bound
         if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) {
-            const v3 ie = mat4_point(P.emission_from_density, ip);
+            const v3 ie = mat4_point(PE.emission_from_density, ip);
             int32_t ex, ey, ez;
             tricubic_tap(ie, h.seed, ex, ey, ez);
-            io.ea = tap_addr<K::edense>(P.emission, ex, ey, ez);
+            io.ea = tap_addr<K::edense>(PE.emission, ex, ey, ez);
         } else {
             rng_skip9(h.seed);
         }
@@ -900,14 +903,18 @@ VR_HD void collide_idle(CollideIO<K>& io) {      // a lane that is not colliding
     if (K::tf) trilinear_idle(io.tri);
 }
 template <class K>
-VR_HD void collide_load(const SceneParams& P, CollideIO<K>& io) {      // unconditional, like march_load
+VR_HD void collide_prep(Hot& h, const SceneParams& P, CollideIO<K>& io) { collide_prep<K>(h, P, P, io); }
+template <class K>
+VR_HD void collide_load(const SceneParams& P, const SceneParams& PE, CollideIO<K>& io) {      // unconditional, like march_load
     if (K::tf) trilinear_load<K::dense>(P.density, io.tri);
     else io.d = tap_load<K::dense>(P.density, io.a);
-    if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) io.ed = tap_load<K::edense>(P.emission, io.ea);
+    if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) io.ed = tap_load<K::edense>(PE.emission, io.ea);
 }
+template <class K>
+VR_HD void collide_load(const SceneParams& P, CollideIO<K>& io) { collide_load<K>(P, P, io); }
 // CACHED: throughput and radiance of the marching path are in h.ethr / h.eL (device scheduler, see Hot); otherwise on the cold line
 template <class K, class Cold, bool CACHED = false>
-VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO<K>& io, const float* tf_lut) {
+VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const SceneParams& PE, const CollideIO<K>& io, const float* tf_lut) {
     constexpr bool USE_TF = K::tf;
     const Uniforms& u = P.u;
     const bool global = K::global == 2 ? u.integrator != 0 : K::global == 1;
@@ -923,7 +930,7 @@ VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO
         const float P_real = d * u.vol_inv_majorant;                 // global trackers only
         if (K::emission == 2 ? u.has_emission != 0 : K::emission == 1) {
             // Le += throughput * (1 - albedo) * lookup_emission(...) * d * vol_inv_majorant
-            const float tt = tap_value<K::edense>(P.emission, io.ed, io.ea.in) * u.vol_emission_norm;
+            const float tt = tap_value<K::edense>(PE.emission, io.ed, io.ea.in) * u.vol_emission_norm;
             const v3 e3 = v3{ tt, sqr(tt), sqr(sqr(tt)) };
             const v3 em = v3{ u.vol_emission_scale * sqr(e3.x), u.vol_emission_scale * sqr(e3.y), u.vol_emission_scale * sqr(e3.z) };
             const v3 oma = v3{ 1.0f - u.vol_albedo[0], 1.0f - u.vol_albedo[1], 1.0f - u.vol_albedo[2] };
@@ -966,6 +973,8 @@ VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO
     h.mipq = h.mipq > 8 ? h.mipq - 8 : 0;                  // mip = max(0, mip - 2)
     h.state = ST_MARCH;
 }
+template <class K, class Cold, bool CACHED = false>
+VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO<K>& io, const float* tf_lut) { collide_finish<K, Cold, CACHED>(h, c, P, P, io, tf_lut); }
 template <class K, class Cold>
 VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
     CollideIO<K> io;
