@@ -90,8 +90,9 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 //     register set so the marching path stays put (VR_BATCH_REGS=0 swaps it through its LDS slot instead).
 // Everything is wave-synchronous (ballots, mbcnt ranks, scalar counters): no atomics, no barriers, no spinning; the only
 // global atomic is the work-queue head.  Which lane runs which path never changes a result.
-// 1 / dir of a parked path: kept in its LDS slot (15 dwords per slot, 152 slots), or recomputed when the path is resumed (12 dwords, 188
-// slots: three exact reciprocals per resume, vr_math.h rcp_exact, against 24 % more paths per wavefront)
+// Pool size = LDS share of a wavefront (10 KiB at 4 wavefronts per SIMD) / bytes per slot.  Round 3: 1/dir of a parked path is no longer kept in its slot
+// (15 dwords, 152 slots: VR_HOT_RI=1) but recomputed when the path is resumed (three exact reciprocals, vr_math.h rcp_exact): 12 dwords in 13-dword
+// slots (odd stride) = 175 slots; 12-dword slots (188, VR_HOT_STRIDE=12) measure the same (profiles/r3f_*: the pool-size elasticity is gone beyond 152).
 #ifndef VR_HOT_RI
 #define VR_HOT_RI 0
 #endif
@@ -102,8 +103,8 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #define VR_NSLOT (VR_HOT_RI ? 152 : (VR_HOT_STRIDE == 12 ? 188 : 175))
 #endif
 constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
-// The transfer-function kernels stage the LUT (up to kLutLdsEntries vec4 = 4 KiB) in LDS and give up 12 path slots for it:
-// 4 workgroups x (140 slots x 65 B x 4 wavefronts + 4 KiB) = 158.2 KiB of the CU's 160 KiB.
+// The transfer-function kernels stage the LUT (up to kLutLdsEntries vec4 = 4 KiB) in LDS and give up 14 path slots for it:
+// 4 workgroups x (161 slots x 57 B x 4 wavefronts + 4 KiB) = 159.4 KiB of the CU's 160 KiB.
 #ifndef VR_NSLOT_TF
 #define VR_NSLOT_TF (VR_NSLOT >= 152 ? VR_NSLOT - (VR_HOT_RI ? 12 : (VR_HOT_STRIDE == 12 ? 15 : 14)) : VR_NSLOT)
 #endif
@@ -127,7 +128,7 @@ enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE
 constexpr int32_t HOT_STRIDE = VR_HOT_STRIDE;           // dwords per slot in LDS (the parked fields, padded to an odd count)
 constexpr int32_t HOT_COL = VR_HOT_RI ? 12 : 4;         // where the transfer-function kernels keep the colour of a real collision until its event: in the place of
                                                         // 1/dir (15-dword slots) or of dir (12-dword slots) -- both dead between the collision and the set-up of the next segment
-struct HotStore {                      // [slot][field]: a path's 15 parked dwords are adjacent (ds_read2/ds_write2 pairs)
+struct HotStore {                      // [slot][field]: a path's parked dwords are adjacent (ds_read2/ds_write2 pairs)
     uint32_t* base;
     float cam_ipos[3];                 // index-space position of the camera (wave-uniform): ipos of every `first` path, see FirstStash
     // mip (a multiple of 1/4 in [0,3]) rides in the flag word
