@@ -136,13 +136,18 @@ KERNEL_SOURCES = ("vr_pathtrace.h", "vr_trace.h", "vr_math.h", "vr_scene.h", "vr
 
 
 def kernel_source_sha():
-    """Fingerprint of the path-tracing kernel's sources: the PMC profile (tests/tools_collect_profiles.sh) records it, and a bench
-    line that quotes the profile's counters for kernels built from other sources says so (`stale`)."""
+    """Fingerprint of the path-tracing kernel's sources (comments and blank space stripped: only code counts): the PMC profile
+    (tests/tools_collect_profiles.sh) records it, and a bench line that quotes the profile's counters for kernels built from other
+    sources says so (`stale`)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "volren_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "volren_amd", "csrc", f), "r", encoding="utf-8", errors="replace") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)          # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                        # line comments (no string literal of these files contains //)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
