@@ -82,6 +82,28 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
 }
 }  // namespace
 
+// ---- access trace (tests/tools_coherence_by_scope.py): which 128-byte line of the majorant table a marching path's next DDA step reads, which
+// 4x4x4-voxel block (one line of the dense grid) / 8^3 brick a path at a tentative collision stands in.  One 32-bit word per lane-step:
+// bits 31..30 = 0 march / 1 collide, bits 29..0 = line id.  Test infrastructure only.
+static uint32_t* g_trace = nullptr;
+static size_t g_trace_cap = 0, g_trace_n = 0;
+static void trace_access(const Hot& h, const SceneParams& P) {
+    if (g_trace_n >= g_trace_cap) return;
+    const v3 c = axpy(h.ipos, h.t, h.idir);
+    if (h.state == ST_MARCH) {
+        if (!(h.t < h.far)) return;
+        const int32_t idx = majorant_index<2>(P.density, c, round_mip_q(h.mipq));
+        if (idx >= 0) g_trace[g_trace_n++] = (uint32_t)idx >> 6;                       // 64 fp16 cells per 128-byte line
+    } else {
+        const int32_t x = (int32_t)floor_(c.x), y = (int32_t)floor_(c.y), z = (int32_t)floor_(c.z);
+        if (x < 0 || y < 0 || z < 0) return;
+        const uint32_t sh = P.density.dense ? 2u : 3u;                                  // dense: 4x4x4 block = one line; bricks: 8^3 block = 4 lines
+        const uint32_t nx = P.density.dense ? (uint32_t)P.density.dblk[0] : (uint32_t)P.density.nb[0], ny = P.density.dense ? (uint32_t)P.density.dblk[1] : (uint32_t)P.density.nb[1];
+        const uint32_t id = (((uint32_t)z >> sh) * ny + ((uint32_t)y >> sh)) * nx + ((uint32_t)x >> sh);
+        g_trace[g_trace_n++] = (1u << 30) | (id & 0x3FFFFFFFu);
+    }
+}
+
 extern "C" {
 
 struct hk_grid_desc {
@@ -189,6 +211,7 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
                         if (l.state == ST_DONE) continue;
                         live = true;
                         if (l.state == ST_NEW) for (float& v : cold[i].v) v = nan_();         // a new path must not depend on what its cold line held
+                        if (g_trace && (l.state == ST_MARCH || l.state == ST_COLLIDE)) trace_access(l, P);
                         if (u.use_tf) lane_step<TraceCfg<true, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]); else lane_step<TraceCfg<false, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]);
                         if (++steps > (1ll << 40)) return -1;
                     }
@@ -202,6 +225,9 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
             }
     return steps;
 }
+
+void hk_set_trace(uint32_t* buf, unsigned long long cap) { g_trace = buf; g_trace_cap = (size_t)cap; g_trace_n = 0; }
+unsigned long long hk_trace_count() { return (unsigned long long)g_trace_n; }
 
 float hk_math(int fn, float x, float y) {
     switch (fn) {
