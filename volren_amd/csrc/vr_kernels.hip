@@ -148,7 +148,7 @@ static int resident_blocks(const PathtraceTuning& T, int mode, int variant, bool
         v = it->second;
     }
     const int per_cu = T.blocks_per_cu > 0 ? T.blocks_per_cu : v.second;
-    return std::min(v.first * per_cu, kMaxWorkgroups);
+    return std::min(v.first * per_cu, kMaxWorkgroups * 4 / kWgWaves);
 }
 
 size_t pathtrace_workspace_floats() { return kColdMainFloats + (size_t)kMaxWorkgroups * 4u * (size_t)kColdSideWaveFloats; }      // cold state of 4 wavefronts per resident workgroup: main slots, then the side array
@@ -175,8 +175,8 @@ void launch_pathtrace(const PathtraceTuning& T, const SceneParams& P, float* fb,
     const bool tf = P.u.use_tf != 0, stats = T.stats != nullptr;
     const int mode = fast_math ? 1 : 0;
     const int blocks = resident_blocks(T, mode, variant, tf, stats);
-    const uint32_t waves_needed = (D.n_units + 3u) / 4u;
-    const dim3 grid((unsigned)std::min<uint32_t>((uint32_t)blocks, waves_needed > 0 ? waves_needed : 1u)), block(256);
+    const uint32_t groups_needed = (D.n_units + (uint32_t)kWgWaves - 1u) / (uint32_t)kWgWaves;      // a wavefront per unit at least
+    const dim3 grid((unsigned)std::min<uint32_t>((uint32_t)blocks, groups_needed > 0 ? groups_needed : 1u)), block(256);
     if (P.u.integrator == 2 && P.u.use_tf) {
         const uint64_t items = (uint64_t)D.n_units * (uint64_t)(D.spu * 64);
         hipLaunchKernelGGL(dvr_kernel, dim3((unsigned)((items + 255) / 256)), block, 0, stream, P, sample_pool, D);

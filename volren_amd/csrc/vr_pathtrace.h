@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "vr_trace.h"
 
 namespace vr {
@@ -99,16 +101,25 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #ifndef VR_HOT_STRIDE
 #define VR_HOT_STRIDE (VR_HOT_RI ? 15 : 13)      /* odd: lanes with different slots spread over the LDS banks (12 fields + 1 pad) */
 #endif
-#ifndef VR_NSLOT
-#define VR_NSLOT (VR_HOT_RI ? 152 : (VR_HOT_STRIDE == 12 ? 188 : 175))
+// Workgroup shape.  Default: four 4-wavefront workgroups per CU.  Build-time experiment (round 3, profiles/r3h_lds_resident_majorants.txt):
+// -DVR_WG_WAVES=16 = ONE workgroup per CU whose 16 wavefronts share nothing but read-only tables in LDS -- the transfer-function LUT once per CU
+// instead of four times and (VR_MAJ_LDS) the coarse levels of the majorant table, or all of it (smoke.brick's is 18 KiB).  Measured: the workgroup
+// shape alone +-0.5 %; serving the majorant gathers from LDS c2 +-0 (its whole table resident: 28 % of the kernel's L1 accesses gone), c3 -4 %, c4 -3 %,
+// c5full -5 % -- the select between the two sources costs what the L1-hit gathers cost.  Not adopted.
+#ifndef VR_WG_WAVES
+#define VR_WG_WAVES 4
 #endif
-constexpr int32_t NSLOT = VR_NSLOT;        // <= 256 (slot ids are bytes)
-// The transfer-function kernels stage the LUT (up to kLutLdsEntries vec4 = 4 KiB) in LDS and give up 14 path slots for it:
-// 4 workgroups x (161 slots x 57 B x 4 wavefronts + 4 KiB) = 159.4 KiB of the CU's 160 KiB.
-#ifndef VR_NSLOT_TF
-#define VR_NSLOT_TF (VR_NSLOT >= 152 ? VR_NSLOT - (VR_HOT_RI ? 12 : (VR_HOT_STRIDE == 12 ? 15 : 14)) : VR_NSLOT)
+#ifndef VR_MAJ_LDS
+#define VR_MAJ_LDS 0
 #endif
+constexpr int32_t kWgWaves = VR_WG_WAVES;
+constexpr int32_t kLdsPerWorkgroup = 163840 / 16 * kWgWaves;      // 160 KiB per CU
+// The transfer-function kernels stage the LUT (up to kLutLdsEntries vec4 = 4 KiB) in LDS.
 constexpr int32_t kLutLdsEntries = 256;
+// cells of the majorant table's tail a kernel keeps in LDS: the brick kernel without transfer function 10 240 fp16 cells (20 KiB: all of a grid of up to
+// ~8 000 bricks), the dense-grid and emission kernels 5 120 (10 KiB: levels 2-3 of a 512^3 grid, level 3 of a 1024^3 one), the transfer-function kernels
+// 2 560 floats (10 KiB: their table holds TF-remapped floats)
+template <class K> constexpr int32_t maj_lds_cells() { return !VR_MAJ_LDS ? 0 : (K::tf ? 2560 : ((K::dense == 0 && K::emission == 0) ? 10240 : 5120)); }
 // Build-time experiment (round 3, -DVR_COLD_REGS=1; profiles/r3a_cold_state_in_registers.txt): cold path state in VECTOR REGISTERS
 // (ColdBanks below) instead of global memory, for the dense-grid kernel, whose paths scatter 3.2 times per sample (c4) and spend a
 // third of their memory-side traffic on the 64-byte cold slots.  Three wavefronts per SIMD instead of four leave each 168 registers:
@@ -120,12 +131,24 @@ constexpr int32_t kLutLdsEntries = 256;
 #define VR_COLD_REGS 0
 #endif
 template <class K> constexpr bool cold_in_regs() { return VR_COLD_REGS != 0 && !K::tf && K::dense == 1 && K::emission == 0; }
-template <class K> constexpr int32_t pool_slots() { return cold_in_regs<K>() ? 192 : (K::tf ? VR_NSLOT_TF : VR_NSLOT); }
 template <class K> constexpr int32_t waves_per_simd() { return cold_in_regs<K>() ? 3 : VR_WAVES_PER_SIMD; }
 
 enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
 
 constexpr int32_t HOT_STRIDE = VR_HOT_STRIDE;           // dwords per slot in LDS (the parked fields, padded to an odd count)
+// slots of a wavefront's pool: what is left of the workgroup's LDS after the shared tables, per wavefront, in slots of HOT_STRIDE dwords + Q_COUNT stack
+// bytes; at most 192 (slot ids index three register banks, ShleBanks) -- or VR_NSLOT when a build pins it
+template <class K> constexpr int32_t pool_slots() {
+#ifdef VR_NSLOT
+    return cold_in_regs<K>() ? 192 : VR_NSLOT;
+#else
+    if (cold_in_regs<K>()) return 192;
+    const int32_t shared = maj_lds_cells<K>() * (K::tf ? 4 : 2) + (K::tf ? kLutLdsEntries * 16 + 16 : kWgWaves * 256);
+    const int32_t n = (kLdsPerWorkgroup - shared) / kWgWaves / (HOT_STRIDE * 4 + Q_COUNT);
+    return n > 192 ? 192 : n;
+#endif
+}
+constexpr int32_t NSLOT = 192;             // upper bound of pool_slots (sizes the cold workspace); slot ids are bytes
 constexpr int32_t HOT_COL = VR_HOT_RI ? 12 : 4;         // where the transfer-function kernels keep the colour of a real collision until its event: in the place of
                                                         // 1/dir (15-dword slots) or of dir (12-dword slots) -- both dead between the collision and the set-up of the next segment
 struct HotStore {                      // [slot][field]: a path's parked dwords are adjacent (ds_read2/ds_write2 pairs)
@@ -193,7 +216,7 @@ struct HotStore {                      // [slot][field]: a path's parked dwords 
 // path with everything in it: c4 +3.3 %, c2 +1.1 %, same bytes moved (profiles/r2y_ab_cold_64_byte_slots.txt).  Earlier experiments:
 // group-major [group][slot][4] (same speed, more traffic), non-temporal accesses (-21 %), everything in LDS (-28 ... -42 %: the
 // pool slots it costs), profiles/r2j_layout_experiments.txt, r2m_cold_state_in_lds_experiments.txt.
-constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state workspace is sized for this many resident workgroups (launch_pathtrace clamps the grid to it)
+constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state workspace is sized for this many resident 4-wavefront units = 8192 wavefronts (launch_pathtrace clamps the grid to it)
 struct ColdGlobal {
     float* base;                       // this slot's 16 floats in the wavefront's slice of the main array
     float* side;                       // this slot's 4 floats in the wavefront's slice of the side array
@@ -355,16 +378,17 @@ __device__ __forceinline__ const KernelArgs& event_args() {
 }
 
 template <class K, bool STATS>
-__global__ void __launch_bounds__(256, waves_per_simd<K>())
+__global__ void __launch_bounds__(64 * kWgWaves, waves_per_simd<K>())
 pathtrace_kernel(const KernelArgs A) {
     const SceneParams& P = A.P;           // hot pair only; events use event_args()
     const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     constexpr int32_t NS = pool_slots<K>();           // path slots of this kernel's wavefronts (shadows the global maximum below)
 
-    __shared__ uint8_t lds_q[4 * Q_COUNT * NS];
+    static_assert(!cold_in_regs<K>() || kWgWaves == 4, "the cold-state-in-registers experiment runs 3 workgroups of 4 wavefronts per CU");
+    __shared__ uint8_t lds_q[kWgWaves * Q_COUNT * NS];
     uint8_t* const q = lds_q + wave * (Q_COUNT * NS);
     // per-wavefront slices of the workspace: the cold fields of its NSLOT paths
-    const uint32_t wave_index = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t wave_index = blockIdx.x * (uint32_t)kWgWaves + (uint32_t)wave;
     float* const cold_base = A.cold_ws + (size_t)wave_index * (size_t)kColdWaveFloats;
     float* const side_base = A.cold_ws + kColdMainFloats + (size_t)wave_index * (size_t)kColdSideWaveFloats;
 #define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE, reinterpret_cast<float*>(hs.base + (SLOT) * HOT_STRIDE + HOT_COL) }
@@ -379,7 +403,7 @@ pathtrace_kernel(const KernelArgs A) {
     static_assert(!kItemInRegs || K::emission == 0, "with an emission grid do_new writes the sample-buffer slot to the side array (no stash to park it from)");
     static_assert(NS <= 192, "ShleBanks holds 3 x 64 slots");
     static_assert(!kColdRegs || (K::emission == 0 && !K::tf), "ColdBanks: no marching-path access to the cold state (EmissionCache), C_COL not wired");
-    __shared__ uint32_t lds_stage[kShleInRegs || kColdRegs ? 4 * 64 : 4];
+    __shared__ uint32_t lds_stage[kShleInRegs || kColdRegs ? kWgWaves * 64 : 4];
     uint32_t* const stage = lds_stage + (kShleInRegs || kColdRegs ? wave * 64 : 0);
     ShleBanks banks;
     banks.b[0] = banks.b[1] = banks.b[2] = v3{ 0, 0, 0 };
@@ -391,7 +415,7 @@ pathtrace_kernel(const KernelArgs A) {
 #pragma unroll
             for (int f = 0; f < kBankFields; ++f) cb.v[k][f] = 0.0f;
     }
-    __shared__ uint32_t lds_hot[4 * HOT_STRIDE * NS];
+    __shared__ uint32_t lds_hot[kWgWaves * HOT_STRIDE * NS];
     HotStore hs;
     hs.base = lds_hot + wave * (HOT_STRIDE * NS);
     {   // wave-uniform: keep it in scalar registers
@@ -405,11 +429,27 @@ pathtrace_kernel(const KernelArgs A) {
     __shared__ float lds_lut[K::tf ? 4 * kLutLdsEntries : 4];
     const bool lut_in_lds = K::tf && P.u.tf_size <= (uint32_t)kLutLdsEntries;
     const bool emission_on = K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1;
-    if (K::tf) {
-        if (lut_in_lds)
-            for (uint32_t i = threadIdx.x; i < 4u * P.u.tf_size; i += 256u) lds_lut[i] = P.tf_lut[i];
-        __syncthreads();                              // the only workgroup barrier of the kernel: before the persistent loop
+    // the tail of the majorant table: cells [maj_first, maj_end) = the coarsest levels that fit (level offsets: vr_scene.h); maj_first = maj_end: none
+    constexpr int32_t kMajCells = maj_lds_cells<K>();
+    typedef typename std::conditional<K::tf, float, uint16_t>::type MajT;
+    __shared__ MajT lds_maj[kMajCells > 0 ? kMajCells : 1];
+    int32_t maj_first = 0x7FFFFFFF;
+    if (kMajCells > 0) {
+        const uint32_t k = (uint32_t)(P.density.mshift[0] + P.density.mshift[1] + P.density.mshift[2]);
+        const int32_t maj_end = (int32_t)majorant_padded_cells(k);
+        maj_first = maj_end;
+#pragma unroll
+        for (int mip = 3; mip >= 0; --mip) {
+            const int32_t off = (int32_t)majorant_level_offset(k, (uint32_t)mip);
+            if (maj_end - off <= kMajCells) maj_first = off;
+        }
+        maj_first = __builtin_amdgcn_readfirstlane(maj_first);
+        for (int32_t i = (int32_t)threadIdx.x; i < maj_end - maj_first; i += 64 * kWgWaves)
+            lds_maj[i] = K::tf ? (MajT)P.density.majorant[maj_first + i] : (MajT)P.density.majorant16[maj_first + i];
     }
+    if (K::tf && lut_in_lds)
+        for (uint32_t i = threadIdx.x; i < 4u * P.u.tf_size; i += 64u * (uint32_t)kWgWaves) lds_lut[i] = P.tf_lut[i];
+    if (K::tf || kMajCells > 0) __syncthreads();      // the only workgroup barrier of the kernel: before the persistent loop
 
     // scheduler thresholds, one byte each in two scalars: batch sizes that trigger NEW / NEE / POSTNEE / ESCAPE, the low-water
     // mark of live paths ("hungry"), the slots in use (diagnostic cap)
@@ -531,7 +571,8 @@ pathtrace_kernel(const KernelArgs A) {
             MarchIO mio;
             march_idle(mio);
             if (is_m) march_prep<K::dense>(l, P, mio);
-            march_load<K::tf>(P, mio);
+            if (kMajCells > 0) march_load_lds<K::tf, MajT>(P, mio, lds_maj, maj_first);
+            else march_load<K::tf>(P, mio);
 #if VR_MARCH_LOADS_PINNED
             // Both majorants must have been REQUESTED before the first is used.  Left alone, the compiler sinks each load into the
             // conditional block of march_finish that consumes it (load, wait, test, load, wait: two dependent round trips); an

@@ -53,7 +53,7 @@ static PtKernel pick(bool tf, bool stats) {
 
 extern "C" int VR_PT_CAT(vr_pt_occupancy_, VR_PT_VARIANT, VR_PT_SUFFIX)(int tf, int stats) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vr::pick(tf != 0, stats != 0), 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vr::pick(tf != 0, stats != 0), 64 * vr::kWgWaves, 0) != hipSuccess || per_cu <= 0) per_cu = 16 / vr::kWgWaves;
     return per_cu;
 }
 // P, D, S: SceneParams, LaunchDesc, SchedParams (plain data, same layout in both builds)
@@ -64,5 +64,5 @@ extern "C" void VR_PT_CAT(vr_pt_launch_, VR_PT_VARIANT, VR_PT_SUFFIX)(int tf, in
     A.D = *static_cast<const vr::LaunchDesc*>(D);
     A.S = *static_cast<const vr::SchedParams*>(S);
     A.sbuf = sbuf; A.cold_ws = cold_ws; A.status = status; A.stats = stats_buf;
-    hipLaunchKernelGGL(vr::pick(tf != 0, stats != 0), dim3(grid), dim3(256), 0, stream, A);
+    hipLaunchKernelGGL(vr::pick(tf != 0, stats != 0), dim3(grid), dim3(64 * vr::kWgWaves), 0, stream, A);
 }

@@ -601,7 +601,7 @@ VR_HD float power_heuristic(float a, float b) { return sqr(a) / (sqr(a) + sqr(b)
 VR_HD v3 rcp3_exact(v3 v) {
 #if defined(__HIP_DEVICE_COMPILE__) && !VR_FAST_DEVICE
     v3 r = v3{ rcp_newton(v.x), rcp_newton(v.y), rcp_newton(v.z) };
-    if (!(rcp_in_fast_range(v.x) & rcp_in_fast_range(v.y) & rcp_in_fast_range(v.z))) r = v3{ 1.0f / v.x, 1.0f / v.y, 1.0f / v.z };
+    if (!((int)rcp_in_fast_range(v.x) & (int)rcp_in_fast_range(v.y) & (int)rcp_in_fast_range(v.z))) r = v3{ 1.0f / v.x, 1.0f / v.y, 1.0f / v.z };
     return r;
 #else
     return v3{ 1.0f / v.x, 1.0f / v.y, 1.0f / v.z };
@@ -765,6 +765,25 @@ template <bool TF>
 VR_HD void march_load(const SceneParams& P, MarchIO& io) {
     io.maj1 = majorant_fetch<TF>(P.density, io.i1);
     io.maj2 = majorant_fetch<TF>(P.density, io.i2);
+}
+// The same loads when the tail of the majorant table -- cells [first, end): the coarse levels, or the whole table of a small grid -- has been copied
+// to LDS (vr_pathtrace.h): a lane whose cell lies there reads the copy and sends its global load to cell 0, which all such lanes share (one
+// line); when the whole table is resident (first == 0, wave-uniform) no global load is issued at all.  T: uint16_t (raw fp16) or float (TF).
+template <bool TF, class T>
+VR_HD uint32_t majorant_fetch_lds(const GridView& g, int32_t idx, const T* lds, int32_t first, bool all_resident) {
+    const int32_t i = idx < 0 ? 0 : idx;
+    const bool in_lds = i >= first;
+    const T s = lds[in_lds ? i - first : 0];
+    const uint32_t sv = TF ? f2u((float)s) : (uint32_t)s;
+    if (all_resident) return sv;
+    const uint32_t gv = majorant_fetch<TF>(g, in_lds ? 0 : i);
+    return in_lds ? sv : gv;
+}
+template <bool TF, class T>
+VR_HD void march_load_lds(const SceneParams& P, MarchIO& io, const T* lds, int32_t first) {
+    const bool all_resident = first == 0;
+    io.maj1 = majorant_fetch_lds<TF, T>(P.density, io.i1, lds, first, all_resident);
+    io.maj2 = majorant_fetch_lds<TF, T>(P.density, io.i2, lds, first, all_resident);
 }
 template <bool TF>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
