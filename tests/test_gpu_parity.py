@@ -327,6 +327,41 @@ def _crop_bricks(a, nbc):
     return out
 
 
+def test_dense_fp16_density_with_emission_grid():
+    """The one combination no specialised kernel serves -- a dense fp16 density grid together with a (brick) temperature grid, with and without a
+    transfer function -- runs on the everything-at-run-time variant (vr_kernels.hip pathtrace_variant -> 3): bit for bit the oracle's image."""
+    from oracle import binding as ob
+    import encoder_ref
+    import volren_amd
+    n = 48
+    dens = scenes.synthetic_density(n)
+    temp = np.clip(dens * 0.15 + 0.05 * scenes.synthetic_density(n, seed=5), 0, None).astype(np.float32)
+    r = volren_amd.Renderer(80, 64)
+    r.load_envmap(scenes.HDR)
+    r.set_volume_dense_f16(dens, commit=False)
+    r.set_volume_dense(temp, name="temperature", commit=True)
+    o = ob.OracleRenderer(80, 64)
+    o.load_envmap(scenes.HDR)
+    gt = encoder_ref.encode(temp)
+    gt.extent = (n, n, n)
+    gt.c.extent[:] = gt.extent
+    o.set_volume(encoder_ref.encode_dense_fp16(dens), emission=gt, majorant_emission=float(temp.max()))
+    for x in (r, o):
+        x.cam_fov, x.bounces, x.albedo, x.phase, x.density_scale, x.emission_scale = 40.0, 12, (0.7, 0.8, 0.9), 0.2, 60.0, 80.0
+    r.render(6)
+    fb = r.framebuffer()
+    assert fb[..., :3].max() > 0 and fb[..., 3].max() > 0
+    _assert_same(fb, o.render(6), "dense fp16 density + emission grid")
+    for x in (r, o):
+        x.load_transferfunc(scenes.LUT)
+        x.reset() if hasattr(x, "reset") else None
+    o.sample = 0
+    if hasattr(o, "fb"):
+        o.fb[:] = 0
+    r.render(4)
+    _assert_same(r.framebuffer(), o.render(4), "dense fp16 density + emission grid + transfer function")
+
+
 @pytest.mark.parametrize("nbc", [(5, 3, 7), (1, 2, 1), (8, 7, 3)])
 def test_odd_brick_counts(nbc):
     """Brick counts that are neither powers of two nor multiples of 8 (a .brick file may hold any): exercises the padded
