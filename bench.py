@@ -266,7 +266,7 @@ class Bench:
         if tp and "hbm_bytes_per_sample" in tp:
             traffic = tp["hbm_bytes_per_sample"] * m["samples_per_launch"]
             traffic_src = {"from_profile": tp_file, "stale": bool(stale),
-                           "note": "not measured by this run: rocprofv3 --pmc passes of %s, scaled to this launch's samples%s" % (
+                           "note": "not measured by this run: rocprofv3 --pmc passes of %s (bytes = 2 x FETCH_SIZE + WRITE_SIZE: profiles/r3j_fetch_size_calibration.txt), scaled to this launch's samples%s" % (
                                tp.get("command", "?"), "; the kernel sources have changed since that profile was taken" if stale else "")}
         use_em = cfg.startswith("c5")
         variant = "dense" if cfg.startswith("c4") else ("emission" if use_em else "brick")

@@ -39,7 +39,7 @@ def merge(summary, target, names):
             continue
         o, n = old["configs"][cfg], summary[tag]
         o["samples"] = n["samples"]
-        for f in ("fetch_bytes_per_sample", "write_bytes_per_sample", "hbm_bytes_per_sample", "l2_hit_rate", "per_sample", "lane_utilisation", "wave_cycles_share"):
+        for f in ("fetch_bytes_per_sample", "fetch_size_counter_bytes_per_sample", "write_bytes_per_sample", "hbm_bytes_per_sample", "l2_hit_rate", "per_sample", "lane_utilisation", "wave_cycles_share"):
             o[f] = n[f]
         o["traffic_over_algorithmic"] = round(n["hbm_bytes_per_sample"] / o["algorithmic_bytes_per_sample"], 2)
         o.setdefault("tcp", {}).update({"l2_read_latency_cycles": n["tcp"]["l2_read_latency_cycles"], "pending_stall_cycles_per_sample": n["tcp"]["pending_stall_per_sample"]})
@@ -64,9 +64,14 @@ def main():
         if not c:
             continue
         g = lambda k: c.get(k, float("nan"))
-        fetch, write = g("FETCH_SIZE") * 1024.0 / samples, g("WRITE_SIZE") * 1024.0 / samples
+        # FETCH_SIZE tallies every memory-side read request at 64 bytes, but a request fills a whole 128-byte line -- for coalesced streams (the guide's
+        # "reports exactly 1/2", MI355X_MICROARCH.md HBM) and, calibrated on this kernel's own patterns (tests/tools_fetch_calibration.hip,
+        # profiles/r3j_fetch_size_calibration.txt), for divergent dword / dwordx4 gathers and 64-byte slot reads alike: 1 request per line, 64 B reported.
+        # WRITE_SIZE is exact for its 32-byte sector and 16-byte coalesced writes.  Hence fetch = 2 x FETCH_SIZE.
+        fetch_raw = g("FETCH_SIZE") * 1024.0 / samples
+        fetch, write = 2.0 * fetch_raw, g("WRITE_SIZE") * 1024.0 / samples
         hit, miss = g("TCC_HIT_sum"), g("TCC_MISS_sum")
-        e = {"samples": int(samples), "fetch_bytes_per_sample": round(fetch, 1), "write_bytes_per_sample": round(write, 1),
+        e = {"samples": int(samples), "fetch_bytes_per_sample": round(fetch, 1), "fetch_size_counter_bytes_per_sample": round(fetch_raw, 1), "write_bytes_per_sample": round(write, 1),
              "hbm_bytes_per_sample": round(fetch + write, 1), "l2_hit_rate": round(hit / (hit + miss), 3),
              "per_sample": {"valu": round(g("SQ_INSTS_VALU") / samples, 3),
                             "salu": round(g("SQ_INSTS_SALU") / samples, 3), "lds": round(g("SQ_INSTS_LDS") / samples, 4),

@@ -13,7 +13,20 @@ shutil.copy(os.path.join(P, "pmc_summary.json"), os.path.join(ROOT, "profiles", 
 line = [x for x in open(os.path.join(P, "bench_under_rocprof.json")) if x.startswith("{")][-1]
 d = json.loads(line)
 json.dump(d, open(os.path.join(ROOT, "profiles", "r3_bench.json"), "w"), indent=1)
+# the traffic profile: the committed skeleton refreshed from the PMC passes under gpurun_out/prof (re-condensed here, so that a change of
+# tools_pmc_summary.py does not need a new GPU run)
+import subprocess
+summary = subprocess.check_output([sys.executable, os.path.join(ROOT, "tests", "tools_pmc_summary.py"), P, "c2=%d" % (2 * 1024 * 1024 * 128), "c4_512=%d" % (2 * 1024 * 1024 * 32),
+                                   "c3=%d" % (2 * 1024 * 1024 * 128), "c5full=%d" % (2 * 2048 * 2048 * 16)])
+open(os.path.join(P, "pmc_summary.json"), "wb").write(summary)
+shutil.copy(os.path.join(P, "pmc_summary.json"), os.path.join(ROOT, "profiles", "r3_pmc_summary.json"))
+shutil.copy(os.path.join(ROOT, "profiles", "r3_hbm_traffic.json"), os.path.join(P, "r3_hbm_traffic.json"))
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "tools_pmc_summary.py"), "--merge", os.path.join(P, "pmc_summary.json"), os.path.join(P, "r3_hbm_traffic.json"),
+                       "c2=c2", "c4=c4_512", "c3=c3", "c5full=c5full"])
 t = json.load(open(os.path.join(P, "r3_hbm_traffic.json")))
+t["note"] = ("fetch_bytes_per_sample = 2 x rocprofv3 FETCH_SIZE (every read request fills a 128-byte line and is tallied at 64 B: MI355X_MICROARCH.md 'HBM' for coalesced streams, "
+             "tests/tools_fetch_calibration.hip / profiles/r3j_fetch_size_calibration.txt for this kernel's gathers and slot reads); WRITE_SIZE is exact; both are L2<->fabric bytes "
+             "(Infinity-Cache hits included)")
 alg = {"c2": d["roofline"]["bytes_per_sample"]}
 for c in d.get("configs", []):
     key = {"c3": "c3", "c4": "c4", "c5full@2048x2048x4096": "c5full"}.get(c["name"])
