@@ -135,7 +135,16 @@ template <class K> constexpr int32_t waves_per_simd() { return cold_in_regs<K>()
 
 enum PoolStack : int32_t { Q_READY = 0, Q_NEE = 1, Q_POST = 2, Q_ESC = 3, Q_FREE = 4, Q_COUNT = 5 };
 
-constexpr int32_t HOT_STRIDE = VR_HOT_STRIDE;           // dwords per slot in LDS (the parked fields, padded to an odd count)
+// Lazy first cold line in the emission kernel too (round 3).  With an emission grid every tentative collision of a camera segment adds emitted light to the
+// path's radiance, so until round 3 do_new wrote the whole cold line up front (80 bytes per sample) and every resume / park of a camera segment moved
+// throughput and radiance through it -- also for the majority of samples that never scatter.  Now the radiance of a `first` path waits in three more dwords
+// of its LDS slot (15-dword slots, 153 of them, in the emission kernel only) and its throughput is 1: such a path touches no cold line at all.
+#ifndef VR_LAZY_EMISSION
+#define VR_LAZY_EMISSION 1
+#endif
+template <class K> constexpr bool lazy_emission() { return VR_LAZY_EMISSION != 0 && !VR_HOT_RI && K::emission == 1; }
+template <class K> constexpr int32_t hot_stride() { return lazy_emission<K>() ? 15 : VR_HOT_STRIDE; }      // dwords per slot in LDS (the parked fields, padded to an odd count)
+constexpr int32_t HOT_EL = 12;                           // lazy_emission kernels: radiance of a `first` path, dwords 12..14 of its slot
 // slots of a wavefront's pool: what is left of the workgroup's LDS after the shared tables, per wavefront, in slots of HOT_STRIDE dwords + Q_COUNT stack
 // bytes; at most 192 (slot ids index three register banks, ShleBanks) -- or VR_NSLOT when a build pins it
 template <class K> constexpr int32_t pool_slots() {
@@ -144,15 +153,20 @@ template <class K> constexpr int32_t pool_slots() {
 #else
     if (cold_in_regs<K>()) return 192;
     const int32_t shared = maj_lds_cells<K>() * (K::tf ? 4 : 2) + (K::tf ? kLutLdsEntries * 16 + 16 : kWgWaves * 256);
-    const int32_t n = (kLdsPerWorkgroup - shared) / kWgWaves / (HOT_STRIDE * 4 + Q_COUNT);
+    const int32_t n = (kLdsPerWorkgroup - shared) / kWgWaves / (hot_stride<K>() * 4 + Q_COUNT);
     return n > 192 ? 192 : n;
 #endif
 }
 constexpr int32_t NSLOT = 192;             // upper bound of pool_slots (sizes the cold workspace); slot ids are bytes
 constexpr int32_t HOT_COL = VR_HOT_RI ? 12 : 4;         // where the transfer-function kernels keep the colour of a real collision until its event: in the place of
                                                         // 1/dir (15-dword slots) or of dir (12-dword slots) -- both dead between the collision and the set-up of the next segment
-struct HotStore {                      // [slot][field]: a path's parked dwords are adjacent (ds_read2/ds_write2 pairs)
+template <int32_t HOT_STRIDE>
+struct HotStoreT {                     // [slot][field]: a path's parked dwords are adjacent (ds_read2/ds_write2 pairs)
+    static constexpr int32_t kStride = HOT_STRIDE;
     uint32_t* base;
+    // lazy_emission kernels: the radiance a `first` path has gathered so far (Hot::eL) waits in its slot
+    __device__ __forceinline__ void save_first_radiance(v3 eL, int32_t slot) const { uint32_t* p = base + slot * HOT_STRIDE + HOT_EL; p[0] = f2u(eL.x); p[1] = f2u(eL.y); p[2] = f2u(eL.z); }
+    __device__ __forceinline__ v3 load_first_radiance(int32_t slot) const { const uint32_t* p = base + slot * HOT_STRIDE + HOT_EL; return v3{ u2f(p[0]), u2f(p[1]), u2f(p[2]) }; }
     float cam_ipos[3];                 // index-space position of the camera (wave-uniform): ipos of every `first` path, see FirstStash
     // mip (a multiple of 1/4 in [0,3]) rides in the flag word
     __device__ __forceinline__ static uint32_t flags(const Hot& h) { return (uint32_t)h.state | ((uint32_t)h.shadow << 8) | ((uint32_t)h.first << 12) | ((uint32_t)h.mipq << 16); }
@@ -391,7 +405,7 @@ pathtrace_kernel(const KernelArgs A) {
     const uint32_t wave_index = blockIdx.x * (uint32_t)kWgWaves + (uint32_t)wave;
     float* const cold_base = A.cold_ws + (size_t)wave_index * (size_t)kColdWaveFloats;
     float* const side_base = A.cold_ws + kColdMainFloats + (size_t)wave_index * (size_t)kColdSideWaveFloats;
-#define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE, reinterpret_cast<float*>(hs.base + (SLOT) * HOT_STRIDE + HOT_COL) }
+#define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE, reinterpret_cast<float*>(hs.base + (SLOT) * HS + HOT_COL) }
     // where the radiance of a parked path's pending light sample waits: vector registers (ShleBanks), or -- in the transfer-function
     // variants, which have no registers to spare (126 of 128) -- the side array
     constexpr bool kColdRegs = cold_in_regs<K>();            // the whole cold state in registers (ColdBanks); else:
@@ -415,9 +429,11 @@ pathtrace_kernel(const KernelArgs A) {
 #pragma unroll
             for (int f = 0; f < kBankFields; ++f) cb.v[k][f] = 0.0f;
     }
-    __shared__ uint32_t lds_hot[kWgWaves * HOT_STRIDE * NS];
-    HotStore hs;
-    hs.base = lds_hot + wave * (HOT_STRIDE * NS);
+    constexpr int32_t HS = hot_stride<K>();
+    constexpr bool kLazyEm = lazy_emission<K>();
+    __shared__ uint32_t lds_hot[kWgWaves * HS * NS];
+    HotStoreT<HS> hs;
+    hs.base = lds_hot + wave * (HS * NS);
     {   // wave-uniform: keep it in scalar registers
         const v3 ci = mat4_point(P.u.vol_density_inv_transform, v3{ P.u.cam_pos[0], P.u.cam_pos[1], P.u.cam_pos[2] });      // == first_resume
         hs.cam_ipos[0] = u2f(__builtin_amdgcn_readfirstlane(f2u(ci.x)));
@@ -547,8 +563,8 @@ pathtrace_kernel(const KernelArgs A) {
                     if (r < take) {
                         slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load_resume(l, slot);
                         if (emission_on && !l.shadow) {              // EmissionCache (vr_trace.h Hot): the collisions of this segment add to L
-                            const ColdT c = VR_COLD(slot);
-                            l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L);
+                            if (kLazyEm && l.first) { l.ethr = v3{ 1.0f, 1.0f, 1.0f }; l.eL = hs.load_first_radiance(slot); }      // no cold line yet
+                            else { const ColdT c = VR_COLD(slot); l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L); }
                         }
                     }
                 }
@@ -632,7 +648,10 @@ pathtrace_kernel(const KernelArgs A) {
             if (wave_ballot(ps >= 0)) {
                 if (ps >= 0) {
                     hs.save_marched(l, slot);
-                    if (emission_on && !l.shadow) { ColdT c = VR_COLD(slot); st3(c, C_L, l.eL); }      // EmissionCache: L back to the cold line
+                    if (emission_on && !l.shadow) {                                                    // EmissionCache: L back to the cold line, or -- a path without one -- to its slot
+                        if (kLazyEm && l.first) hs.save_first_radiance(l.eL, slot);
+                        else { ColdT c = VR_COLD(slot); st3(c, C_L, l.eL); }
+                    }
                 }
                 VR_PUSH(Q_NEE, cnt_nee, ps == ST_NEE, slot);
                 VR_PUSH(Q_POST, cnt_post, ps == ST_POSTNEE, slot);
@@ -671,7 +690,7 @@ pathtrace_kernel(const KernelArgs A) {
                 n = min(64, cnt_esc);
                 VR_STAT(ST_ESCAPE, n);
                 int32_t bs = -1;
-                if (lane < n) { bs = q[Q_ESC * NS + cnt_esc - 1 - lane]; hs.load(b, bs); }
+                if (lane < n) { bs = q[Q_ESC * NS + cnt_esc - 1 - lane]; hs.load(b, bs); if (kLazyEm && b.first) b.eL = hs.load_first_radiance(bs); }
                 if (kItemInRegs) b.item = item_fetch(banks, lane, bs);                      // all lanes
                 if constexpr (kColdRegs) {
                     ColdLocal c;
@@ -688,7 +707,7 @@ pathtrace_kernel(const KernelArgs A) {
                     const ColdT c = VR_COLD(b.first ? 0 : bs);
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
-                    do_escape<ColdT, kItemInRegs>(b, c, E.P, w);          // writes the sample; the slot becomes free
+                    do_escape<ColdT, kItemInRegs, kLazyEm>(b, c, E.P, w);          // writes the sample; the slot becomes free
                 }
                 cnt_esc -= n;
                 VR_ROUTE_B(bs);                                            // ST_NEW: the slot is free again
@@ -747,8 +766,9 @@ pathtrace_kernel(const KernelArgs A) {
                         bs = q[Q_FREE * NS + cnt_free - 1 - lane];
                         hot_init(b);
                         ColdT c = VR_COLD(bs);
-                        do_new<K>(b, c, event_args().P, wu, cursor + (uint32_t)lane);
+                        do_new<K, ColdT, kLazyEm>(b, c, event_args().P, wu, cursor + (uint32_t)lane);
                         hs.save_new(b, bs);
+                        if (kLazyEm) hs.save_first_radiance(v3{ 0.0f, 0.0f, 0.0f }, bs);
                     }
                     cnt_free -= n;
                     cursor += (uint32_t)n;
@@ -778,9 +798,10 @@ pathtrace_kernel(const KernelArgs A) {
                 } else
                 if (lane < n) {
                     was_first = b.first != 0; first_item = f2u(b.Tr);      // a path's first collision: its sample-buffer slot is in the stash
+                    if (kLazyEm && b.first) b.eL = hs.load_first_radiance(bs);
                     ColdT c = VR_COLD(bs);
                     const ColdT crd = VR_COLD(b.first ? 0 : bs);      // first scatter of a path: nothing to read yet (do_nee)
-                    do_nee<K, ColdT, kShleInRegs, kItemInRegs>(b, c, crd, event_args().P);
+                    do_nee<K, ColdT, kShleInRegs, kItemInRegs, kLazyEm>(b, c, crd, event_args().P);
                     hs.save(b, bs);
                 }
                 if (kShleInRegs) shle_park<kItemInRegs>(banks, stage, lane, bs >= 0, bs, b.shle, was_first, first_item);      // all lanes: the light samples go to their slots' home lanes

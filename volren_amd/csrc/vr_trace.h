@@ -698,7 +698,8 @@ VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
 }
 
 // pathtracer_brick.glsl:27-30 + common.glsl:76-80; the lane has just been given `item` (< n_items)
-template <class K, class Cold>
+// LAZY_EM: also with an emission grid no cold line is written (the scheduler keeps the radiance of a `first` path in its parked hot state: vr_pathtrace.h)
+template <class K, class Cold, bool LAZY_EM = false>
 VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uint32_t item) {
     const int32_t W = P.u.resolution[0], H = P.u.resolution[1];
     const int32_t px = wu.px0 + (int32_t)(item & 7u), py = wu.py0 + (int32_t)((item >> 3) & 7u);
@@ -713,7 +714,7 @@ VR_HD void do_new(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, uin
     const bool hit = begin_segment<K>(h, P, pos, dir, 0);
     // With an emission grid the collision code accumulates into the cold line during the camera segment: then the line is
     // initialised here; otherwise not at all (FirstStash).  A ray that misses the box never collides: always a `first` path.
-    const bool lazy = !hit || !(K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1);
+    const bool lazy = LAZY_EM || !hit || !(K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1);
     if (!lazy) {
         st3(c, C_POS, pos); st3(c, C_DIR, dir);
         st3(c, C_L, v3{ 0, 0, 0 }); st3(c, C_THR, v3{ 1, 1, 1 });
@@ -1009,7 +1010,8 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
 // the path state into scratch memory.
 // SHLE_IN_HOT: the radiance of the light sample goes to h.shle (the scheduler parks it in registers) instead of the side array;
 // ITEM_IN_HOT: likewise the path's slot in the sample buffer (h.item)
-template <class K, class Cold, bool SHLE_IN_HOT = false, bool ITEM_IN_HOT = false>
+// FIRST_L_IN_HOT: the radiance a `first` path gathered on its camera segment (emission) is in h.eL instead of being 0
+template <class K, class Cold, bool SHLE_IN_HOT = false, bool ITEM_IN_HOT = false, bool FIRST_L_IN_HOT = false>
 VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     const bool first = h.first != 0;
     v3 dir = ld3(crd, C_DIR), pos0 = ld3(crd, C_POS), thr = ld3(crd, C_THR);
@@ -1028,7 +1030,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     if (first) {
         // what do_new left unwritten
         st3(c, C_DIR, dir); stu(c, C_NPATHS, 0u);
-        st3(c, C_L, v3{ 0, 0, 0 });
+        st3(c, C_L, FIRST_L_IN_HOT ? h.eL : v3{ 0, 0, 0 });
         if (!ITEM_IN_HOT) stu(c, C_ITEM, f2u(h.Tr));       // else the scheduler takes it from the stash (h.Tr) before this call
         c.st(C_FP, 0.0f);
     }
@@ -1084,13 +1086,14 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
 // common.glsl:644-651
 // `c` of a `first` path (never scattered: L = 0, throughput 1; direction and sample slot in the stash) is only read and the
 // values discarded: the scheduler points it at a line the batch shares (see do_nee)
-template <class Cold, bool ITEM_IN_HOT = false>
+template <class Cold, bool ITEM_IN_HOT = false, bool FIRST_L_IN_HOT = false>
 VR_HD void do_escape(Hot& h, const Cold& c, const SceneParams& P, const WorkUnit& wu) {
     const bool first = h.first != 0;
     v3 L = ld3(c, C_L), thr = ld3(c, C_THR), dir = ld3(c, C_DIR);
     uint32_t n_paths = ldu(c, C_NPATHS), item = ITEM_IN_HOT ? h.item : ldu(c, C_ITEM);
     const float f_p = c.ld(C_FP);
-    L = v3{ first ? 0.0f : L.x, first ? 0.0f : L.y, first ? 0.0f : L.z };
+    const v3 L_first = FIRST_L_IN_HOT ? h.eL : v3{ 0.0f, 0.0f, 0.0f };
+    L = v3{ first ? L_first.x : L.x, first ? L_first.y : L.y, first ? L_first.z : L.z };
     thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
     dir = v3{ first ? h.ipos.x : dir.x, first ? h.ipos.y : dir.y, first ? h.ipos.z : dir.z };
     n_paths = first ? 0u : n_paths;
