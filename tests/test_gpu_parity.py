@@ -893,6 +893,47 @@ def _hip_emission_scene(w, h):
     return r
 
 
+def _oracle_emission_scene(w, h):
+    from oracle import binding as ob
+    import encoder_ref
+    dens = scenes.synthetic_density(40)
+    temp = np.clip(dens * 0.2 + 0.1 * scenes.synthetic_density(40, seed=99), 0, None).astype(np.float32)
+    at = encoder_ref.encode_arrays(temp)
+    o = ob.OracleRenderer(w, h)
+    o.load_envmap(scenes.HDR)
+    o.set_volume(encoder_ref.encode(dens), emission=encoder_ref.encode(temp), majorant_emission=at["min_maj"][1])
+    o.cam_fov, o.bounces, o.albedo, o.emission_scale = 40.0, 8, (0.7, 0.8, 0.9), 50.0
+    return o
+
+
+@pytest.mark.parametrize("variant", ["lut", "lut_window_env", "global_trackers", "global_trackers_lut", "one_bounce_dark", "crop_no_env", "thin"])
+def test_emission_kernel_variants(variant):
+    """The emission grid together with the other switches -- a transfer function (the TF + emission kernel instance: collision colour and the lazy
+    first line's radiance share a path's LDS slot), the global-majorant trackers (run-time variant), bounce cap / roulette, crop box, hidden
+    environment, a thin medium in which most paths never scatter (every one of them a lazy first line): bit for bit the oracle's image."""
+    w, h, spp = 64, 48, 5
+    r, o = _hip_emission_scene(w, h), _oracle_emission_scene(w, h)
+    fields = {
+        "lut": dict(),
+        "lut_window_env": dict(tf_window_left=0.05, tf_window_width=0.5, show_environment=True),
+        "global_trackers": dict(integrator=1),
+        "global_trackers_lut": dict(integrator=1),
+        "one_bounce_dark": dict(bounces=1, albedo=(0.05, 0.05, 0.05)),
+        "crop_no_env": dict(vol_clip_min=(0.1, 0.2, 0.0), vol_clip_max=(0.8, 0.9, 0.7), show_environment=False),
+        "thin": dict(density_scale=4.0),
+    }[variant]
+    if "lut" in variant:
+        r.load_transferfunc(scenes.LUT)
+        o.load_transferfunc(scenes.LUT)
+    for k, v in fields.items():
+        setattr(r, k, v)
+        setattr(o, k, v)
+    r.render(spp)
+    fb = r.framebuffer()
+    assert np.isfinite(fb).all() and fb[..., :3].max() > 0
+    _assert_same(fb, o.render(spp), "emission: " + variant)
+
+
 def test_hip_against_unmodified_reference_kernel_text():
     """Round 3: the HIP renderer against tests/golden/glsl_golden_r3.npz -- pathtracer_brick_tf.glsl (c3), c1, the README scene and the
     emission path rendered on llvmpipe from the reference's kernel text as it stands (the driver's log / acos / atan; rounds 1-2 spliced the
