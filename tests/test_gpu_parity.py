@@ -1124,6 +1124,44 @@ def test_sample_pool_falls_back_when_memory_is_short():
     _assert_same(img, r2.framebuffer(), "split launches vs one launch")
 
 
+@pytest.mark.parametrize("config", ["c3", "c4:64", "c5:32"])
+def test_frames_split_into_sub_launches_are_identical(config):
+    """A frame whose samples do not fit the sample pool is rendered by several launches (BASELINE configs[3..4] need 8 and 16 of them at their own
+    frames): the running mean is applied in sample order across launches, so the image is the single-launch image bit for bit -- on the
+    transfer-function, dense-grid and emission kernels, with a sample count that leaves a ragged last launch."""
+    w, h, spp = 200, 136, 100
+    one = scenes.hip_scene(config, w, h)
+    one.render(spp)
+    assert one.last_launches == 1
+    want = one.framebuffer().copy()
+    r = scenes.hip_scene(config, w, h)
+    r.sample_pool_mb = 16                      # the smallest pool: 208 x 144 pixels (whole 16 x 16 tiles) x 16 bytes -> 32 samples per launch: 32 + 32 + 32 + 4
+    r.render(spp)
+    assert r.last_launches >= 3, r.last_launches
+    assert np.array_equal(_bits(r.framebuffer()), _bits(want))
+    assert r.last_pathtrace_ms() > 0 and r.last_pathtrace_ms() <= r.last_kernel_ms() + 1e-3      # the kernels of ALL sub-launches, inside the frame's span
+
+
+@pytest.mark.parametrize("variant", ["crop", "camera_inside", "very_dense_rgb_albedo", "thin_no_env", "ragged_frame"])
+def test_dense_grid_kernel_variants(variant):
+    """The dense fp16 kernel (BASELINE configs[3]'s path) under the switches the brick kernel is tested with: crop box, a camera inside the grid,
+    an optically thick medium with a coloured albedo, a thin one without visible environment, a frame that is not a multiple of the tile size."""
+    w, h = (61, 45) if variant == "ragged_frame" else (64, 48)
+    r, o = scenes.hip_scene("c4:64", w, h), scenes.oracle_scene("c4:64", w, h)
+    fields = {
+        "crop": dict(vol_clip_min=(0.15, 0.0, 0.2), vol_clip_max=(0.85, 0.7, 1.0)),
+        "camera_inside": dict(cam_pos=(0.05, 0.0, -0.1), cam_dir=(0.4, 0.2, 1.0), cam_fov=80.0),
+        "very_dense_rgb_albedo": dict(density_scale=3000.0, albedo=(0.95, 0.6, 0.3), bounces=24),
+        "thin_no_env": dict(density_scale=5.0, show_environment=False),
+        "ragged_frame": dict(),
+    }[variant]
+    for k, v in fields.items():
+        setattr(r, k, v)
+        setattr(o, k, v)
+    r.render(5)
+    _assert_same(r.framebuffer(), o.render(5), "dense grid: " + variant)
+
+
 @pytest.mark.parametrize("config", ["c1", "c3", "c5:32"])
 def test_no_path_depends_on_stale_cold_state(config, monkeypatch):
     """A new path writes no cold line before its first scatter event (FirstStash, vr_trace.h) and a path that never scatters
