@@ -51,6 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     ap.add_argument("--extra-configs", default=None, help="comma list of further configs measured at N=1 and reported under 'configs' (default: c3,c4 for the headline run; 'none' to skip)")
+    ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: still initialise the process group (RCCL) and run the sharded flow pack_tiles -> all_gather -> unpack_tiles with one rank")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous and exchange one tile buffer (no rendering): checks the launcher path")
     return ap.parse_args(argv)
 
@@ -165,35 +166,41 @@ def traffic_profile(cfg):
 class Bench:
     """One configuration on this rank's GPU: scene resident, tile shard set up, step() = one frame."""
 
-    def __init__(self, config, w, h, spp, world, rank, local_rank, dist, fast_math=False):
+    def __init__(self, config, w, h, spp, world, rank, local_rank, dist, fast_math=False, pipelined=None):
         import torch
         import scenes
         from volren_amd.shard import TileShard
         self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
         self.config, self.w, self.h, self.spp = config, w, h, spp
         self.shard = TileShard(w, h, world, rank)
-        self.staged = world > 1 and os.environ.get("VOLREN_DIST_BACKEND", "nccl") != "nccl"
-        # Multi-GPU: a rank's share of a frame is short (tens of ms), so the fixed drain of the persistent wavefronts' path pools at
-        # the end of a launch (4-5 ms, set by the deepest paths) is what bounds strong scaling.  Consecutive frames are independent:
-        # two renderers on two streams let frame i+1's wavefronts move onto the CUs that frame i's draining workgroups free
-        # (profiles/r2_launch_overhead.txt).  Each has its own framebuffer, sample pool and tile buffers; one GPU needs neither.
-        self.pipelined = world > 1 and os.environ.get("VOLREN_PIPELINE", "1") != "0"
+        self.sharded = dist is not None                     # pack -> all_gather -> unpack per frame (every N > 1; N = 1 with --force-dist)
+        self.staged = self.sharded and dist.get_backend() != "nccl"
+        # The fixed cost of a launch is the drain of the persistent wavefronts' path pools at its end (4-5 ms, set by the deepest
+        # paths): a few per cent of a whole frame on one GPU, 15 % of a rank's share of it on eight.  Consecutive frames are
+        # independent: two renderers on two streams let frame i+1's wavefronts move onto the CUs that frame i's draining workgroups
+        # free (profiles/r2_launch_overhead.txt).  Each has its own framebuffer, sample pool and tile buffers.  The SAME for every N
+        # (round 4: N = 1 used to run unpipelined, which made value(8) / value(1) compare two different things); the bench line
+        # also carries value_single_frame, one frame at a time, for every N.  VOLREN_PIPELINE=0 switches it off.
+        self.pipelined = (os.environ.get("VOLREN_PIPELINE", "1") != "0") if pipelined is None else bool(pipelined)
+        pool_mb = os.environ.get("VOLREN_SAMPLE_POOL_MB")   # several ranks sharing one GPU (tests): a smaller radiance pool per renderer
         self.slots = []
         for k in range(2 if self.pipelined else 1):
             r = scenes.hip_scene(config, w, h, device=local_rank)
             if fast_math:
                 r.fast_math = 1
+            if pool_mb:
+                r.sample_pool_mb = int(pool_mb)
             stream = torch.cuda.Stream() if self.pipelined else torch.cuda.current_stream()
             r.set_stream(stream.cuda_stream)
             slot = dict(r=r, stream=stream)
-            if world > 1:
+            if self.sharded:
                 r.set_tiles(self.shard.mine)
                 slot["packed"] = torch.empty(self.shard.packed_floats, dtype=torch.float32, device="cuda")
                 slot["gathered"] = torch.empty(self.shard.gathered_floats, dtype=torch.float32, device="cuda")
             self.slots.append(slot)
         self.r = self.slots[0]["r"]
         self.frame = 0
-        if world > 1:
+        if self.sharded:
             self.tiles_dev = torch.from_numpy(self.shard.pack_ids).cuda()
             self.all_tiles_dev = torch.from_numpy(self.shard.unpack_ids).cuda()
 
@@ -205,7 +212,7 @@ class Bench:
         with torch.cuda.stream(slot["stream"]):
             r.reset()
             r.render(self.spp, sync=False)                                      # ONE fused launch: all spp of all owned tiles
-            if self.world > 1:
+            if self.sharded:
                 r.pack_tiles(self.tiles_dev.data_ptr(), self.shard.n_max, slot["packed"].data_ptr())
                 if self.staged:
                     r.synchronize()
@@ -217,9 +224,19 @@ class Bench:
                 r.unpack_tiles(self.all_tiles_dev.data_ptr(), self.world * self.shard.n_max, slot["gathered"].data_ptr())
 
     def barrier(self):
-        if self.world > 1:
+        if self.dist is not None:
             self.dist.barrier()
         self.torch.cuda.synchronize()
+
+    def last_renderer(self):
+        return self.slots[(self.frame - 1) % len(self.slots)]["r"]
+
+    def frame_crc32(self):
+        """CRC-32 of the RGBA32F frame the last step left on this rank (after the gather: the whole frame on every rank)."""
+        import zlib
+        r = self.last_renderer()
+        r.synchronize()
+        return zlib.crc32(r.framebuffer().tobytes()) & 0xFFFFFFFF
 
     def measure(self, steps, warmup):
         torch, dist = self.torch, self.dist
@@ -237,23 +254,30 @@ class Bench:
         elapsed = time.perf_counter() - t0
         for slot in self.slots:
             slot["r"].synchronize()                                             # also raises if the kernel watchdog tripped
-        if self.pipelined:                                                      # the kernel's own duration: one more frame with nothing beside it
-            self.frame = 0
-            self.step()
+        # one frame at a time (what a single-frame render sees: BASELINE configs[3..4]); also gives the kernel's own duration, with
+        # nothing beside it on the GPU
+        n_single = min(steps, 2) if self.pipelined else 0
+        single = elapsed / steps
+        if n_single:
             self.barrier()
-        last_r = self.slots[(self.frame - 1) % len(self.slots)]["r"]
+            t1 = time.perf_counter()
+            for _ in range(n_single):
+                self.step()
+                self.barrier()
+            single = (time.perf_counter() - t1) / n_single
+        last_r = self.last_renderer()
         pt_ms = last_r.last_pathtrace_ms()                                      # HIP events around the path-tracing kernels alone, summed over the frame's sub-launches
         last_ms = last_r.last_kernel_ms()                                       # HIP events on the renderer's stream around the last frame's launches
-        if self.world > 1:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if not self.staged else "cpu")
+        if dist is not None:
+            tmax = torch.tensor([elapsed, single], dtype=torch.float64, device="cuda" if not self.staged else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+            elapsed, single = float(tmax[0].item()), float(tmax[1].item())
         samples = float(self.w) * self.h * self.spp
-        launches = max(1, self.slots[(self.frame - 1) % len(self.slots)]["r"].last_launches)                                 # a frame is split so that a sub-launch fits the sample pool
+        launches = max(1, last_r.last_launches)                                 # a frame is split so that a sub-launch fits the sample pool
         my_samples = len(self.shard.mine) * 256.0 * self.spp if self.world > 1 else samples
         # pt_ms is the sum over the frame's sub-launches (HIP events around each path-tracing kernel): kernel_ms = its AVERAGE launch duration,
         # samples_per_launch = the average samples of a launch -- what the rocprofv3 kernel statistics of the same run report
-        return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, kernel_ms=(pt_ms if pt_ms > 0 else last_ms) / launches, frame_gpu_ms=last_ms,
+        return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, value_single_frame=samples / single / 1e6, ms_single_frame=single * 1e3, kernel_ms=(pt_ms if pt_ms > 0 else last_ms) / launches, frame_gpu_ms=last_ms,
                     launches=launches, samples_per_launch=my_samples / launches)
 
     def roofline(self, m, counters):
@@ -350,9 +374,13 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % max(1, n_dev)                # test mode: ranks may share a device
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                         # --force-dist without a launcher: a one-rank group in this process
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL ("nccl") over xGMI is the real path; VOLREN_DIST_BACKEND=gloo exists only so that the multi-rank flow can be
         # exercised on a box where several ranks have to share one GPU (the collective is then staged through the host)
         if backend == "nccl":
@@ -368,7 +396,7 @@ def main():
     if rank == 0:
         use_tf = args.config == "c3"
         cpu = cpu_rm = None
-        if world == 1 and args.cpu_budget > 0:
+        if world == 1 and dist is None and args.cpu_budget > 0:
             cpu, counters = cpu_baseline_and_counters(args.config, args.cpu_budget, aspect=w / h)
         else:
             _, counters = cpu_baseline_and_counters(args.config, 0.5, aspect=w / h)
@@ -376,13 +404,17 @@ def main():
             "metric": "Msamples/s (pixels x spp / s), volume path tracing",
             "value": m["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+            # one frame at a time (barrier + device synchronisation around every frame): what a single-frame render sees; `value` overlaps the
+            # drain of frame i with the start of frame i+1 (two streams), for every N alike
+            "value_single_frame": m["value_single_frame"], "ms_single_frame": m["ms_single_frame"], "pipelined": bool(b.pipelined),
+            "frame_crc32": b.frame_crc32(),                    # of the RGBA32F frame on rank 0 after the last step: the same for every N
             "vs_baseline": None, "dtype": "f32", "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else
                                       "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
             "config": {"workload": workload_name(args.config, w, h, spp),
-                       "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, ", consecutive frames pipelined over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, %d fused launch(es)/frame (16 GiB sample pool)" % m["launches"]},
+                       "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, ", consecutive frames pipelined over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, %d fused launch(es)/frame (16 GiB sample pool)%s%s" % (m["launches"], ", consecutive frames pipelined over 2 streams" if b.pipelined else "", ", one-rank process group: pack_tiles -> all_gather -> unpack_tiles per frame" if dist is not None else "")},
             "roofline": b.roofline(m, counters),
-            "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1,
-            "dist_backend": (dist.get_backend() if world > 1 else None),
+            "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
+            "dist_backend": (dist.get_backend() if dist is not None else None),
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -393,7 +425,7 @@ def main():
                 out["cpu_baseline_raymarch"] = {"error": str(e)}
 
     # tolerance-mode kernels (v_log/v_rcp/v_sin hardware math): speed and distance from the bit-exact default, same frame
-    if world == 1 and args.extra_configs != "none" and getattr(b.r, "has_fast_math", lambda: False)():
+    if world == 1 and dist is None and args.extra_configs != "none" and getattr(b.r, "has_fast_math", lambda: False)():
         ref = b.r.framebuffer().copy()
         bf = Bench(args.config, w, h, spp, world, rank, local_rank, dist, fast_math=True)
         mf = bf.measure(max(1, args.steps - 1), 1)
@@ -408,7 +440,7 @@ def main():
     # the other single-GPU BASELINE configs at the resolution north_star quotes (driver-run, not builder-only)
     extra = args.extra_configs
     if extra is None:
-        extra = "c3,c4,c4@1920x1080x4096,c5full@2048x2048x4096" if (args.config == "c2" and world == 1) else "none"
+        extra = "c3,c4,c4@1920x1080x4096,c5full@2048x2048x4096" if (args.config == "c2" and world == 1 and dist is None) else "none"
     if rank == 0 and world == 1 and extra != "none":
         del b
         out["configs"] = []
@@ -417,17 +449,17 @@ def main():
             fw, fh, fspp = (int(v) for v in frame.split("x")) if frame else (w, h, spp)
             steps_x = 2 if frame else 3
             try:
-                bx = Bench(name, fw, fh, fspp, 1, 0, local_rank, None)
+                bx = Bench(name, fw, fh, fspp, 1, 0, local_rank, None, pipelined=False)      # one frame at a time: BASELINE configs[3..4] are single frames
                 mx = bx.measure(steps_x, 1)
                 _, cx = cpu_baseline_and_counters(name, 0.5, aspect=fw / fh)
                 out["configs"].append({"name": spec, "workload": workload_name(name, fw, fh, fspp), "value": mx["value"], "unit": "Msamples/s",
-                                       "ms_per_step": mx["ms_per_step"], "steps": steps_x, "warmup": 1, "roofline": bx.roofline(mx, cx)})
+                                       "ms_per_step": mx["ms_per_step"], "steps": steps_x, "warmup": 1, "pipelined": False, "roofline": bx.roofline(mx, cx)})
                 del bx
             except Exception as e:                             # noqa: BLE001
                 out["configs"].append({"name": spec, "error": str(e)})
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,206 @@
+// sharded.cpp -- see sharded.h.
+#include "sharded.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is opened at run time (no link-time dependency)
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+
+#include "vr_device.h"
+
+namespace vr {
+
+std::vector<std::vector<int32_t>> tile_owner_lists(int width, int height, int n_parts) {
+    if (width <= 0 || height <= 0 || n_parts <= 0) throw std::runtime_error("tile_owner_lists: bad arguments");
+    const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
+    std::vector<std::vector<int32_t>> lists((size_t)n_parts);
+    for (int ty = 0; ty < tiles_y; ++ty)
+        for (int tx = 0; tx < tiles_x; ++tx) lists[(size_t)((tx + ty) % n_parts)].push_back(ty * tiles_x + tx);
+    return lists;
+}
+
+// ---- librccl, opened on first use ------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+Rccl& rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+            R.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (R.handle) break;
+        }
+        if (!R.handle) { R.error = std::string("librccl.so.1 could not be opened: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(R.handle, n); if (!p && R.error.empty()) R.error = std::string("librccl lacks ") + n; return p; };
+        R.CommInitAll = reinterpret_cast<decltype(R.CommInitAll)>(sym("ncclCommInitAll"));
+        R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+        R.AllGather = reinterpret_cast<decltype(R.AllGather)>(sym("ncclAllGather"));
+        R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
+        R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
+        R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return R;
+}
+void rccl_check(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) throw std::runtime_error(std::string("RCCL error: ") + rccl().GetErrorString(r) + " in " + what);
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------
+ShardedRenderer::ShardedRenderer(const std::vector<RendererHIP*>& parts, const std::vector<int>& devices) : parts_(parts), devices_(devices) {
+    if (parts_.empty() || parts_.size() != devices_.size()) throw std::runtime_error("ShardedRenderer: one device per part, at least one part");
+    for (RendererHIP* p : parts_)
+        if (!p) throw std::runtime_error("ShardedRenderer: null part");
+    int n_dev = 0;
+    VR_HIP(hipGetDeviceCount(&n_dev));
+    for (int d : devices_)
+        if (d < 0 || d >= n_dev) throw std::runtime_error("ShardedRenderer: device " + std::to_string(d) + " does not exist (" + std::to_string(n_dev) + " visible)");
+    const std::set<int> distinct(devices_.begin(), devices_.end());
+    const char* want = std::getenv("VR_SHARDED_TRANSPORT");
+    const std::string forced = want ? want : "";
+    if (!forced.empty() && forced != "rccl" && forced != "copy") throw std::runtime_error("VR_SHARDED_TRANSPORT must be rccl or copy");
+    if (forced == "rccl" && distinct.size() != devices_.size()) throw std::runtime_error("ShardedRenderer: RCCL needs distinct devices (two parts share one)");
+    if (parts_.size() == 1 && forced != "rccl") transport_ = "none";
+    else if (forced == "copy" || distinct.size() != devices_.size()) transport_ = "copy";
+    else transport_ = "rccl";
+    buf_.resize(parts_.size());
+    for (size_t i = 0; i < parts_.size(); ++i) {
+        VR_HIP(hipSetDevice(devices_[i]));
+        VR_HIP(hipStreamCreateWithFlags(&buf_[i].stream, hipStreamNonBlocking));
+        VR_HIP(hipEventCreateWithFlags(&buf_[i].packed_ready, hipEventDisableTiming));
+        parts_[i]->stream = buf_[i].stream;
+    }
+    if (transport_ == "rccl") {
+        Rccl& R = rccl();
+        if (!R.error.empty()) throw std::runtime_error("ShardedRenderer: " + R.error + " (VR_SHARDED_TRANSPORT=copy uses peer copies instead)");
+        std::vector<ncclComm_t> comms(parts_.size());
+        rccl_check(R.CommInitAll(comms.data(), (int)parts_.size(), devices_.data()), "ncclCommInitAll");
+        for (ncclComm_t c : comms) comms_.push_back((void*)c);
+    }
+}
+
+ShardedRenderer::~ShardedRenderer() {
+    for (size_t i = 0; i < parts_.size(); ++i) {
+        (void)hipSetDevice(devices_[i]);
+        if (buf_[i].stream) (void)hipStreamSynchronize(buf_[i].stream);
+    }
+    for (void* c : comms_) (void)rccl().CommDestroy((ncclComm_t)c);
+    for (size_t i = 0; i < parts_.size(); ++i) {
+        (void)hipSetDevice(devices_[i]);
+        if (parts_[i]->stream == buf_[i].stream) parts_[i]->stream = nullptr;
+        buf_[i].pack_ids.reset(); buf_[i].packed.reset(); buf_[i].gathered.reset();
+        if (i == 0) unpack_ids_.reset();
+        if (buf_[i].packed_ready) (void)hipEventDestroy(buf_[i].packed_ready);
+        if (buf_[i].stream) (void)hipStreamDestroy(buf_[i].stream);
+    }
+}
+
+void ShardedRenderer::setup(int width, int height) {
+    width_ = width; height_ = height;
+    const size_t n = parts_.size();
+    if (transport_ == "none") {
+        VR_HIP(hipSetDevice(devices_[0]));
+        parts_[0]->set_tiles({});
+        return;
+    }
+    const auto lists = tile_owner_lists(width, height, (int)n);
+    n_max_ = 1;
+    for (const auto& l : lists) n_max_ = std::max(n_max_, (int)l.size());
+    const size_t packed_bytes = (size_t)n_max_ * 256u * 4u * sizeof(float);
+    std::vector<int32_t> unpack;
+    for (size_t i = 0; i < n; ++i) {
+        VR_HIP(hipSetDevice(devices_[i]));
+        parts_[i]->set_tiles(lists[i]);
+        // pack list: own tiles, padded by repeating the last one (any valid tile: its slot is ignored on unpack)
+        std::vector<int32_t> pack(lists[i]);
+        pack.resize((size_t)n_max_, lists[i].empty() ? 0 : lists[i].back());
+        buf_[i].pack_ids = make_device_buffer(pack.size() * sizeof(int32_t));
+        buf_[i].pack_ids->upload(pack.data(), pack.size() * sizeof(int32_t), buf_[i].stream);
+        buf_[i].packed = make_device_buffer(packed_bytes);
+        buf_[i].gathered = (i == 0 || transport_ == "rccl") ? make_device_buffer(packed_bytes * n) : nullptr;
+        unpack.insert(unpack.end(), lists[i].begin(), lists[i].end());
+        unpack.resize((i + 1) * (size_t)n_max_, -1);
+    }
+    VR_HIP(hipSetDevice(devices_[0]));
+    unpack_ids_ = make_device_buffer(unpack.size() * sizeof(int32_t));
+    unpack_ids_->upload(unpack.data(), unpack.size() * sizeof(int32_t), buf_[0].stream);
+}
+
+void ShardedRenderer::reset() {
+    for (RendererHIP* p : parts_) p->reset();
+}
+
+void ShardedRenderer::render(int spp) {
+    RendererHIP& first = *parts_[0];
+    for (RendererHIP* p : parts_)
+        if (p->resolution.x != first.resolution.x || p->resolution.y != first.resolution.y || p->sample != first.sample)
+            throw std::runtime_error("ShardedRenderer::render: the parts disagree on resolution or sample count");
+    if (first.resolution.x != width_ || first.resolution.y != height_) setup(first.resolution.x, first.resolution.y);
+    const int n_samples = spp <= 0 ? first.sppx - first.sample : spp;
+    if (n_samples <= 0) return;
+    const size_t n = parts_.size();
+    const size_t count = (size_t)n_max_ * 256u * 4u;             // floats a part contributes
+    for (size_t i = 0; i < n; ++i) {                             // every part: all samples of its tiles, then its compact tile buffer
+        VR_HIP(hipSetDevice(devices_[i]));
+        RendererHIP& p = *parts_[i];
+        if (p.stream != buf_[i].stream) throw std::runtime_error("ShardedRenderer::render: a part's stream was changed behind the sharded renderer");
+        p.render(n_samples);
+        if (transport_ == "none") continue;
+        launch_pack_tiles(p.color->as<float>(), width_, height_, buf_[i].pack_ids->as<int32_t>(), n_max_, buf_[i].packed->as<float>(), buf_[i].stream);
+        VR_HIP(hipGetLastError());
+    }
+    if (transport_ == "none") return;
+    if (transport_ == "rccl") {
+        Rccl& R = rccl();
+        rccl_check(R.GroupStart(), "ncclGroupStart");
+        for (size_t i = 0; i < n; ++i) {
+            VR_HIP(hipSetDevice(devices_[i]));
+            rccl_check(R.AllGather(buf_[i].packed->get(), buf_[i].gathered->get(), count, ncclFloat, (ncclComm_t)comms_[i], buf_[i].stream), "ncclAllGather");
+        }
+        rccl_check(R.GroupEnd(), "ncclGroupEnd");
+    } else {
+        // logical shards of one device (or VR_SHARDED_TRANSPORT=copy): every part copies its buffer into part 0's gathered buffer on its
+        // own stream, and part 0's stream waits for all of them.  The copies of frame k+1 must not overtake part 0's unpack of frame k,
+        // which reads that buffer: they wait for an event part 0 records after its pack -- in stream order after the unpack before it.
+        VR_HIP(hipSetDevice(devices_[0]));
+        VR_HIP(hipEventRecord(buf_[0].packed_ready, buf_[0].stream));       // part 0 has packed (and, in stream order, finished last frame's unpack)
+        float* gathered = buf_[0].gathered->as<float>();
+        for (size_t i = 0; i < n; ++i) {
+            VR_HIP(hipSetDevice(devices_[i]));
+            if (i > 0) VR_HIP(hipStreamWaitEvent(buf_[i].stream, buf_[0].packed_ready, 0));
+            if (devices_[i] == devices_[0]) VR_HIP(hipMemcpyAsync(gathered + i * count, buf_[i].packed->get(), count * sizeof(float), hipMemcpyDeviceToDevice, buf_[i].stream));
+            else VR_HIP(hipMemcpyPeerAsync(gathered + i * count, devices_[0], buf_[i].packed->get(), devices_[i], count * sizeof(float), buf_[i].stream));
+            if (i > 0) VR_HIP(hipEventRecord(buf_[i].packed_ready, buf_[i].stream));
+        }
+        VR_HIP(hipSetDevice(devices_[0]));
+        for (size_t i = 1; i < n; ++i) VR_HIP(hipStreamWaitEvent(buf_[0].stream, buf_[i].packed_ready, 0));
+    }
+    VR_HIP(hipSetDevice(devices_[0]));
+    launch_unpack_tiles(buf_[0].gathered->as<float>(), unpack_ids_->as<int32_t>(), (int32_t)(n * (size_t)n_max_), first.color->as<float>(), width_, height_, buf_[0].stream);
+    VR_HIP(hipGetLastError());
+}
+
+void ShardedRenderer::synchronize() {
+    uint32_t tripped = 0;
+    for (size_t i = 0; i < parts_.size(); ++i) {
+        VR_HIP(hipSetDevice(devices_[i]));
+        parts_[i]->synchronize();
+        tripped |= parts_[i]->watchdog_status();
+    }
+    VR_HIP(hipSetDevice(devices_[0]));
+    if (tripped) throw std::runtime_error("path-tracing kernel watchdog tripped: a launch did not finish within its budget");
+}
+
+}  // namespace vr
