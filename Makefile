@@ -8,7 +8,7 @@ CSRC     := volren_amd/csrc
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result -Iinclude
 HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 OBJDIR   := build
-SRCS_CPP := grids.cpp imageio.cpp environment.cpp transferfunc.cpp renderer.cpp capi.cpp
+SRCS_CPP := grids.cpp imageio.cpp environment.cpp transferfunc.cpp renderer.cpp sharded.cpp capi.cpp
 PT_VARIANTS := 0 1 2 3
 OBJS     := $(OBJDIR)/vr_kernels.o $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_%.o) $(PT_VARIANTS:%=$(OBJDIR)/vr_ptfast_%.o) $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
 # tolerance-mode kernels (opt-in, vr_math.h VR_FAST_MATH): hardware transcendentals, reciprocal division, contraction allowed
@@ -40,7 +40,7 @@ $(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 volren_amd/libvolren_amd.so: $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -lz
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -lz -ldl
 
 volren_amd/volren: $(CSRC)/main.cpp volren_amd/libvolren_amd.so $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -x hip $(CSRC)/main.cpp -o $@ -Lvolren_amd -lvolren_amd -Wl,-rpath,'$$ORIGIN' -lz

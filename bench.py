@@ -242,7 +242,7 @@ class Bench:
         torch, dist = self.torch, self.dist
         import gc
         gc.collect()                                                            # destructors of earlier renderers (16 GiB pools) run now, not inside the timed region
-        for _ in range(warmup):
+        for _ in range(max(warmup, len(self.slots))):                           # every pipelined renderer has run once (pools allocated, launch rate measured)
             self.step()
         self.barrier()
         for slot in self.slots:

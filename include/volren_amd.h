@@ -91,7 +91,10 @@ int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
  *     relative L2 of the default -- refused with VR_ERR while a transfer function is bound, where it misses that bound)
  *     "tf_float_atlas" (default 1: transfer-function renders of brick grids decode the atlas to floats once, 4x its size; 0 = read the bytes)
  *     "grid_frame_counter"
- *     "sample_pool_mb" (HBM budget of the per-sample radiance pool, default 16384) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
+ *     "sample_pool_mb" (HBM budget of the per-sample radiance pool, default 16384)
+ *     "launch_target_ms" (default 2000: a vr_render is split into sub-launches planned to take at most this long each, from the rate this
+ *     renderer measured last -- a short probe launch, one synchronisation, when it has none for the current settings and the request is
+ *     large; 0 = split by the sample pool alone.  Results never depend on the split) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
  *     "emission_scale" "vol_clip_min"(3) "vol_clip_max"(3) "env_strength" "env_transform"(9) "env_rot"(1, degrees about +y,
  *     main.cpp:382) "tf_window_left" "tf_window_width" "cam_pos"(3) "cam_dir"(3) "cam_up"(3) "cam_fov" "volume_transform"(16) (float) */
 int vr_set_int(vr_renderer* r, const char* name, int value);
@@ -134,6 +137,26 @@ int vr_set_stream(vr_renderer* r, void* hip_stream);
 /* pack the owned tiles of the framebuffer into a compact device buffer (n_tiles*256*4 floats) / scatter a gathered buffer back */
 int vr_pack_tiles(vr_renderer* r, const int32_t* tile_ids_device, int n_tiles, void* packed_device);
 int vr_unpack_tiles(vr_renderer* r, const int32_t* tile_ids_device, int n_tiles, const void* packed_device);
+/* --- ONE frame on SEVERAL devices, in one process (no reference counterpart: the reference drives one GL context, src/main.cpp:524-557;
+ *     SURVEY.md 8e; volren_amd/csrc/sharded.h).  vr_sharded_create makes n_parts renderers, part i on HIP device devices[i] (vr_create each).
+ *     The scene is REPLICATED by the caller: apply the scene calls of this header (vr_load_volume, vr_set_float, ...) to every
+ *     vr_sharded_part(s, i).  vr_sharded_render deals the frame's 16x16 tiles diagonally (owner = (tx + ty) mod n_parts), lets every part
+ *     render `spp` more samples of its tiles on its own stream, and gathers the accumulated radiance with ONE grouped ncclAllGather per frame
+ *     (RCCL over xGMI; librccl.so.1 is opened at run time); afterwards part 0's framebuffer (vr_framebuffer / vr_save_png on
+ *     vr_sharded_part(s, 0)) holds the whole frame, bit-identical to a single-device render.  Parts that share a device (logical shards:
+ *     devices = {0, 0, 0}) exchange their tiles with device-to-device copies instead -- vr_sharded_transport says which: "rccl", "copy", or
+ *     "none" for one part; environment VR_SHARDED_TRANSPORT=copy|rccl overrides (rccl also with ONE part: a one-rank communicator).
+ *     Asynchronous like vr_render; vr_sharded_synchronize waits for every part and reports a tripped watchdog.  The parts belong to the
+ *     sharded renderer: never vr_destroy one, never vr_set_stream / vr_set_tiles on one. */
+typedef struct vr_sharded vr_sharded;
+int vr_sharded_create(vr_sharded** out, const int* devices, int n_parts, int width, int height);
+void vr_sharded_destroy(vr_sharded* s);
+int vr_sharded_parts(vr_sharded* s);
+vr_renderer* vr_sharded_part(vr_sharded* s, int i);
+const char* vr_sharded_transport(vr_sharded* s);
+int vr_sharded_reset(vr_sharded* s);                      /* vr_reset on every part */
+int vr_sharded_render(vr_sharded* s, int spp);
+int vr_sharded_synchronize(vr_sharded* s);
 /* the uniform block the next launch would use (struct vr::Uniforms of volren_amd/csrc/vr_scene.h, `bytes` must match) */
 int vr_get_uniforms(vr_renderer* r, void* out, int bytes);
 int vr_uniforms_size(void);

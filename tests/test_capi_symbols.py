@@ -45,6 +45,11 @@ def test_no_device_fails_loudly():
         volren_amd.Renderer(32, 32)
     with pytest.raises(volren_amd.VolrenError):
         volren_amd.math_probe(0, [1.0])
+    hs = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.vr_sharded_create(C.byref(hs), devs, 2, 64, 64) == 2 and not hs.value      # the sharded renderer has no CPU path either
+    with pytest.raises(volren_amd.VolrenError):
+        volren_amd.ShardedRenderer(32, 32, [0, 0])
 
 
 def test_null_arguments_are_rejected():
@@ -52,6 +57,10 @@ def test_null_arguments_are_rejected():
     assert lib.vr_trace(None) == 3 and b"null renderer" in lib.vr_last_error()      # VR_ERR_ARG
     assert lib.vr_render(None, 4) == 3
     assert lib.vr_create(None, 0, 8, 8) == 3
+    assert lib.vr_sharded_create(None, None, 1, 8, 8) == 3 and lib.vr_sharded_render(None, 1) == 3 and lib.vr_sharded_synchronize(None) == 3
+    hs = C.c_void_p()
+    assert lib.vr_sharded_create(C.byref(hs), None, 2, 8, 8) == 3 and lib.vr_sharded_parts(None) == 0 and not lib.vr_sharded_part(None, 0)
+    lib.vr_sharded_destroy(None)
     lib.vr_destroy(None)                                                           # no-op
 
 

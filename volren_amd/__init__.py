@@ -4,4 +4,4 @@ The compute lives in libvolren_amd.so (hand-written HIP kernels + C++ host class
 this package is the thin Python binding used by the tests, bench.py and multi-GPU sharding.  No CPU fallback.
 """
 from ._lib import LIB_PATH, SYMBOLS, VolrenError, load  # noqa: F401
-from .renderer import Renderer, math_probe  # noqa: F401
+from .renderer import Renderer, ShardedRenderer, math_probe  # noqa: F401

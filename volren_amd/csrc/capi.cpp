@@ -6,15 +6,26 @@
 #include <functional>
 #include <iostream>
 #include <stdexcept>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "imageio.h"
 #include "renderer.h"
+#include "sharded.h"
 #include "vr_device.h"
 
 struct vr_renderer {
     vr::RendererHIP impl;
     int device = 0;
+};
+
+// N renderers on N devices behind one frame (sharded.h).  The parts are ordinary vr_renderer objects owned by this object: every scene
+// call of this header applies to them one by one (vr_sharded_part), which is how the scene is replicated.
+struct vr_sharded {
+    std::vector<vr_renderer*> parts;
+    std::unique_ptr<vr::ShardedRenderer> impl;
+    std::string transport;
 };
 
 static thread_local std::string g_last_error;
@@ -277,6 +288,7 @@ int vr_set_int(vr_renderer* r, const char* name, int v) {
         else if (n == "tf_float_atlas") R.tf_float_atlas = v != 0;
         else if (n == "gpu_encoder") R.gpu_encoder = v != 0;
         else if (n == "sample_pool_mb") { if (v < 16 || v > 49152) throw std::runtime_error("sample_pool_mb must be in [16, 49152] (item indices of a sub-launch are 32-bit: < 2^32 RGBA32F items)"); R.sample_pool_bytes = (size_t)v << 20; }
+        else if (n == "launch_target_ms") { if (v < 0) throw std::runtime_error("launch_target_ms must be >= 0 (0 = no sizing by time)"); R.launch_target_ms = v; }
         else if (n == "grid_frame_counter") {
             if (!R.volume || v < 0 || (size_t)v >= R.volume->n_grid_frames()) throw std::runtime_error("grid_frame_counter out of range");
             R.volume->grid_frame_counter = (size_t)v;
@@ -301,6 +313,7 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "tf_float_atlas") *v = R.tf_float_atlas ? 1 : 0;
         else if (n == "gpu_encoder") *v = R.gpu_encoder ? 1 : 0;
         else if (n == "sample_pool_mb") *v = (int)(R.sample_pool_bytes >> 20);
+        else if (n == "launch_target_ms") *v = R.launch_target_ms;
         else if (n == "grid_frame_counter") *v = R.volume ? (int)R.volume->grid_frame_counter : 0;
         else if (n == "n_grid_frames") *v = R.volume ? (int)R.volume->n_grid_frames() : 0;
         else if (n == "last_launches") *v = R.last_launches;
@@ -463,6 +476,51 @@ int vr_grid_checksums(vr_renderer* r, uint64_t out[3]) {
         if (!R.volume || R.density_grids.empty()) throw std::runtime_error("no committed volume");
         R.grid_checksums(R.density_grids.at(R.volume->grid_frame_counter), out);
     });
+}
+
+// ---- one frame on several devices (sharded.h) ------------------------------------------------------------------------------
+int vr_sharded_create(vr_sharded** out, const int* devices, int n_parts, int width, int height) {
+    if (!out) return fail(VR_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    if (!devices || n_parts <= 0 || n_parts > 64) return fail(VR_ERR_ARG, "vr_sharded_create: 1..64 parts, one device ordinal each");
+    if (vr_device_count() <= 0) return fail(VR_ERR_NO_DEVICE, "no HIP device available (libvolren_amd has no CPU path)");
+    vr_sharded* s = new vr_sharded();
+    const int rc = guard([&] {
+        std::vector<vr::RendererHIP*> impls;
+        std::vector<int> devs(devices, devices + n_parts);
+        for (int i = 0; i < n_parts; ++i) {
+            vr_renderer* r = nullptr;
+            if (vr_create(&r, devices[i], width, height) != VR_OK) throw std::runtime_error(g_last_error);
+            s->parts.push_back(r);
+            impls.push_back(&r->impl);
+        }
+        s->impl = std::make_unique<vr::ShardedRenderer>(impls, devs);
+        s->transport = s->impl->transport();
+    });
+    if (rc != VR_OK) { const std::string keep = g_last_error; vr_sharded_destroy(s); g_last_error = keep; return rc; }
+    *out = s;
+    return VR_OK;
+}
+void vr_sharded_destroy(vr_sharded* s) {
+    if (!s) return;
+    s->impl.reset();                                  // waits for the parts' streams, gives them their default stream back
+    for (vr_renderer* r : s->parts) vr_destroy(r);
+    delete s;
+}
+int vr_sharded_parts(vr_sharded* s) { return s ? (int)s->parts.size() : 0; }
+vr_renderer* vr_sharded_part(vr_sharded* s, int i) { return (s && i >= 0 && i < (int)s->parts.size()) ? s->parts[(size_t)i] : nullptr; }
+const char* vr_sharded_transport(vr_sharded* s) { return s ? s->transport.c_str() : ""; }
+int vr_sharded_reset(vr_sharded* s) {
+    if (!s) return fail(VR_ERR_ARG, "null sharded renderer");
+    return guard([&] { s->impl->reset(); });
+}
+int vr_sharded_render(vr_sharded* s, int spp) {
+    if (!s) return fail(VR_ERR_ARG, "null sharded renderer");
+    return guard([&] { s->impl->render(spp); });
+}
+int vr_sharded_synchronize(vr_sharded* s) {
+    if (!s) return fail(VR_ERR_ARG, "null sharded renderer");
+    return guard([&] { s->impl->synchronize(); });
 }
 
 int vr_uniforms_size(void) { return (int)sizeof(vr::Uniforms); }

@@ -3,7 +3,9 @@
 // Same command line, same order semantics (src/main.cpp:311-347 for -w/-h, :360-435 for everything else: arguments are
 // processed left to right, paths load immediately, later flags override what a loader set), same per-frame loop
 // (:524-557): reset -> sppx samples -> tonemap -> "<stem>_%06d.png" in the current directory.
-// Not provided: the interactive window/GUI, Python scripts (.py arguments) and the tinycolormap presets.
+// Not provided: the interactive window/GUI, Python scripts (.py arguments: `python -m volren_amd.run_script` runs them) and the tinycolormap presets.
+// Addition: --gpus N [--devices a,b,...] renders every frame on N devices (sharded.h: scene replicated, 16x16 tiles dealt diagonally, one
+// grouped ncclAllGather per frame; a device named more than once = logical shards of one GPU, exchanged by device-to-device copies).
 //
 //   volren data/smoke.brick data/table_mountain_2_puresky_1k.hdr -w 1024 -h 1024 --render --spp 4096 --bounces 128 \
 //          --albedo 0.8 --phase 0.3 --density 100 --env_strength 3 --env_rot 270 --exposure 3 --gamma 2.0 --cam_fov 40
@@ -11,10 +13,13 @@
 #include <cstdio>
 #include <filesystem>
 #include <iostream>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "imageio.h"
 #include "renderer.h"
+#include "sharded.h"
 
 namespace fs = std::filesystem;
 using namespace vr;
@@ -109,46 +114,88 @@ static void parse_cmd(int argc, char** argv) {
         } else if (arg == "--vol_crop_min") { renderer->vol_clip_min.x = a.nextf(); renderer->vol_clip_min.y = a.nextf(); renderer->vol_clip_min.z = a.nextf(); }
         else if (arg == "--vol_crop_max") { renderer->vol_clip_max.x = a.nextf(); renderer->vol_clip_max.y = a.nextf(); renderer->vol_clip_max.z = a.nextf(); }
         else if (arg == "--seed") renderer->seed = a.nexti();                        // addition
-        else if (arg == "--device") a.next();                                        // consumed earlier
+        else if (arg == "--device" || arg == "--gpus" || arg == "--devices") a.next();  // consumed earlier
         else if (fs::is_regular_file(arg) || fs::is_directory(arg)) handle_path(arg);
     }
 }
 
-int main(int argc, char** argv) {
-    int width = 1280, height = 720, device = 0;        // cppgl ContextParameters defaults (unverified): always pass -w/-h
-    for (int i = 1; i < argc; ++i) {
-        const std::string arg = argv[i];
-        if (arg == "-w" && i + 1 < argc) width = std::stoi(argv[++i]);
-        else if (arg == "-h" && i + 1 < argc) height = std::stoi(argv[++i]);
-        else if (arg == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
+static std::vector<int> parse_int_list(const std::string& s) {
+    std::vector<int> v;
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        const size_t c = s.find(',', pos);
+        const std::string tok = s.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+        if (!tok.empty()) v.push_back(std::stoi(tok));
+        if (c == std::string::npos) break;
+        pos = c + 1;
     }
+    return v;
+}
+
+int main(int argc, char** argv) {
+    int width = 1280, height = 720, device = 0, gpus = 0;        // cppgl ContextParameters defaults (unverified): always pass -w/-h
+    std::vector<int> devices;
     try {
-        VR_HIP(hipSetDevice(device));
-        renderer = std::make_shared<RendererHIP>();
-        renderer->resolution = { width, height };
-        renderer->init();
-        parse_cmd(argc, argv);
-        if (renderer->volume->grids.empty()) {
-            // debug box of the reference (main.cpp:465-474): a 1x1x4 dense grid in front of the camera
-            const float values[4] = { 1.f, 2.5f, 5.f, 10.f };
-            auto box = std::make_shared<DenseGrid>(1, 1, 4, values);
-            const vec3 d = renderer->camera.dir;
-            box->transform = scale_then_translate(1.f, vec3(2.f * d.x + 0.f, 2.f * d.y - 0.5f, 2.f * d.z - 2.f));
-            renderer->volume = std::make_shared<Volume>(box);
-            renderer->commit();
+        for (int i = 1; i < argc; ++i) {
+            const std::string arg = argv[i];
+            if (arg == "-w" && i + 1 < argc) width = std::stoi(argv[++i]);
+            else if (arg == "-h" && i + 1 < argc) height = std::stoi(argv[++i]);
+            else if (arg == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
+            else if (arg == "--gpus" && i + 1 < argc) gpus = std::stoi(argv[++i]);
+            else if (arg == "--devices" && i + 1 < argc) devices = parse_int_list(argv[++i]);
         }
-        renderer->reset();
+        // one renderer per part; without --gpus / --devices: one part on --device, the reference's single-context loop
+        if (devices.empty()) {
+            if (gpus <= 1) devices = { device };
+            else for (int d = 0; d < gpus; ++d) devices.push_back(d);
+        } else if (gpus > 0 && (size_t)gpus != devices.size()) throw std::runtime_error("--gpus and --devices disagree");
+        const bool sharded = devices.size() > 1 || gpus > 0;
+        std::vector<std::shared_ptr<RendererHIP>> parts;
+        for (size_t k = 0; k < devices.size(); ++k) {
+            // the scene is replicated by running the command line once per part (paths load onto the part's device)
+            VR_HIP(hipSetDevice(devices[k]));
+            renderer = std::make_shared<RendererHIP>();
+            renderer->resolution = { width, height };
+            renderer->init();
+            parse_cmd(argc, argv);
+            if (renderer->volume->grids.empty()) {
+                // debug box of the reference (main.cpp:465-474): a 1x1x4 dense grid in front of the camera
+                const float values[4] = { 1.f, 2.5f, 5.f, 10.f };
+                auto box = std::make_shared<DenseGrid>(1, 1, 4, values);
+                const vec3 d = renderer->camera.dir;
+                box->transform = scale_then_translate(1.f, vec3(2.f * d.x + 0.f, 2.f * d.y - 0.5f, 2.f * d.z - 2.f));
+                renderer->volume = std::make_shared<Volume>(box);
+                renderer->commit();
+            }
+            renderer->reset();
+            parts.push_back(renderer);
+        }
+        renderer = parts[0];                            // holds the whole frame after the gather
+        std::unique_ptr<ShardedRenderer> shards;
+        if (sharded) {
+            std::vector<RendererHIP*> raw;
+            for (auto& p : parts) raw.push_back(p.get());
+            shards = std::make_unique<ShardedRenderer>(raw, devices);
+            std::cout << "rendering on " << devices.size() << " part(s), devices";
+            for (int d : devices) std::cout << " " << d;
+            std::cout << ", tile exchange: " << shards->transport() << std::endl;
+        }
         std::cout << "rendering..." << std::endl;
         for (size_t i = 0; i < renderer->volume->n_grid_frames(); ++i) {
-            renderer->reset();
-            renderer->volume->grid_frame_counter = i;
+            for (auto& p : parts) { p->reset(); p->volume->grid_frame_counter = i; }
             const auto t0 = std::chrono::steady_clock::now();
-            renderer->render(renderer->sppx);          // == while (sample < sppx) trace();
-            renderer->synchronize();
-            if (renderer->watchdog_status()) throw std::runtime_error("path-tracing kernel watchdog tripped");
+            if (shards) {
+                shards->render(renderer->sppx);
+                shards->synchronize();
+            } else {
+                renderer->render(renderer->sppx);          // == while (sample < sppx) trace();
+                renderer->synchronize();
+                if (renderer->watchdog_status()) throw std::runtime_error("path-tracing kernel watchdog tripped");
+            }
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::cout << renderer->sample << " / " << renderer->sppx << "  (" << sec << " s, "
                       << (double)width * height * renderer->sppx / sec / 1e6 << " Msamples/s)" << std::endl;
+            VR_HIP(hipSetDevice(devices[0]));
             renderer->tonemapping = true;               // the offline loop always tonemaps (main.cpp:540-550)
             renderer->draw();
             std::vector<float> fb((size_t)width * height * 4);
@@ -161,6 +208,7 @@ int main(int argc, char** argv) {
             save_png_rgba8(out_fn, rgba.data(), width, height);
             std::cout << out_fn << " written." << std::endl;
         }
+        shards.reset();                                 // before the parts it points at
     } catch (std::exception& e) {
         std::cerr << "volren: " << e.what() << std::endl;
         return 1;

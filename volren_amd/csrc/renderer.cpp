@@ -60,6 +60,7 @@ void RendererHIP::reset() { sample = 0; }
 
 // ---------------------------------------------------------------------------------------------------
 void RendererHIP::commit() {
+    rate_samples_per_ms_ = 0.0; rate_pending_samples_ = 0.0;      // a new volume: nothing measured yet
     density_grids.clear();
     emission_grids.clear();
     majorant_emission = 0.f;
@@ -449,13 +450,46 @@ void RendererHIP::launch(int n) {
         // test hook: no path may depend on what its cold line held before the path wrote it (tests/test_gpu_parity.py)
         if (const char* e = std::getenv("VR_TEST_POISON_WORKSPACE"); e && *e == '1') VR_HIP(hipMemsetAsync(workspace_->get(), 0xFF, workspace_->size_bytes(), stream));
     }
+    const bool pt_kernel = !(integrator == 3 || (integrator == 2 && transferfunc));      // launch_pathtrace records the events around the path-tracing kernel only
+    // Launch sizing by time (round 4): no sub-launch is PLANNED to take longer than launch_target_ms.  The plan uses the rate of this renderer's last
+    // finished sub-launch; when there is none for the current settings and the request is large, a short probe launch measures it first (one
+    // synchronisation, once per change of settings).  A plan can still be off -- the rate is a property of the scene AND the view -- which costs nothing
+    // but the bound: the kernel's watchdog watches progress, not duration (vr_pathtrace.h).
+    const double px_samples = (double)n_tiles * 256.0;                          // samples per spp of this launch
+    const uint64_t key = [&] {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&h](const void* p, size_t nbytes) { const uint8_t* b = static_cast<const uint8_t*>(p); for (size_t i = 0; i < nbytes; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+        const Uniforms& u = P.u;
+        mix(&u.bounces, sizeof u.bounces); mix(u.vol_albedo, sizeof u.vol_albedo); mix(&u.vol_phase_g, sizeof u.vol_phase_g); mix(&u.vol_density_scale, sizeof u.vol_density_scale);
+        mix(&u.use_tf, sizeof u.use_tf); mix(&u.tf_window_left, sizeof u.tf_window_left); mix(&u.tf_window_width, sizeof u.tf_window_width); mix(&u.integrator, sizeof u.integrator);
+        mix(&u.has_emission, sizeof u.has_emission); mix(u.resolution, sizeof u.resolution); mix(u.vol_bb_min, sizeof u.vol_bb_min); mix(u.vol_bb_max, sizeof u.vol_bb_max);
+        const size_t frame = volume->grid_frame_counter; mix(&frame, sizeof frame); mix(&n_tiles, sizeof n_tiles);
+        const uint64_t tfv = transferfunc ? transferfunc->version : 0; mix(&tfv, sizeof tfv);
+        return h ? h : 1ull;
+    }();
+    auto cap_by_rate = [&](int planned) {
+        if (launch_target_ms <= 0 || rate_samples_per_ms_ <= 0.0) return planned;
+        const double cap = rate_samples_per_ms_ * (double)launch_target_ms / px_samples;
+        int c = cap >= (double)planned ? planned : std::max(1, (int)cap);
+        if (c > 32) c -= c % 32;
+        return c;
+    };
+    int probe = 0;
+    if (pt_kernel && launch_target_ms > 0) {
+        harvest_rate(false);
+        const bool known = rate_samples_per_ms_ > 0.0 && rate_key_ == key;
+        if (!known && px_samples * (double)std::min(per_launch, n) > (double)(1u << 26)) {
+            rate_samples_per_ms_ = 0.0;                                          // measured under other settings: not a basis for a plan
+            probe = (int)std::min<double>(32.0, std::max(1.0, (double)(1u << 24) / px_samples));
+            probe = std::min(probe, n);
+        } else per_launch = cap_by_rate(per_launch);
+    }
     VR_HIP(hipEventRecord(ev0_, stream));
     last_launches = 0;
     pt_events_used_ = 0;
-    const bool pt_kernel = !(integrator == 3 || (integrator == 2 && transferfunc));      // launch_pathtrace records the events around the path-tracing kernel only
-    for (int done = 0; done < n; done += per_launch) {
+    for (int done = 0; done < n;) {
         ++last_launches;
-        const int m = std::min(per_launch, n - done);
+        const int m = probe > 0 ? probe : std::min(per_launch, n - done);
         hipEvent_t eb = nullptr, ee = nullptr;
         if (pt_kernel) {
             while (pt_events_.size() < pt_events_used_ + 2) { hipEvent_t e; VR_HIP(hipEventCreate(&e)); pt_events_.push_back(e); }
@@ -464,10 +498,30 @@ void RendererHIP::launch(int n) {
         }
         launch_pathtrace(tuning, P, color->as<float>(), pool_->as<float>(), workspace_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, sample + 1 + done, m, status_->as<uint32_t>(), stream, fast_math, eb, ee);
         VR_HIP(hipGetLastError());
+        done += m;
+        if (pt_kernel) { rate_pending_samples_ = px_samples * (double)m; rate_pending_key_ = key; }
+        if (probe > 0) {                                                         // the probe: wait for it, then plan the rest
+            probe = 0;
+            harvest_rate(true);
+            per_launch = cap_by_rate(per_launch);
+        }
     }
     VR_HIP(hipEventRecord(ev1_, stream));
     timing_pending_ = true;
     sample += n;
+}
+
+// rate of the last path-tracing sub-launch that was enqueued, if it has finished (wait: block until it has)
+void RendererHIP::harvest_rate(bool wait) {
+    if (rate_pending_samples_ <= 0.0 || pt_events_used_ < 2) return;
+    hipEvent_t eb = pt_events_[pt_events_used_ - 2], ee = pt_events_[pt_events_used_ - 1];
+    if (wait) VR_HIP(hipEventSynchronize(ee));
+    else if (hipEventQuery(ee) != hipSuccess) { (void)hipGetLastError(); return; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, eb, ee) != hipSuccess || !(ms > 0.f)) { (void)hipGetLastError(); return; }
+    rate_samples_per_ms_ = rate_pending_samples_ / (double)ms;
+    rate_key_ = rate_pending_key_;
+    rate_pending_samples_ = 0.0;
 }
 
 void RendererHIP::trace() { launch(1); }

@@ -119,6 +119,9 @@ struct RendererHIP {
                                                       // with one bound the renderer refuses it: DESIGN.md 3)
     PathtraceTuning tuning = default_tuning();        // scheduler thresholds, work-unit size, statistics buffer of THIS renderer's launches
     int last_launches = 0;                            // path-tracing sub-launches of the last trace()/render()
+    int launch_target_ms = 2000;                      // a sub-launch is planned to take at most this long, from the rate the renderer measured on its last launch (a short
+                                                      // probe launch when it has none for the current settings and the request is large); 0 = plan by the sample pool alone.
+                                                      // Correctness does not depend on it (the kernel's watchdog is progress-based): it bounds how long one launch holds the GPU
     size_t sample_pool_bytes = (size_t)16 << 30;      // HBM budget of the per-sample radiance pool (16 B per pixel-sample; sized for 288 GB HBM3E, allocated on demand)
 
     void set_tiles(const std::vector<int32_t>& tile_ids);     // empty = whole frame
@@ -147,6 +150,11 @@ private:
     size_t pt_events_used_ = 0;
     double last_ms_ = 0.0, last_pathtrace_ms_ = 0.0;
     bool timing_pending_ = false;
+    // launch sizing: samples per millisecond of the last finished path-tracing sub-launch, and a fingerprint of the settings it ran with
+    double rate_samples_per_ms_ = 0.0;
+    uint64_t rate_key_ = 0, rate_pending_key_ = 0;
+    double rate_pending_samples_ = 0.0;               // samples of the last sub-launch enqueued (its events: the last pair of pt_events_)
+    void harvest_rate(bool wait);
     // majorant cache key
     struct MajKey { float density_scale = -1.f; uint64_t tf_version = ~0ull; float wl = 0, ww = 0; size_t frame = ~(size_t)0; } maj_key_;   // tf_version: TransferFunction::version (unique per upload), 0 = no LUT
 };

@@ -167,7 +167,7 @@ void launch_pathtrace(const PathtraceTuning& T, const SceneParams& P, float* fb,
     D.chunks = (uint32_t)chunks;
     D.seg_len = (D.n_units + kQueueSegments - 1u) / kQueueSegments;
     D.unit_counter = unit_counter;
-    S.max_iters = kMaxIters;
+    S.max_iters = kMaxIdleIters;
     // lanes that must stand at a tentative collision before the collision code runs while others still march (vr_pathtrace.h):
     // measured optimum 24 (smoke.brick +0.5 %, dense +0.7 %, sparse + emission +2...3.5 %), 32 with a transfer function, whose
     // collision code (8 corner taps + LUT) is the dearest (+4.4 %); profiles/r2ab_collide_threshold.txt

@@ -17,7 +17,7 @@ namespace vr {
 
 struct SchedParams {
     int32_t thr[ST_COUNT];     // minimum number of lanes that must wait in a state before its code runs
-    uint32_t max_iters;        // watchdog: scheduler iterations per wavefront
+    uint32_t max_iters;        // watchdog: scheduler iterations a wavefront may run without finishing a path
 };
 
 // Persistent wavefronts.  The frame's work is cut into units = one 8x8 pixel tile x `spu` consecutive samples
@@ -29,7 +29,12 @@ struct SchedParams {
 // blockIdx.x & 7 names the XCD): the waves of one XCD -- which share one L2 -- work on one band of tile rows; a wave whose
 // segment is empty takes units from the next one.
 constexpr uint32_t kQueueSegments = 8u;
-constexpr uint32_t kMaxIters = 1u << 27;      // watchdog: ~100x the scheduler iterations of the heaviest wavefront seen
+// Watchdog (round 4: progress-based).  A wavefront gives up -- and the launch is reported as failed -- when it has neither finished a path nor pulled a
+// work unit for kMaxIdleIters scheduler iterations or kMaxIdleTicks of shader clock (~3 s), whichever comes first.  Both counters restart with every
+// finished path, so a launch may legitimately run for as long as it has work (round 3 measured the wavefront's LIFETIME against 8 s, which a
+// 1000-bounce render of a thick cloud approaches); an input whose paths never end (a majorant that overflowed to +inf) still stops within seconds.
+constexpr uint32_t kMaxIdleIters = 1u << 26;       // the heaviest wavefront seen runs ~10^6 iterations in its whole life
+constexpr uint64_t kMaxIdleTicks = 7200000000ull;  // ~3 s at 2.4 GHz
 struct LaunchDesc {
     const int32_t* tiles;     // 16x16 tile ids (raster, row 0 = bottom) or nullptr = all tiles
     int32_t n_tiles, first_sample, n_samples, spu;
@@ -493,7 +498,7 @@ pathtrace_kernel(const KernelArgs A) {
     hot_init(l);
     int32_t slot = -1;                // path held in this lane's registers (-1: none)
 
-    uint32_t iters = 0u;
+    uint32_t iters = 0u, idle_iters = 0u;     // scheduler iterations: in all (statistics), since the last finished path or pulled unit (watchdog)
     uint32_t t_last = (uint32_t)__builtin_readcyclecounter(), t_elapsed = 0u;
     uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
@@ -522,15 +527,17 @@ pathtrace_kernel(const KernelArgs A) {
         VR_PUSH(Q_ESC, cnt_esc, s_ == ST_ESCAPE, BS); \
         const bool lost_ = s_ == ST_BEGIN || s_ > ST_ESCAPE || s_ < -1; \
         if (wave_ballot(lost_)) { if (lost_) atomicOr(event_args().status, 2u); } \
+        const int32_t free0_ = cnt_free; \
         VR_PUSH(Q_FREE, cnt_free, s_ == ST_NEW || lost_, BS); \
+        if (cnt_free != free0_) { idle_iters = 0u; t_elapsed = 0u; }          /* a path has ended: the watchdog starts over */ \
     } while (0)
 #define VR_ROUTE(BS) VR_ROUTE_ST(BS, l.state)
 #define VR_ROUTE_B(BS) VR_ROUTE_ST(BS, b.state)
 
     for (;;) {
-        // watchdog: a wavefront's share of a launch is tens of milliseconds; give up (and report) after kMaxIters scheduler
-        // iterations or ~8 s of shader clock, whichever comes first -- a kernel must never hang the GPU
-        bool give_up = ++iters > kMaxIters;
+        // watchdog (kMaxIdleIters above): a kernel must never hang the GPU
+        ++iters;
+        bool give_up = ++idle_iters > kMaxIdleIters;
         if ((iters & 1023u) == 0u) {
             // elapsed shader-clock time in units of 1024 ticks, summed over 1024-iteration windows (low 32 bits of the counter:
             // a window is a few million ticks).  A window that appears to take more than 2^31 ticks is a counter discontinuity
@@ -539,7 +546,7 @@ pathtrace_kernel(const KernelArgs A) {
             const uint32_t now = (uint32_t)__builtin_readcyclecounter(), d = now - t_last;
             t_last = now;
             if (d < (1u << 31)) t_elapsed += d >> 10;
-            give_up = give_up || t_elapsed > (20000000000ull >> 10);
+            give_up = give_up || t_elapsed > (uint32_t)(kMaxIdleTicks >> 10);
         }
         if (give_up) {
             if (lane == 0) atomicOr(event_args().status, 1u);
@@ -756,7 +763,7 @@ pathtrace_kernel(const KernelArgs A) {
                         ++seg_tries;                                        // this segment is used up for good
                     }
                     if (j == 0xFFFFFFFFu) exhausted = true;
-                    else { wu = make_unit(E.D, E.P.u.resolution[0], j, nullptr); cursor = 0u; }
+                    else { wu = make_unit(E.D, E.P.u.resolution[0], j, nullptr); cursor = 0u; idle_iters = 0u; t_elapsed = 0u; }
                 }
                 n = min(min(64, cnt_free), (int32_t)((uint32_t)wu.n_items - cursor));
                 if (n > 0) {

@@ -7,7 +7,7 @@ import numpy as np
 from . import _lib
 
 _INT_FIELDS = ("sample", "sppx", "seed", "bounces", "show_environment", "tonemapping", "integrator", "grid_frame_counter",
-               "sample_pool_mb", "gpu_encoder", "fast_math", "tf_float_atlas")
+               "sample_pool_mb", "gpu_encoder", "fast_math", "tf_float_atlas", "launch_target_ms")
 _FLOAT_FIELDS = {"tonemap_exposure": 1, "tonemap_gamma": 1, "albedo": 3, "phase": 1, "density_scale": 1,
                  "emission_scale": 1, "vol_clip_min": 3, "vol_clip_max": 3, "env_strength": 1, "env_transform": 9,
                  "tf_window_left": 1, "tf_window_width": 1, "cam_pos": 3, "cam_dir": 3, "cam_up": 3, "cam_fov": 1,
@@ -21,11 +21,15 @@ def _f32(a):
 class Renderer:
     """`Renderer(w, h)`; set fields; `load_volume/load_envmap/load_transferfunc`; `render(spp)`; `fbo_data()`."""
 
-    def __init__(self, width, height, device=0):
+    def __init__(self, width, height, device=0, _borrowed=None):
         object.__setattr__(self, "_h", None)
         L = _lib.load()
-        h = C.c_void_p()
-        _lib.check(L.vr_create(C.byref(h), int(device), int(width), int(height)))
+        object.__setattr__(self, "_owned", _borrowed is None)
+        if _borrowed is None:
+            h = C.c_void_p()
+            _lib.check(L.vr_create(C.byref(h), int(device), int(width), int(height)))
+        else:
+            h = C.c_void_p(_borrowed)                       # a part of a ShardedRenderer: the handle belongs to it
         object.__setattr__(self, "_h", h)
         object.__setattr__(self, "_L", L)
         object.__setattr__(self, "width", int(width))
@@ -33,7 +37,8 @@ class Renderer:
 
     def close(self):
         if self._h is not None:
-            self._L.vr_destroy(self._h)
+            if self._owned:
+                self._L.vr_destroy(self._h)
             object.__setattr__(self, "_h", None)
 
     def __del__(self):
@@ -273,6 +278,63 @@ class Renderer:
         out = np.empty(n, np.float32)
         _lib.check(self._L.vr_get_impmap(self._h, out.ctypes.data, n))
         return out
+
+
+class ShardedRenderer:
+    """One frame on several devices in ONE process (include/volren_amd.h vr_sharded_*, csrc/sharded.h): `parts[i]` is an ordinary
+    Renderer on `devices[i]` -- replicate the scene by applying the same calls to every part (`each`) -- `render(spp)` lets every
+    part render its diagonal share of the 16x16 tiles and gathers them (RCCL all-gather between distinct devices, device-to-device
+    copies between logical shards of one device); afterwards `parts[0]` holds the whole frame."""
+
+    def __init__(self, width, height, devices):
+        self._h = None
+        L = _lib.load()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        _lib.check(L.vr_sharded_create(C.byref(h), devs, len(devices), int(width), int(height)))
+        self._h, self._L = h, L
+        self.devices = [int(d) for d in devices]
+        self.parts = [Renderer(width, height, _borrowed=L.vr_sharded_part(h, i)) for i in range(L.vr_sharded_parts(h))]
+
+    def close(self):
+        if self._h is not None:
+            for p in self.parts:
+                p.close()
+            self._L.vr_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def each(self, fn):
+        """fn(part) for every part: how scene calls are replicated."""
+        for p in self.parts:
+            fn(p)
+        return self
+
+    @property
+    def transport(self):
+        return self._L.vr_sharded_transport(self._h).decode()
+
+    def reset(self):
+        _lib.check(self._L.vr_sharded_reset(self._h))
+
+    def render(self, spp=0, sync=True):
+        _lib.check(self._L.vr_sharded_render(self._h, int(spp)))
+        if sync:
+            self.synchronize()
+
+    def synchronize(self):
+        _lib.check(self._L.vr_sharded_synchronize(self._h))
+
+    def framebuffer(self):
+        return self.parts[0].framebuffer()
+
+    def save(self, path):
+        self.parts[0].save(path)
 
 
 def math_probe(fn, a, b=None):
