@@ -559,6 +559,26 @@ def test_volpy_grid_frames():
         o.cam_fov, o.bounces, o.density_scale = 40.0, 6, 40.0
         ref = o.render(SPP)
         assert np.array_equal(_bits(np.asarray(renderer.fbo_data()).reshape(H, W, 3)), _bits(ref[..., :3])), frame
+    # an edit AFTER scale_and_move_to_unit_cube(): the reference mutates the renderer's voldata::Volume in place, so the unit-cube transform
+    # (and the density scale that goes with it) stays -- the edit must not rebuild the volume from scratch
+    for k in range(3):                                                # a per-frame update loop: each update supersedes the one before
+        vol.update_grid_frame(0, scenes.synthetic_density(32, seed=20 + k))
+    vol.update_grid_frame(0, d1)
+    assert len([e for e in vol._edits if e[0] == "update" and e[1] == 0 and e[3] == "density"]) == 1
+    assert vol.n_grid_frames() == 2
+    renderer.commit()
+    vol.grid_frame_counter = 0
+    renderer.render(SPP)
+    o = ob.OracleRenderer(W, H)
+    o.load_envmap(scenes.HDR)
+    gd, gt = encoder_ref.encode(d1), encoder_ref.encode(t0)
+    for g in (gd, gt):
+        g.extent = (32, 32, 32)
+        g.c.extent[:] = g.extent
+    o.set_volume(gd, emission=gt, majorant_emission=maj_e)
+    o.cam_fov, o.bounces, o.density_scale = 40.0, 6, 40.0
+    ref = o.render(SPP)
+    assert np.array_equal(_bits(np.asarray(renderer.fbo_data()).reshape(H, W, 3)), _bits(ref[..., :3])), "edit after the unit cube"
 
 
 def test_volpy_runs_the_reference_script_bodies(tmp_path):
@@ -688,6 +708,48 @@ def test_volpy_runs_the_reference_script_bodies(tmp_path):
             o.seed, o.bounces, o.sample = seed, p["max_bounces"], 0
             _assert_same(renderer._r.framebuffer(), o.render(spp), "datagen_denoise image %d %s" % (i, what))
     renderer.shutdown()
+
+
+@pytest.mark.parametrize("launcher", ["volren", "module"])
+def test_scripts_written_for_volpy_run_unmodified(tmp_path, launcher):
+    """A script whose only renderer import is `import volpy` (tests/fixtures/script_views.py: init, draw, volume =, scale_and_move_to_unit_cube,
+    commit, render, fbo_data, save_with_alpha -- the calls of scripts/datagen_colmap.py:46-95), started the way the reference starts its scripts:
+    `volren script.py --render -w W -h H` (src/main.cpp:83-91), or `python -m volren_amd.run_script`.  `volpy.Renderer()` gets the -w / -h
+    resolution; every view is the oracle's frame bit for bit."""
+    import json
+    import subprocess
+    import sys
+    from PIL import Image
+    from oracle import binding as ob
+    W, H, SPP = 72, 48, 4
+    script = os.path.join(scenes.FIX, "script_views.py")
+    env = dict(os.environ, VIEWS_OUT=str(tmp_path), VIEWS_N="2", VIEWS_SPP=str(SPP))
+    if launcher == "volren":
+        cmd = [scenes.ROOT + "/volren_amd/volren", script, "--render", "-w", str(W), "-h", str(H)]
+    else:
+        cmd = [sys.executable, "-m", "volren_amd.run_script", script, "-w", str(W), "-h", str(H), "--render", "extra-arg"]
+        env["PYTHONPATH"] = scenes.ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    meta = json.load(open(tmp_path / "views.json"))
+    assert (meta["width"], meta["height"], meta["spp"]) == (W, H, SPP)
+    assert meta["argv"] == ([] if launcher == "volren" else ["extra-arg"])           # the context flags are the launcher's, the rest is the script's
+    o = ob.OracleRenderer(W, H)
+    o.load_envmap(scenes.HDR)
+    o.load_volume(scenes.SMOKE)                                                      # unit cube: density_scale = size
+    o.density_scale = float(np.float32(0.5) * np.float32(o.density_scale))
+    o.env_strength, o.albedo, o.phase, o.bounces, o.seed = 1.5, (0.8, 0.85, 0.9), 0.25, 12, 7
+    for i, v in enumerate(meta["views"]):
+        assert abs(v["density_scale"] - o.density_scale) <= 1e-6 * o.density_scale
+        o.cam_pos, o.cam_dir, o.cam_fov = tuple(v["cam_pos"]), tuple(v["cam_dir"]), v["cam_fov"]
+        o.sample = 0
+        ref = o.render(SPP)
+        got = np.load(tmp_path / ("view_%03d.npy" % i))
+        assert got.shape == (W, H, 3)                                                # the reference's declared buffer shape (bindings.cpp:69-77,143)
+        assert np.array_equal(_bits(got.reshape(H, W, 3)), _bits(ref[..., :3])), "view %d" % i
+        png = np.asarray(Image.open(tmp_path / ("view_%03d.png" % i)))
+        want = np.floor(np.clip(o.tonemapped()[::-1], 0, 1) * 255.0 + 0.5).astype(np.uint8)
+        assert png.shape == (H, W, 4) and np.array_equal(png, want)
 
 
 def test_dense_and_raw_volume_files(tmp_path):
@@ -1086,19 +1148,73 @@ def test_degenerate_inputs_match_oracle(case):
 
 def test_watchdog_turns_a_non_terminating_input_into_an_error():
     """density_scale = 1e30 overflows every majorant to +inf; the reference's tracker then never terminates (the oracle
-    does not either: `timeout 60 python -c ...` in DESIGN.md).  The kernel must not hang the GPU: its watchdog ends the
-    wavefronts after ~8 s of shader clock and the next call reports it; the renderer stays usable."""
+    does not either: `timeout 60 python -c ...` in DESIGN.md).  The kernel must not hang the GPU: its watchdog ends a wavefront
+    that has neither finished a path nor pulled a work unit for ~3 s of shader clock, the next call reports it, and the renderer
+    stays usable."""
+    import time
     import volren_amd
     r = scenes.hip_scene("c1", 32, 32)
     good = r.density_scale
     r.density_scale = 1e30
+    t0 = time.time()
     with pytest.raises(volren_amd.VolrenError, match="watchdog"):
         r.render(1)
+    assert time.time() - t0 < 10.0
     r.density_scale = good
     r.reset()
     r.render(2)
     o = scenes.oracle_scene("c1", 32, 32)
     _assert_same(r.framebuffer(), o.render(2), "render after a watchdog trip")
+
+
+@pytest.mark.timeout(900)
+def test_watchdog_watches_progress_not_duration():
+    """A legitimately long launch: thick, nearly white medium (albedo 0.999, 1000 bounces, density x 10 on the dense 128^3 grid), 512 x 512 x 256 spp
+    -- two orders of magnitude more work per sample than the bench scenes.  The watchdog restarts with every path a wavefront finishes, so no
+    launch is too long for it; a crop is checked bit for bit against the oracle."""
+    w = h = 512
+
+    def thick(r):
+        r.albedo = (0.999,) * 3
+        r.bounces = 1000
+        r.density_scale = 1000.0
+        return r
+    r = thick(scenes.hip_scene("c4:128", w, h))
+    r.launch_target_ms = 0                        # one launch for the whole frame: duration is not what the watchdog measures
+    r.render(256)
+    assert r.last_launches == 1
+    ms = r.last_kernel_ms()
+    fb = r.framebuffer()
+    x0, y0, cw, ch = 248, 250, 12, 6              # through the thick of the medium
+    o = thick(scenes.oracle_scene("c4:128", w, h))
+    ref = o.render(256, rect=(x0, y0, x0 + cw, y0 + ch))
+    assert np.array_equal(_bits(fb[y0:y0 + ch, x0:x0 + cw]), _bits(ref[y0:y0 + ch, x0:x0 + cw])), "crop differs (launch took %.0f ms)" % ms
+    assert fb[y0:y0 + ch, x0:x0 + cw, 3].min() == 1.0           # every sample of the crop scattered
+
+
+def test_launches_are_sized_by_the_measured_rate():
+    """launch_target_ms: a render is split into sub-launches planned from the rate the renderer measured (a probe launch first when it has none and
+    the request is large); the image does not depend on the split."""
+    w = h = 512
+    a = scenes.hip_scene("c2", w, h)
+    a.launch_target_ms = 0
+    a.render(320)
+    assert a.last_launches == 1
+    ref = a.framebuffer()
+    b = scenes.hip_scene("c2", w, h)
+    b.launch_target_ms = 4                        # the frame takes ~20 ms: several sub-launches, the first of them the probe
+    b.render(320)
+    n1 = b.last_launches
+    assert n1 >= 3, n1
+    assert np.array_equal(_bits(b.framebuffer()), _bits(ref))
+    b.reset()
+    b.render(320)                                 # the rate is known now: no probe, the same plan otherwise
+    assert b.last_launches >= 2
+    assert np.array_equal(_bits(b.framebuffer()), _bits(ref))
+    b.launch_target_ms = 2000
+    b.reset()
+    b.render(320)
+    assert b.last_launches == 1
 
 
 def test_sample_pool_falls_back_when_memory_is_short():
@@ -1119,6 +1235,7 @@ def test_sample_pool_falls_back_when_memory_is_short():
         lib.vr_test_alloc_cap_mb(-1)
     assert launches >= 2, launches
     r2 = scenes.hip_scene("c1", 1024, 1024)
+    r2.launch_target_ms = 0                       # no probe launch (test_launches_are_sized_by_the_measured_rate): the pool alone decides
     r2.render(512)
     assert r2.last_launches == 1
     _assert_same(img, r2.framebuffer(), "split launches vs one launch")
@@ -1210,6 +1327,10 @@ def test_tuning_state_is_per_renderer():
     assert sb["waves"] == 0 and sb["iterations"] == 0                # b's launch was not instrumented
     assert sa["occupancy"]["free"] <= 66                             # a ran with its own pool cap
     assert np.array_equal(_bits(a.framebuffer()), _bits(b.framebuffer()))
+    import volren_amd
+    for bad in ([65, 0, 56, 0, 60, 60, 64, 0], [64, 0, -1, 0, 60, 60, 64, 0], [64, 193, 56, 0, 60, 60, 64, 0], [64, 40, 56, 0, 60, 60, 64, 0], [64, 0, 56, 0, 60, 60, 256, 0]):
+        with pytest.raises(volren_amd.VolrenError):              # out of range, or a NEW threshold the capped pool can never reach: refused, not truncated
+            a.set_sched(bad)
 
 
 def test_random_parameter_sets_match_oracle():

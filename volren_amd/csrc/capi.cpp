@@ -543,6 +543,14 @@ int vr_get_impmap(vr_renderer* r, float* out, int count) {
 int vr_set_sched(vr_renderer* r, const int32_t thr[8]) {
     NEED(r);
     if (!thr) return fail(VR_ERR_ARG, "null argument");
+    // the kernel packs each threshold into a byte: a batch size is a number of lanes (NEW / MARCH = low-water mark / COLLIDE / NEE / POSTNEE / ESCAPE:
+    // 0..64, 0 = the default of COLLIDE), [1] caps the slots of a wavefront's pool (0 = all, else 1..192).  A NEW threshold above the pool size
+    // would never trigger a batch and end in the watchdog: refused here instead.
+    for (int i = 0; i < 8; ++i) {
+        const int hi = i == 1 ? 192 : 64;
+        if (thr[i] < 0 || thr[i] > hi) return fail(VR_ERR_ARG, i == 1 ? "vr_set_sched: the slot cap [1] must be in 0..192" : "vr_set_sched: batch thresholds must be in 0..64");
+    }
+    if (thr[1] > 0 && thr[0] > thr[1]) return fail(VR_ERR_ARG, "vr_set_sched: the NEW threshold [0] exceeds the slot cap [1]");
     for (int i = 0; i < 8; ++i) r->impl.tuning.thr[i] = thr[i];
     g_last_error.clear();
     return VR_OK;

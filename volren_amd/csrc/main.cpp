@@ -9,7 +9,10 @@
 //
 //   volren data/smoke.brick data/table_mountain_2_puresky_1k.hdr -w 1024 -h 1024 --render --spp 4096 --bounces 128 \
 //          --albedo 0.8 --phase 0.3 --density 100 --env_strength 3 --env_rot 270 --exposure 3 --gamma 2.0 --cam_fov 40
+#include <sys/wait.h>
+
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <filesystem>
 #include <iostream>
@@ -52,10 +55,7 @@ static const PathKind kPathKinds[] = {
 };
 static void handle_path(const std::string& path) {
     const std::string ext = fs::path(path).extension().string();
-    if (ext == ".py") {
-        std::cerr << "Python scripts are not supported by this build (" << path << "): use the volren_amd python package" << std::endl;
-        return;
-    }
+    if (ext == ".py") return;                               // main() hands the whole command line to python -m volren_amd.run_script before anything else
     for (const PathKind& kind : kPathKinds) {
         if (kind.ext && ext != kind.ext) continue;
         try {
@@ -132,7 +132,28 @@ static std::vector<int> parse_int_list(const std::string& s) {
     return v;
 }
 
+// `volren script.py --render -w W -h H` (src/main.cpp:83-91 embeds CPython and evaluates the file): this build starts an ordinary interpreter on
+// volren_amd.run_script, which makes `import volpy` resolve to the HIP-backed module and gives `volpy.Renderer()` the -w / -h resolution.  Done before
+// this process has touched the GPU; the interpreter is a child, its exit status is ours.
+static int run_python_script(int argc, char** argv) {
+    std::error_code ec;
+    const fs::path exe = fs::read_symlink("/proc/self/exe", ec);
+    const std::string root = ec ? std::string(".") : exe.parent_path().parent_path().string();      // <root>/volren_amd/volren
+    std::string cmd = "PYTHONPATH='" + root + "'${PYTHONPATH:+:$PYTHONPATH} python3 -m volren_amd.run_script";
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i], q = "'";
+        for (char c : a) { if (c == '\'') q += "'\\''"; else q += c; }
+        cmd += " " + q + "'";
+    }
+    const int rc = std::system(cmd.c_str());
+    return rc == -1 ? 1 : (WIFEXITED(rc) ? WEXITSTATUS(rc) : 1);
+}
+
 int main(int argc, char** argv) {
+    for (int i = 1; i < argc; ++i) {
+        const std::string arg = argv[i];
+        if (arg.size() > 3 && arg.compare(arg.size() - 3, 3, ".py") == 0 && fs::is_regular_file(arg)) return run_python_script(argc, argv);
+    }
     int width = 1280, height = 720, device = 0, gpus = 0;        // cppgl ContextParameters defaults (unverified): always pass -w/-h
     std::vector<int> devices;
     try {

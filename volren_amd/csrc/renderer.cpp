@@ -406,9 +406,16 @@ void RendererHIP::launch(int n) {
         BrickGridHIP& g = density_grids.at(volume->grid_frame_counter);
         if (transferfunc && tf_float_atlas && !g.dense && g.atlas && g.rng && !g.atlas_f32 && !g.atlas_f32_failed) {
             try {
-                for (BrickGridHIP& other : density_grids)               // one decoded atlas at a time: an animation does not keep 4x the atlas per rendered frame
-                    if (&other != &g) other.atlas_f32.reset();
-                g.atlas_f32 = make_device_buffer(g.atlas->size_bytes() * sizeof(float));
+                // decoded atlases of the other animation frames stay while they fit: a looping animation behind a transfer function (the reference cycles
+                // its frames) decodes every frame once, not at every frame change (hipFree synchronises the device).  Budget: half of what the device
+                // has free, and at the latest when the allocation fails, all others go (least recently decoded = lowest index first: no LRU bookkeeping)
+                const size_t want = g.atlas->size_bytes() * sizeof(float);
+                auto drop_others = [&] { for (BrickGridHIP& other : density_grids) if (&other != &g) other.atlas_f32.reset(); };
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = ~(size_t)0; }
+                if (want > free_b / 2) drop_others();
+                try { g.atlas_f32 = make_device_buffer(want); }
+                catch (const std::exception&) { (void)hipGetLastError(); drop_others(); g.atlas_f32 = make_device_buffer(want); }
                 launch_decode_atlas(g.rng->as<float>(), g.atlas->as<uint8_t>(), g.atlas_f32->as<float>(), g.atlas->size_bytes() / 512, stream);
                 VR_HIP(hipGetLastError());
             } catch (const std::exception& e) {

@@ -436,6 +436,7 @@ pathtrace_kernel(const KernelArgs A) {
     }
     constexpr int32_t HS = hot_stride<K>();
     constexpr bool kLazyEm = lazy_emission<K>();
+    static_assert(VR_BATCH_REGS || !kLazyEm, "the VR_BATCH_REGS=0 swap path moves a marching path's radiance through its cold line: a `first` path of a lazy-emission kernel has none");
     __shared__ uint32_t lds_hot[kWgWaves * HS * NS];
     HotStoreT<HS> hs;
     hs.base = lds_hot + wave * (HS * NS);

@@ -286,17 +286,32 @@ class Volume:
             raise TypeError("grid: a dense Volume(w, h, d, data) or a float array [z][y][x]")
         return np.ascontiguousarray(a, np.float32)
 
+    def _record(self, edit):
+        """Keep the edit for a later (re)assignment of this volume; an update supersedes earlier updates of the same (frame, name)."""
+        if edit[0] == "update":
+            self._edits = [e for e in self._edits if not (e[0] == "update" and e[1] == edit[1] and e[3] == edit[3])]
+        self._edits.append(edit)
+
     def add_grid_frame(self, grid, name="density"):
-        """voldata::Volume::add_grid_frame (bindings.cpp:89): a further animation frame that holds `grid` as `name`."""
-        self._edits.append(("add", None, self._dense_of(grid), name))
+        """voldata::Volume::add_grid_frame (bindings.cpp:89): a further animation frame that holds `grid` as `name`.  On a volume that a
+        renderer holds the edit goes to THAT volume object in place, as in the reference (its transform -- scale_and_move_to_unit_cube --
+        and frame counter stay); it takes effect at the next commit()."""
+        dense = self._dense_of(grid)
+        self._record(("add", None, dense, name))
         if self._owner is not None:
-            self._owner._attach_volume(self)
+            if len(self._edits) == 1 and not self.path and self.dense is None:
+                self._owner._attach_volume(self)          # Volume() + the first add_grid_frame: this creates the renderer's volume
+            else:
+                self._owner._r.volume_add_grid_frame(dense, name)
+                object.__setattr__(self._owner, "_committed", False)
 
     def update_grid_frame(self, i, grid, name="density"):
-        """voldata::Volume::update_grid_frame (bindings.cpp:90): grid `name` of frame `i` replaced (or added to that frame)."""
-        self._edits.append(("update", int(i), self._dense_of(grid), name))
+        """voldata::Volume::update_grid_frame (bindings.cpp:90): grid `name` of frame `i` replaced (or added to that frame), in place."""
+        dense = self._dense_of(grid)
+        self._record(("update", int(i), dense, name))
         if self._owner is not None:
-            self._owner._attach_volume(self)
+            self._owner._r.volume_update_grid_frame(int(i), dense, name)
+            object.__setattr__(self._owner, "_committed", False)
 
     def n_grid_frames(self):
         return self._need_owner("n_grid_frames").volume_n_grid_frames()
@@ -371,6 +386,20 @@ class TransferFunction:
     window_width = property(lambda s: s._width, lambda s, v: s._apply("_width", v))
 
 
+# what stands in for the reference's GL context: the resolution (Context::resolution()) and the device renderers are created on
+_CONTEXT = {"width": 1024, "height": 1024, "device": 0}
+
+
+def set_context(width=None, height=None, device=None):
+    """The -w / -h (and --device) of the command line that started the script (src/main.cpp:311-357): the size of every `Renderer()` created
+    without explicit arguments afterwards."""
+    for k, v in (("width", width), ("height", height), ("device", device)):
+        if v is not None:
+            if int(v) < (0 if k == "device" else 1):
+                raise ValueError("%s must be positive" % k)
+            _CONTEXT[k] = int(v)
+
+
 _SCALARS = ("sample", "sppx", "bounces", "seed", "tonemap_exposure", "tonemap_gamma", "tonemapping", "show_environment",
             "phase", "density_scale", "emission_scale", "cam_fov")
 _VEC3S = ("albedo", "vol_clip_min", "vol_clip_max", "cam_pos", "cam_dir", "cam_up")
@@ -379,7 +408,12 @@ _VEC3S = ("albedo", "vol_clip_min", "vol_clip_max", "cam_pos", "cam_dir", "cam_u
 class Renderer:
     """RendererOpenGL as exposed by src/bindings.cpp:117-209."""
 
-    def __init__(self, width=1024, height=1024, device=0):
+    def __init__(self, width=None, height=None, device=None):
+        # `volpy.Renderer()` of the reference's scripts takes its size from the GL context the executable created from -w / -h
+        # (src/main.cpp:311-357, src/renderer.cpp:47); here from set_context(), which volren_amd.run_script calls with the same flags
+        width = _CONTEXT["width"] if width is None else width
+        height = _CONTEXT["height"] if height is None else height
+        device = _CONTEXT["device"] if device is None else device
         object.__setattr__(self, "_r", _Renderer(width, height, device=device))
         object.__setattr__(self, "_volume", None)
         object.__setattr__(self, "_environment", None)
