@@ -104,6 +104,8 @@ def configure_sparse(r, is_oracle, n=512):
 
 
 def configure(r, name, is_oracle):
+    if name.startswith("c5cloud"):
+        return configure_cloud(r, is_oracle, int(name[8:]) if len(name) > 8 else 1024)
     if name.startswith("c5full"):
         return configure_sparse_full(r, is_oracle, int(name[7:]) if len(name) > 7 else 1024)
     if name.startswith("c5"):
@@ -251,9 +253,179 @@ def sparse_brick_arrays_full(n=1024, chunks=160, seed=777):
     return _SPARSE_FULL[key]
 
 
+_CLOUD = {}
+_CLOUD_DENSE = {}
+
+
+def _half_outward(lo, hi):
+    """fp16 range of encoder_ref.encode_arrays, vectorised: minimum rounded down, maximum rounded up."""
+    hl = lo.astype(np.float16)
+    hl = np.where(hl.astype(np.float32) > lo, np.nextafter(hl, np.float16(-np.inf)), hl)
+    hh = hi.astype(np.float16)
+    hh = np.where(hh.astype(np.float32) < hi, np.nextafter(hh, np.float16(np.inf)), hh)
+    return hl, hh
+
+
+def _window_minmax(pad, nb):
+    """(min, max) over the 12^3 neighbourhood (8^3 brick dilated by 2 voxels) of each of the nb^3 bricks of a padded block [8 nb + 4]^3."""
+    lo, hi = pad, pad
+    for axis in range(3):
+        idx = [slice(None)] * 3
+        los, his = [], []
+        for b in range(nb):
+            idx[axis] = slice(8 * b, 8 * b + 12)
+            los.append(lo[tuple(idx)].min(axis=axis, keepdims=True))
+            his.append(hi[tuple(idx)].max(axis=axis, keepdims=True))
+        lo, hi = np.concatenate(los, axis=axis), np.concatenate(his, axis=axis)
+    return lo, hi
+
+
+def cloud_brick_arrays(n=1024, seed=2026, target=0.15):
+    """BASELINE configs[4] as SURVEY 8d specifies it ('c5cloud'): an n^3 sparse brick grid of wdas_cloud-like occupancy -- 10-20 % of its (n/8)^3
+    bricks allocated (1024^3: ~300 000 of 2 097 152) -- holding ONE connected cloud: an ellipsoidal body modulated by five octaves of noise
+    (amplitude ~ 1 / frequency), thresholded, maximum 5.0, plus a temperature grid correlated with the density (emission).  Built directly in brick
+    form, 64^3-voxel blocks at a time (the dense 4 GiB array is never materialised): the field is a sum of separable products of 1-D sinusoids,
+    so a block with its 2-voxel halo is one small matrix product, and blocks that the field's Lipschitz bound proves empty are skipped.  The
+    encoding rules are encoder_ref.encode_arrays' (dilated fp16 ranges rounded outwards, u8 quantisation), vectorised; test_cloud_generator_*
+    checks that on a small n against that encoder.  Returns (density, temperature) dicts: the input of vr_set_volume_brick / oracle Grid.set."""
+    key = (n, seed, target)
+    if key in _CLOUD:
+        return _CLOUD[key]
+    rs = np.random.RandomState(seed)
+    nb = n // 8
+    c = min(64, n)                       # block edge in voxels
+    cells = n // c
+    lb = c // 8
+    # noise: octave o has wavelength n / (3 * 2^o) voxels (>= 21 voxels at n = 1024: smooth at the voxel scale), amplitude 2^-o, 6 terms each
+    terms = []
+    for o in range(5):
+        for _ in range(6):
+            w = 2.0 * np.pi * 3.0 * (2 ** o) / n * rs.uniform(0.7, 1.3, 3)
+            terms.append((rs.uniform(0.6, 1.0) * 0.5 ** o * rs.choice([-1.0, 1.0]), w, rs.uniform(0, 2 * np.pi, 3)))
+    amp = np.array([t[0] for t in terms], np.float32)
+    freq = np.array([t[1] for t in terms])
+    phase = np.array([t[2] for t in terms])
+    axis_pos = np.arange(-2, n + 2, dtype=np.float64)                                   # voxel centres incl. the halo
+    S = [np.sin(freq[:, a:a + 1] * axis_pos[None, :] + phase[:, a:a + 1]).astype(np.float32) for a in range(3)]     # [K][n + 4] per axis
+    centre = np.array([0.5, 0.46, 0.5]) * n
+    radii = np.array([0.40, 0.30, 0.36]) * n
+    body = [(((axis_pos - centre[a]) / radii[a]) ** 2).astype(np.float32) for a in range(3)]   # 1 - sum = ellipsoidal body
+    noise_gain = np.float32(0.55)
+    lipschitz = float(noise_gain * np.sum(np.abs(amp) * np.sqrt((freq ** 2).sum(1))) + 2.0 * np.sqrt(3.0) / radii.min())
+
+    def field(z0, z1, y0, y1, x0, x1):
+        """raw field (before the threshold) on voxels [z0, z1) x [y0, y1) x [x0, x1), halo indices allowed (-2 .. n + 1)"""
+        zs, ys, xs = slice(z0 + 2, z1 + 2), slice(y0 + 2, y1 + 2), slice(x0 + 2, x1 + 2)
+        zy = (S[2][:, zs][:, :, None] * S[1][:, ys][:, None, :]).reshape(len(amp), -1)                   # [K][nz * ny]
+        nz_, ny_, nx_ = z1 - z0, y1 - y0, x1 - x0
+        noise = (zy.T @ (S[0][:, xs] * amp[:, None])).reshape(nz_, ny_, nx_)
+        return (np.float32(1.0) - body[2][zs][:, None, None] - body[1][ys][None, :, None] - body[0][xs][None, None, :]) + noise_gain * noise
+
+    # threshold from the field at the brick centres: `target` of the bricks above it
+    cz = np.arange(4, n, 8)
+    zyc = (S[2][:, cz + 2][:, :, None] * S[1][:, cz + 2][:, None, :]).reshape(len(amp), -1)
+    coarse = (np.float32(1.0) - body[2][cz + 2][:, None, None] - body[1][cz + 2][None, :, None] - body[0][cz + 2][None, None, :]) + \
+        noise_gain * (zyc.T @ (S[0][:, cz + 2] * amp[:, None])).reshape(nb, nb, nb)
+    thr = np.float32(np.quantile(coarse, 1.0 - target * 0.82))           # the dilated ranges allocate ~20 % more bricks than have their centre inside
+    peak = np.float32(max(float(coarse.max()) - float(thr), 1e-3))
+    scale = np.float32(5.0) / peak
+    # a block can only hold non-zero voxels if some brick centre in or next to it comes within reach of the threshold
+    reach = np.float32(lipschitz * (4.0 * np.sqrt(3.0) + 2.0 * np.sqrt(3.0)))
+    near = np.pad(coarse > thr - reach, 1, mode="constant")
+    out = {}
+    state = {}
+    for which in ("density", "temperature"):
+        state[which] = dict(rng=np.zeros((nb, nb, nb), np.uint32), where=[], blocks=[])
+    tw = 2.0 * np.pi * 5.0 / n
+    full = (np.zeros((n, n, n), np.float32), np.zeros((n, n, n), np.float32)) if n <= 256 else None      # small grids: the dense voxels too (cloud_dense)
+    for bz in range(cells):
+        for by in range(cells):
+            for bx in range(cells):
+                if not near[bz * lb:bz * lb + lb + 2, by * lb:by * lb + lb + 2, bx * lb:bx * lb + lb + 2].any():
+                    continue
+                z0, y0, x0 = bz * c, by * c, bx * c
+                raw = field(z0 - 2, z0 + c + 2, y0 - 2, y0 + c + 2, x0 - 2, x0 + c + 2)
+                dens = np.minimum(np.maximum(raw - thr, np.float32(0.0)) * scale, np.float32(5.0))
+                # outside the grid the encoder sees zeros (encoder_ref pads with 0)
+                for a, o in enumerate((z0, y0, x0)):
+                    idx = [slice(None)] * 3
+                    if o == 0:
+                        idx[a] = slice(0, 2); dens[tuple(idx)] = 0
+                    if o + c == n:
+                        idx[a] = slice(c + 2, c + 4); dens[tuple(idx)] = 0
+                if not dens.any():
+                    continue
+                # temperature: hot core, cooler towards the rim, modulated along y and x; zero wherever the density is
+                zi = np.arange(z0 - 2, z0 + c + 2)[:, None, None]
+                yi = np.arange(y0 - 2, y0 + c + 2)[None, :, None]
+                xi = np.arange(x0 - 2, x0 + c + 2)[None, None, :]
+                mod = (np.float32(0.7) + np.float32(0.3) * np.sin(tw * yi + 0.5).astype(np.float32) * np.cos(tw * xi + tw * 0.7 * zi).astype(np.float32))
+                temp = (np.square(dens * np.float32(0.2)) * mod).astype(np.float32)
+                if full is not None:
+                    full[0][z0:z0 + c, y0:y0 + c, x0:x0 + c] = dens[2:c + 2, 2:c + 2, 2:c + 2]
+                    full[1][z0:z0 + c, y0:y0 + c, x0:x0 + c] = temp[2:c + 2, 2:c + 2, 2:c + 2]
+                for which, v in (("density", dens), ("temperature", temp)):
+                    st = state[which]
+                    lo, hi = _window_minmax(v, lb)
+                    hl, hh = _half_outward(lo, hi)
+                    st["rng"][bz * lb:(bz + 1) * lb, by * lb:(by + 1) * lb, bx * lb:(bx + 1) * lb] = hl.view(np.uint16).astype(np.uint32) | (hh.view(np.uint16).astype(np.uint32) << 16)
+                    lo32, hi32 = hl.astype(np.float32), hh.astype(np.float32)
+                    alloc = hi32 != lo32
+                    if not alloc.any():
+                        continue
+                    inner = v[2:c + 2, 2:c + 2, 2:c + 2].reshape(lb, 8, lb, 8, lb, 8).transpose(0, 2, 4, 1, 3, 5)      # [bz][by][bx][z][y][x]
+                    sel = inner[alloc]                                                                                  # [m][8][8][8]
+                    l_, h_ = lo32[alloc][:, None, None, None], hi32[alloc][:, None, None, None]
+                    inv = np.float32(255.0) / (h_ - l_)
+                    q = np.clip(np.floor((sel - l_) * inv + np.float32(0.5)), 0, 255).astype(np.uint8)
+                    lz, ly, lx = np.nonzero(alloc)
+                    st["where"].append(np.stack([lz + bz * lb, ly + by * lb, lx + bx * lb], 1))
+                    st["blocks"].append(q)
+    for which in ("density", "temperature"):
+        st = state[which]
+        where = np.concatenate(st["where"]) if st["where"] else np.zeros((0, 3), np.int64)
+        blocks = np.concatenate(st["blocks"]) if st["blocks"] else np.zeros((0, 8, 8, 8), np.uint8)
+        order = np.lexsort((where[:, 2], where[:, 1], where[:, 0]))        # slots in brick order (z, y, x), as the sequential encoder hands them out
+        where, blocks = where[order], blocks[order]
+        m = len(where)
+        per_layer = nb * nb
+        layers = max(1, (m + per_layer - 1) // per_layer)
+        k = np.arange(m)
+        ind = np.zeros((nb, nb, nb), np.uint32)
+        ind[where[:, 0], where[:, 1], where[:, 2]] = (((k % nb) << 22) | (((k // nb) % nb) << 12) | ((k // per_layer) << 2)).astype(np.uint32)
+        tex = np.zeros((layers * per_layer, 8, 8, 8), np.uint8)
+        tex[:m] = blocks
+        atlas = tex.reshape(layers, nb, nb, 8, 8, 8).transpose(0, 3, 1, 4, 2, 5).reshape(layers * 8, nb * 8, nb * 8)
+        lo_f = (st["rng"] & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)
+        hi_f = (st["rng"] >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+        out[which] = dict(transform=np.eye(4, dtype=np.float32).reshape(16), n_bricks=(nb, nb, nb), min_maj=(float(lo_f.min()), float(hi_f.max())),
+                          brick_counter=m, indirection=ind.reshape(-1), rng=st["rng"].reshape(-1),
+                          atlas_dim=(nb * 8, nb * 8, layers * 8), atlas=np.ascontiguousarray(atlas).reshape(-1), mips=_range_mips(lo_f, hi_f))
+    _CLOUD[key] = (out["density"], out["temperature"])
+    if full is not None:
+        _CLOUD_DENSE[key] = full
+    return _CLOUD[key]
+
+
+def cloud_dense(n, seed=2026, target=0.15):
+    """The dense voxels (density, temperature) behind cloud_brick_arrays for a small n: what the generator's check hands to encoder_ref.encode_arrays."""
+    cloud_brick_arrays(n, seed, target)
+    return _CLOUD_DENSE[(n, seed, target)]
+
+
+def configure_cloud(r, is_oracle, n=1024):
+    """BASELINE configs[4] on the grid of cloud_brick_arrays(): the c5 settings (emission on, albedo 0.9, g 0.3, density x 100, 128 bounces)."""
+    ad, at = cloud_brick_arrays(n)
+    return _configure_brick_pair(r, is_oracle, ad, at)
+
+
 def configure_sparse_full(r, is_oracle, n=1024):
     """The c5 settings (configure_sparse) on the brick-form full-size grid of sparse_brick_arrays_full()."""
     ad, at = sparse_brick_arrays_full(n)
+    return _configure_brick_pair(r, is_oracle, ad, at)
+
+
+def _configure_brick_pair(r, is_oracle, ad, at):
     if is_oracle:
         from oracle import binding as ob
 

@@ -836,7 +836,7 @@ def test_gpu_dense_to_brick_encoder_equals_host_encoder():
     _assert_same(fb, o.render(6), "gpu-encoded dense grid")
 
 
-@pytest.mark.parametrize("name", ["c4:64", "c5:64"])
+@pytest.mark.parametrize("name", ["c4:64", "c5:64", "c5cloud:128"])
 def test_synthetic_baseline_configs_small(name):
     """BASELINE configs[3] / [4] at a size the oracle finishes in seconds: dense fp16 grid (c4) and sparse brick grid +
     temperature grid with emission through the device encoder (c5)."""
@@ -913,6 +913,39 @@ def test_c5_full_size_sparse_1024():
     _assert_same(r.framebuffer(), o.render(4), "c5 1024^3, corner view")
     del r, o
     _full_resolution_properties("c5full", 2048, 2048)
+
+
+@pytest.mark.timeout(900)
+def test_c5_cloud_at_the_occupancy_the_survey_names():
+    """BASELINE configs[4] as SURVEY 8d words it: 1024^3 voxels, wdas_cloud-like occupancy -- 10-20 % of the 2 M bricks allocated -- one connected
+    cloud, temperature grid correlated with the density (scenes.cloud_brick_arrays: 352 k bricks = 16.8 %, 99 % of them one component; the
+    round-1..3 stand-in `c5full` allocates 3 % in 160 sealed blobs).  Bit for bit against the oracle from outside and from inside the cloud,
+    then the properties at 2048 x 2048."""
+    from scipy import ndimage
+    ad, at = scenes.cloud_brick_arrays(1024)
+    nb = 128
+    frac = ad["brick_counter"] / nb ** 3
+    assert 0.10 <= frac <= 0.20, frac
+    rg = ad["rng"].reshape(nb, nb, nb)
+    lab, k = ndimage.label((rg >> 16) != (rg & 0xFFFF))
+    sizes = np.bincount(lab.ravel())[1:]
+    assert sizes.max() >= 0.98 * sizes.sum()                       # one connected cloud (a few detached wisps)
+    assert at["brick_counter"] == ad["brick_counter"] and at["min_maj"][1] > 0.5
+    o = scenes.oracle_scene("c5cloud", 96, 64)
+    r = scenes.hip_scene("c5cloud", 96, 64)
+    r.render(4)
+    fb = r.framebuffer()
+    assert fb[..., :3].max() > 0 and fb[..., 3].mean() > 0.2
+    _assert_same(fb, o.render(4), "c5cloud 1024^3")
+    for x in (r, o):                                               # from inside the cloud's body
+        x.cam_pos = (0.05, -0.02, 0.1)
+        x.cam_dir = (-0.5, 0.3, -0.81)
+    r.reset()
+    o.sample = 0
+    r.render(4)
+    _assert_same(r.framebuffer(), o.render(4), "c5cloud 1024^3, inside view")
+    del r, o
+    _full_resolution_properties("c5cloud", 2048, 2048)
 
 
 def test_readme_command_reproduces_the_reference_example_image():

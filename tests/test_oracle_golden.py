@@ -208,3 +208,25 @@ def test_white_furnace():
     r.density_scale = 20.0
     fb = r.render(64)
     assert abs(fb[..., :3].mean() - 1.0) < 0.03
+
+
+def test_cloud_generator_equals_the_reference_encoder():
+    """scenes.cloud_brick_arrays builds BASELINE configs[4]'s grid ('c5cloud') in brick form, block by block, with a vectorised restatement of
+    the encoder's rules; on a grid small enough to hold densely it must equal encoder_ref.encode_arrays of the same voxels word for word --
+    across block borders (128^3 = 8 blocks with halos, some of them skipped as empty) and for both grids."""
+    import encoder_ref
+    import scenes
+    n = 128
+    ad, at = scenes.cloud_brick_arrays(n)
+    dd, dt = scenes.cloud_dense(n)
+    assert dd.max() == 5.0 and (dt > 0).sum() <= (dd > 0).sum() and dt[dd == 0].max() == 0.0        # the temperature lives where the density does
+    for a, d in ((ad, dd), (at, dt)):
+        e = encoder_ref.encode_arrays(d)
+        assert a["brick_counter"] == e["brick_counter"] > 0 and tuple(a["atlas_dim"]) == tuple(e["atlas_dim"]) and a["min_maj"] == e["min_maj"]
+        for k in ("indirection", "rng", "atlas"):
+            assert np.array_equal(np.asarray(a[k]), np.asarray(e[k])), k
+        for (da, wa), (de, we) in zip(a["mips"], e["mips"]):
+            assert tuple(da) == tuple(de) and np.array_equal(wa, we)
+    # the occupancy falls towards the 1024^3 grid's 16.8 % as the surface-to-volume ratio does (asserted at full size by the GPU suite)
+    a256, _ = scenes.cloud_brick_arrays(256)
+    assert 0.15 < a256["brick_counter"] / 32 ** 3 < 0.35
