@@ -36,7 +36,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-GATHER_CEILINGS = {"l1": 1002.0, "l2": 268.0, "beyond_l2": 56.0}      # G per-lane accesses/s, whole chip, fully divergent dword loads (profiles/r2_gather_rate.txt)
+SIMDS = 1024                 # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4              # peak engine clock, MI355X_MICROARCH.md
+CYCLES_PER_VALU_OP = 1.8     # a wave64 fp32 VALU instruction occupies a SIMD for 1.8 cycles with >= 4 resident wavefronts (profiles/r2_valu_issue_rate.txt)
+COUNTER_SPP = 8              # oracle samples per pixel behind events_per_sample (COUNTER_SPP batches of 1 spp: their spread is the standard error)
 CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}
 
 
@@ -94,13 +97,12 @@ def algorithmic_bytes_per_sample(counters, use_tf, has_emission, dense=False):
                    primary_miss=counters["n_primary_miss"] / n)
 
 
-def cpu_baseline_and_counters(config, budget_s, integrator=0, kind="port", aspect=1.0):
+def cpu_baseline(config, budget_s, integrator=0, kind="port", aspect=1.0, size=None, spp=None):
     """Oracle on the host cores: low-resolution full view of the same scene (same camera and aspect ratio, so the same mix
-    of box-missing and cloud pixels), spp chosen to fill ~budget_s seconds."""
+    of box-missing and cloud pixels), spp chosen to fill ~budget_s seconds -- or the frame (size, spp) as given, repeated to fill the budget."""
     import scenes
     from oracle import binding as ob
-    cw = 512
-    ch = max(16, int(round(cw / aspect / 2)) * 2)
+    cw, ch = size if size else (512, max(16, int(round(512 / aspect / 2)) * 2))
 
     def scene():
         o = scenes.oracle_scene(config, cw, ch)
@@ -108,24 +110,52 @@ def cpu_baseline_and_counters(config, budget_s, integrator=0, kind="port", aspec
         return o
     o = scene()
     o.render(1)                                          # library load, thread pool start
-    probe = 1
-    while True:                                          # probe long enough (>= 1 s) that burst clocks / quotas do not skew the estimate
+    reps = 1
+    if spp is None:
+        probe = 1
+        while True:                                      # probe long enough (>= 1 s) that burst clocks / quotas do not skew the estimate
+            t0 = time.time()
+            o.render(probe)
+            dt = time.time() - t0
+            if dt >= min(1.0, budget_s) or probe >= 1024:
+                break
+            probe *= 2
+        rate = cw * ch * probe / max(dt, 1e-6)
+        spp = int(max(1, min(4096, budget_s * rate / (cw * ch))))
+        o2 = scene()
         t0 = time.time()
-        o.render(probe)
+        o2.render(spp)
         dt = time.time() - t0
-        if dt >= min(1.0, budget_s) or probe >= 1024:
-            break
-        probe *= 2
-    rate = cw * ch * probe / max(dt, 1e-6)
-    spp = int(max(1, min(4096, budget_s * rate / (cw * ch))))
-    o2 = scene()
-    t0 = time.time()
-    o2.render(spp)
-    dt = time.time() - t0
+    else:
+        t0 = time.time()
+        while True:                                      # the frame as BASELINE names it, as often as fits the budget (at least once)
+            o2 = scene()
+            o2.render(spp)
+            dt = time.time() - t0
+            if dt >= budget_s:
+                break
+            reps += 1
     cores = ob.lib().orc_num_threads()
     what = "oracle/liboracle.so, OpenMP over rows" + (", 64-step ray-marching trackers (common.glsl:506-566)" if integrator == 3 else "")
-    return dict(value=cw * ch * spp / dt / 1e6, unit="Msamples/s", cores=int(cores), kind=kind,
-                sample="%s scene at %dx%d, %d spp (%.1f s of %s)" % (config, cw, ch, spp, dt, what)), o2.counters.as_dict()
+    return dict(value=cw * ch * spp * reps / dt / 1e6, unit="Msamples/s", cores=int(cores), kind=kind,
+                sample="%s scene at %dx%d, %d spp%s (%.1f s of %s)" % (config, cw, ch, spp, " x %d frames" % reps if reps > 1 else "", dt, what))
+
+
+def event_counters(config, aspect=1.0):
+    """Event counts per sample from the oracle's instrumented counters on the same config and seed: COUNTER_SPP batches of one sample
+    per pixel of a 256-pixel-wide full view.  Returns (summed counters, list of per-batch counters): the batches' spread gives the standard error
+    of the bytes per sample behind roofline.frac."""
+    import scenes
+    cw = 256
+    ch = max(16, int(round(cw / aspect / 2)) * 2)
+    o = scenes.oracle_scene(config, cw, ch)
+    batches, prev = [], {k: 0 for k in o.counters.as_dict()}
+    for _ in range(COUNTER_SPP):
+        o.render(1)
+        cur = o.counters.as_dict()
+        batches.append({k: cur[k] - prev[k] for k in cur})
+        prev = cur
+    return prev, batches
 
 
 def profile_json(name):
@@ -156,7 +186,7 @@ def traffic_profile(cfg):
     """(entry, file, stale) of the newest committed PMC profile that has this config, or (None, None, None)."""
     key = cfg.split("@")[0]
     key = {"c4:512": "c4"}.get(key, key)
-    for name in ("r3_hbm_traffic.json", "r2_hbm_traffic.json"):
+    for name in ("r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
         tj = profile_json(name)
         if tj and key in tj.get("configs", {}):
             return tj["configs"][key], "profiles/" + name, tj.get("kernel_source_sha") != kernel_source_sha()
@@ -280,10 +310,18 @@ class Bench:
         return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, value_single_frame=samples / single / 1e6, ms_single_frame=single * 1e3, kernel_ms=(pt_ms if pt_ms > 0 else last_ms) / launches, frame_gpu_ms=last_ms,
                     launches=launches, samples_per_launch=my_samples / launches)
 
-    def roofline(self, m, counters):
+    def roofline(self, m, counted):
+        counters, batches = counted
         cfg = self.config
         use_tf = cfg == "c3"
-        b_sample, events = algorithmic_bytes_per_sample(counters, use_tf, cfg.startswith("c5"), dense=cfg.startswith("c4"))
+        use_em = cfg.startswith("c5")
+        dense = cfg.startswith("c4")
+        b_sample, events = algorithmic_bytes_per_sample(counters, use_tf, use_em, dense=dense)
+        per_batch = [algorithmic_bytes_per_sample(b, use_tf, use_em, dense=dense)[0] for b in batches]
+        mean_b = sum(per_batch) / len(per_batch)
+        stderr = (sum((x - mean_b) ** 2 for x in per_batch) / max(1, len(per_batch) - 1)) ** 0.5 / len(per_batch) ** 0.5
+        events["oracle_samples"] = int(counters["samples"])
+        events["oracle_spp"] = len(batches)
         achieved = b_sample * m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tp, tp_file, stale = traffic_profile(cfg)                               # PMC passes (FETCH_SIZE / WRITE_SIZE), collected separately
@@ -292,34 +330,34 @@ class Bench:
             traffic_src = {"from_profile": tp_file, "stale": bool(stale),
                            "note": "not measured by this run: rocprofv3 --pmc passes of %s (bytes = 2 x FETCH_SIZE + WRITE_SIZE: profiles/r3j_fetch_size_calibration.txt), scaled to this launch's samples%s" % (
                                tp.get("command", "?"), "; the kernel sources have changed since that profile was taken" if stale else "")}
-        use_em = cfg.startswith("c5")
-        variant = "dense" if cfg.startswith("c4") else ("emission" if use_em else "brick")
-        # second yardstick: the path tracer's loads are per-lane gathers, priced here at the throughput this GPU sustains for fully
-        # divergent wave-level loads served by L1 / L2 / beyond L2 (tests/tools_gather_rate.hip, profiles/r2_gather_rate.txt)
-        gather = None
-        if tp and "per_sample" in tp:
-            ps, hit = tp["per_sample"], tp["l2_hit_rate"]
-            acc, miss = ps["l1_accesses"], ps["l1_misses_to_l2"]
-            beyond = miss * (1.0 - hit)
-            ns = (acc - miss) / GATHER_CEILINGS["l1"] + (miss - beyond) / GATHER_CEILINGS["l2"] + beyond / GATHER_CEILINGS["beyond_l2"]
-            model = 1e3 / ns                                                    # Msamples/s
-            kernel_rate = m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e6
-            gather = {"model": "additive: per-lane accesses x the measured cost of a fully divergent gather at the level that serves it",
-                      "ceilings_G_lane_accesses_per_s": GATHER_CEILINGS, "ceilings_source": "profiles/r2_gather_rate.txt",
-                      "per_sample": {"l1_accesses": acc, "l1_misses": miss, "beyond_l2": beyond}, "counts_source": tp_file, "stale": bool(stale),
-                      "model_Msamples_s": model, "kernel_Msamples_s": kernel_rate, "kernel_over_model": kernel_rate / model}
+        variant = "dense" if dense else ("emission" if use_em else "brick")
+        kernel_rate = m["samples_per_launch"] / (m["kernel_ms"] * 1e-3)         # samples/s of the kernel alone
+        # The resource that binds: vector-instruction issue at partial lane utilisation, not HBM.  VALU wave-instructions per sample come
+        # from the PMC profile (SQ_INSTS_VALU of the same kernel; `stale` when the kernel sources changed since), the rate is this run's: achieved =
+        # wave-instructions/s the kernel issued, peak = what 1024 SIMDs issue at 2.4 GHz when an instruction occupies a SIMD for 1.8 cycles.
+        issue = None
+        if tp and "per_sample" in tp and "valu" in tp["per_sample"]:
+            valu = tp["per_sample"]["valu"]
+            peak_issue = SIMDS * CLOCK_GHZ / CYCLES_PER_VALU_OP                 # G wave-instructions/s
+            ach_issue = valu * kernel_rate / 1e9
+            issue = {"bound": "valu_issue", "achieved": ach_issue, "peak": peak_issue, "unit": "G wave-instructions/s", "frac": ach_issue / peak_issue,
+                     "valu_wave_instructions_per_sample": valu, "lane_utilisation": tp.get("lane_utilisation"), "hbm_frac": achieved / HBM_PEAK_GBS,
+                     "cycles_per_valu_op": CYCLES_PER_VALU_OP, "cycles_source": "profiles/r2_valu_issue_rate.txt", "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
+                     "counts_source": tp_file, "stale": bool(stale),
+                     "summary": "hbm %.2f / issue %.2f / lanes %s" % (achieved / HBM_PEAK_GBS, ach_issue / peak_issue, ("%.2f" % tp["lane_utilisation"]) if tp.get("lane_utilisation") else "?")}
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "pathtrace_kernel<TraceCfg<tf=%s, %s>, false>" % ("true" if use_tf else "false", variant),
                 "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "samples_per_launch": m["samples_per_launch"],
-                "bytes_per_sample": b_sample, "events_per_sample": events, "gather": gather,
-                "note": "bytes = algorithmic (SURVEY 8d); the kernel is limited by its work per sample (vector instructions and fully divergent vector-memory accesses at ~73 % lane utilisation), not by HBM bandwidth nor by where its gathers hit (DESIGN.md 7, profiles/r3c_whatif_voxel_taps_in_cache.txt): 2-9 useful bytes per 128-byte line"}
+                "bytes_per_sample": b_sample, "bytes_per_sample_stderr": stderr, "events_per_sample": events, "roofline_issue": issue,
+                "note": "bytes = algorithmic (SURVEY 8d), event counts from %d oracle samples per pixel (stderr over the batches); the kernel is limited by its work per sample (vector instructions and fully divergent vector-memory accesses at ~74 %% lane utilisation: roofline_issue), not by HBM bandwidth nor by where its gathers hit (DESIGN.md 5, profiles/r3c_whatif_voxel_taps_in_cache.txt): 2-9 useful bytes per 128-byte line" % len(batches)}
 
 
 def workload_name(config, w, h, spp):
     what = "synthetic dense fp16 grid" if config.startswith("c4") else ("synthetic sparse brick grid + temperature grid (emission)" if config.startswith("c5") else "smoke.brick")
     tf = " + lut.txt" if config == "c3" else (", no transfer function" if not config.startswith(("c4", "c5")) else "")
-    size = " (1024^3 voxels, brick-form generator)" if config.startswith("c5full") else (" (512^3 voxels)" if config in ("c4", "c4:512") else "")
+    size = (" (1024^3 voxels, 16.8 % of 2 M bricks allocated, one connected cloud: SURVEY 8d's occupancy)" if config == "c5cloud" else
+            " (1024^3 voxels, 3 % of the bricks allocated in 160 sealed blobs: rounds 1-3's stand-in)" if config.startswith("c5full") else (" (512^3 voxels)" if config in ("c4", "c4:512") else ""))
     return "BASELINE configs[%d] '%s': %s%s%s, %dx%d, %d spp, seed 42, fov 40" % (CONFIG_INDEX.get(config[:2], -1), config, what, size, tf, w, h, spp)
 
 
@@ -395,11 +433,10 @@ def main():
     out = None
     if rank == 0:
         use_tf = args.config == "c3"
-        cpu = cpu_rm = None
+        cpu = None
         if world == 1 and dist is None and args.cpu_budget > 0:
-            cpu, counters = cpu_baseline_and_counters(args.config, args.cpu_budget, aspect=w / h)
-        else:
-            _, counters = cpu_baseline_and_counters(args.config, 0.5, aspect=w / h)
+            cpu = cpu_baseline(args.config, args.cpu_budget, aspect=w / h)
+        counted = event_counters(args.config, aspect=w / h)
         out = {
             "metric": "Msamples/s (pixels x spp / s), volume path tracing",
             "value": m["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -412,17 +449,21 @@ def main():
                                       "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
             "config": {"workload": workload_name(args.config, w, h, spp),
                        "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, ", consecutive frames pipelined over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, %d fused launch(es)/frame (16 GiB sample pool)%s%s" % (m["launches"], ", consecutive frames pipelined over 2 streams" if b.pipelined else "", ", one-rank process group: pack_tiles -> all_gather -> unpack_tiles per frame" if dist is not None else "")},
-            "roofline": b.roofline(m, counters),
+            "roofline": b.roofline(m, counted),
             "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
             "dist_backend": (dist.get_backend() if dist is not None else None),
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-            try:                                               # second baseline SURVEY 8d names: the 64-step ray marcher
-                cpu_rm, _ = cpu_baseline_and_counters(args.config, min(args.cpu_budget, 6.0), integrator=3, kind="raymarch-64", aspect=w / h)
-                out["cpu_baseline_raymarch"] = cpu_rm
-            except Exception as e:                             # noqa: BLE001 -- a missing optional leg must not lose the headline line
-                out["cpu_baseline_raymarch"] = {"error": str(e)}
+            for key, fn in (("cpu_baseline_raymarch", lambda: cpu_baseline(args.config, min(args.cpu_budget, 6.0), integrator=3, kind="raymarch-64", aspect=w / h)),
+                            # BASELINE configs[0] itself ("c1": smoke.brick + envmap, 256x256, 16 spp, 4 bounces, CPU ray-march reference, no GPU): the frame as
+                            # named, by the 64-step ray-marching trackers and by the DDA trackers the reference's kernels use
+                            ("cpu_baseline_c1", lambda: dict(cpu_baseline("c1", min(args.cpu_budget, 3.0), integrator=3, kind="raymarch-64", size=(256, 256), spp=16),
+                                                             dda=cpu_baseline("c1", min(args.cpu_budget, 3.0), integrator=0, kind="port", size=(256, 256), spp=16)))):
+                try:
+                    out[key] = fn()
+                except Exception as e:                         # noqa: BLE001 -- a missing optional leg must not lose the headline line
+                    out[key] = {"error": str(e)}
 
     # tolerance-mode kernels (v_log/v_rcp/v_sin hardware math): speed and distance from the bit-exact default, same frame
     if world == 1 and dist is None and args.extra_configs != "none" and getattr(b.r, "has_fast_math", lambda: False)():
@@ -440,7 +481,7 @@ def main():
     # the other single-GPU BASELINE configs at the resolution north_star quotes (driver-run, not builder-only)
     extra = args.extra_configs
     if extra is None:
-        extra = "c3,c4,c4@1920x1080x4096,c5full@2048x2048x4096" if (args.config == "c2" and world == 1 and dist is None) else "none"
+        extra = "c3,c4,c4@1920x1080x4096,c5full@2048x2048x4096,c5cloud@2048x2048x4096" if (args.config == "c2" and world == 1 and dist is None) else "none"
     if rank == 0 and world == 1 and extra != "none":
         del b
         out["configs"] = []
@@ -451,7 +492,7 @@ def main():
             try:
                 bx = Bench(name, fw, fh, fspp, 1, 0, local_rank, None, pipelined=False)      # one frame at a time: BASELINE configs[3..4] are single frames
                 mx = bx.measure(steps_x, 1)
-                _, cx = cpu_baseline_and_counters(name, 0.5, aspect=fw / fh)
+                cx = event_counters(name, aspect=fw / fh)
                 out["configs"].append({"name": spec, "workload": workload_name(name, fw, fh, fspp), "value": mx["value"], "unit": "Msamples/s",
                                        "ms_per_step": mx["ms_per_step"], "steps": steps_x, "warmup": 1, "pipelined": False, "roofline": bx.roofline(mx, cx)})
                 del bx

@@ -22,5 +22,5 @@ for v in 0 1 2 3; do
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libvolren_amd.so $out/vr_kernels.o $out/vr_pathtrace_0.o $out/vr_pathtrace_1.o $out/vr_pathtrace_2.o $out/vr_pathtrace_3.o $out/vr_pathtrace_fast_0.o $out/vr_pathtrace_fast_1.o $out/vr_pathtrace_fast_2.o $out/vr_pathtrace_fast_3.o build/grids.o build/imageio.o $out/environment.o build/transferfunc.o $out/renderer.o build/capi.o -lz
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libvolren_amd.so $out/vr_kernels.o $out/vr_pathtrace_0.o $out/vr_pathtrace_1.o $out/vr_pathtrace_2.o $out/vr_pathtrace_3.o $out/vr_pathtrace_fast_0.o $out/vr_pathtrace_fast_1.o $out/vr_pathtrace_fast_2.o $out/vr_pathtrace_fast_3.o build/grids.o build/imageio.o $out/environment.o build/transferfunc.o $out/renderer.o build/sharded.o build/capi.o -lz -ldl
 grep -h -A8 "TraceCfgILb0ELi0ELi0ELi[01]EEELb0E" $out/res_0.txt $out/res_1.txt | grep -E "VGPRs:|ScratchSize|Occupancy|LDS" | sed 's/.*remark: [^ ]* *//; s/ \[-R.*//' | paste - - - - 

@@ -595,7 +595,7 @@ pathtrace_kernel(const KernelArgs A) {
             MarchIO mio;
             march_idle(mio);
             if (is_m) march_prep<K::dense>(l, P, mio);
-            if (kMajCells > 0) march_load_lds<K::tf, MajT>(P, mio, lds_maj, maj_first);
+            if constexpr (kMajCells > 0) march_load_lds<K::tf, MajT>(P, mio, lds_maj, maj_first);
             else march_load<K::tf>(P, mio);
 #if VR_MARCH_LOADS_PINNED
             // Both majorants must have been REQUESTED before the first is used.  Left alone, the compiler sinks each load into the

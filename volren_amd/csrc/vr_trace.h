@@ -183,6 +183,14 @@ VR_HD TapData tap_load(const GridView& g, TapAddr a) {
         const float* rec = g.rng + 2u * (size_t)a.cell;          // compact (rmin, rdiff) pairs: twice as many bricks per cache line as BrickRec
         d.rmin = rec[0]; d.rdiff = rec[1];
         d.raw = g.atlas[(size_t)a.cell * 512u + a.off];
+#if defined(VR_DIAG_EXTRA_RNG) && defined(__HIP_DEVICE_COMPILE__)
+        {   // diagnostic (profiles/r4c_*): one more gather of the record's kind per tap, from the record of another brick -- what does such a gather cost?
+            const uint32_t n_ = (uint32_t)g.nb[0] * (uint32_t)g.nb[1] * (uint32_t)g.nb[2];
+            uint32_t c_ = a.cell * 2654435761u; c_ = c_ % n_;
+            float x_ = g.rng[2u * (size_t)c_];
+            asm volatile("" :: "v"(x_));
+        }
+#endif
     }
     return d;
 }
@@ -840,6 +848,8 @@ VR_HD void march_load(const SceneParams& P, MarchIO& io) {
 #pragma unroll
     for (int k = 0; k < kMarchSteps; ++k) io.maj[k] = majorant_fetch<TF>(P.density, io.idx[k]);
 }
+template <bool TF, class T>
+VR_HD void march_load_lds(const SceneParams&, MarchIO&, const T*, int32_t) { static_assert(sizeof(T) == 0, "VR_MAJ_LDS is written for VR_MARCH_STEPS == 2"); }
 template <bool TF>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     float tau = h.tau, maj = 0.0f, t = h.t;
