@@ -182,14 +182,19 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def traffic_profile(cfg):
-    """(entry, file, stale) of the newest committed PMC profile that has this config, or (None, None, None)."""
-    key = cfg.split("@")[0]
-    key = {"c4:512": "c4"}.get(key, key)
+def traffic_profile(cfg, w, h):
+    """(entry, file, stale) of the newest committed PMC profile taken on this configuration AT THIS FRAME SIZE (the instruction and traffic mix per sample
+    depends on the view: c4 at 1920x1080 is not c4 at 1024x1024), or (None, None, None).  Round 4's file is keyed by the bench line's config names and
+    records the frame; older files only have the square frames of their rounds."""
     for name in ("r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
         tj = profile_json(name)
-        if tj and key in tj.get("configs", {}):
-            return tj["configs"][key], "profiles/" + name, tj.get("kernel_source_sha") != kernel_source_sha()
+        if not tj:
+            continue
+        for key, e in tj.get("configs", {}).items():
+            scene = e.get("scene") or {"c4": "c4:512"}.get(key, key)
+            frame = e.get("frame") or ([2048, 2048] if key.startswith("c5") else [1024, 1024])
+            if scene in (cfg, {"c4": "c4:512"}.get(cfg, cfg)) and list(frame) == [w, h]:
+                return e, "profiles/" + name, tj.get("kernel_source_sha") != kernel_source_sha()
     return None, None, None
 
 
@@ -324,7 +329,7 @@ class Bench:
         events["oracle_spp"] = len(batches)
         achieved = b_sample * m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        tp, tp_file, stale = traffic_profile(cfg)                               # PMC passes (FETCH_SIZE / WRITE_SIZE), collected separately
+        tp, tp_file, stale = traffic_profile(cfg, self.w, self.h)               # PMC passes (FETCH_SIZE / WRITE_SIZE), collected separately
         if tp and "hbm_bytes_per_sample" in tp:
             traffic = tp["hbm_bytes_per_sample"] * m["samples_per_launch"]
             traffic_src = {"from_profile": tp_file, "stale": bool(stale),

@@ -28,7 +28,7 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
     const uint32_t sx = ad[0] / 8, sy = ad[1] / 8, sz = ad[2] / 8;
     for (int i = 0; i < 3; ++i) { g.view.mshift[i] = ceil_log2(nb[i]) < 3 ? 3 : ceil_log2(nb[i]); g.view.mlim[i] = (float)(8u << g.view.mshift[i]); }
     g.recs.assign(n, BrickRec{ 0u, 0.f, 0.f, 0u });
-    g.atlas.assign(g.recs.size() * 512, 0);                                 // brick-linear blocks == brick_grid_to_device
+    g.atlas.assign(g.recs.size() * (size_t)kBrickBlockBytes, 0);            // brick-linear blocks == brick_grid_to_device
     for (size_t i = 0; i < n; ++i) {
         const uint32_t ind = indirection[i], rg = range[i];
         const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
@@ -36,9 +36,14 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
         const size_t idx = i;
         BrickRec& r = g.recs[idx];
         r.slot = (uint32_t)idx; r.rmin = lo; r.rdiff = hi - lo; r.range = rg;
+        uint8_t* dst = &g.atlas[idx * (size_t)kBrickBlockBytes];
+        if (VR_BRICK_HEADERS)
+            for (uint32_t l = 0; l < 5; ++l) { memcpy(dst + l * 128u, &r.rmin, 4); memcpy(dst + l * 128u + 4u, &r.rdiff, 4); }
         if (r.rdiff != 0.f && px < sx && py < sy && pz < sz)
-            for (uint32_t z = 0; z < 8; ++z) for (uint32_t y = 0; y < 8; ++y)
-                memcpy(&g.atlas[idx * 512 + z * 64 + y * 8], atlas + (((size_t)(pz * 8 + z) * ad[1] + (py * 8 + y)) * ad[0] + px * 8), 8);
+            for (uint32_t z = 0; z < 8; ++z) for (uint32_t y = 0; y < 8; ++y) {
+                const uint8_t* src = atlas + (((size_t)(pz * 8 + z) * ad[1] + (py * 8 + y)) * ad[0] + px * 8);
+                for (uint32_t x = 0; x < 8; ++x) dst[brick_voxel_byte(z * 64 + y * 8 + x)] = src[x];
+            }
     }
     std::vector<uint32_t> words(range, range + n);
     uint32_t mip_off[4] = { 0u, 0u, 0u, 0u };
@@ -73,8 +78,9 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
     g.view.majorant16 = g.majorant16.data(); g.view.rng = g.rng.data();
     g.view.atlas_f32 = nullptr;
     if (density && u.use_tf) {                  // == RendererHIP::launch: decoded float atlas for transfer-function renders
-        g.atlas_f32.resize(g.atlas.size());
-        for (size_t i = 0; i < g.atlas.size(); ++i) g.atlas_f32[i] = g.rng[2 * (i >> 9)] + unorm8(g.atlas[i]) * g.rng[2 * (i >> 9) + 1];
+        g.atlas_f32.resize(g.recs.size() * 512);
+        for (size_t i = 0; i < g.atlas_f32.size(); ++i)
+            g.atlas_f32[i] = g.rng[2 * (i >> 9)] + unorm8(g.atlas[(i >> 9) * (size_t)kBrickBlockBytes + brick_voxel_byte((uint32_t)(i & 511u))]) * g.rng[2 * (i >> 9) + 1];
         g.view.atlas_f32 = g.atlas_f32.data();
     }
     for (int i = 0; i < 3; ++i) g.view.nb[i] = (int32_t)nb[i];

@@ -156,8 +156,8 @@ BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseG
     uint32_t* words = out.range_words->as<uint32_t>();
     launch_encode_ranges(dense.as<float>(), dim, nb, words, flag.as<uint32_t>(), stream);
     VR_HIP(hipGetLastError());
-    check_grid_bytes(brick_records(out) * (512 + sizeof(BrickRec) + 8), "the brick-linear atlas", out.nb);
-    out.atlas = make_device_buffer(brick_records(out) * 512);               // brick-linear blocks (see brick_grid_to_device)
+    check_grid_bytes(brick_records(out) * (kBrickBlockBytes + sizeof(BrickRec) + 8), "the brick-linear atlas", out.nb);
+    out.atlas = make_device_buffer(brick_records(out) * kBrickBlockBytes);   // brick-linear blocks (see brick_grid_to_device)
     VR_HIP(hipMemsetAsync(out.atlas->get(), 0, out.atlas->size_bytes(), stream));
     out.bricks = make_device_buffer(brick_records(out) * sizeof(BrickRec));
     VR_HIP(hipMemsetAsync(out.bricks->get(), 0, out.bricks->size_bytes(), stream));
@@ -216,16 +216,16 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
     if (n_bricks == 0) throw std::runtime_error("brick_grid_to_device: empty grid");
     out.nb[0] = (int)nb.x; out.nb[1] = (int)nb.y; out.nb[2] = (int)nb.z;
     out.transform = g->transform;
-    // atlas: 3D texture of 8^3 blocks addressed through the indirection words -> brick-LINEAR blocks of 512 contiguous bytes:
-    // the block of brick record i is bytes [512 i, 512 i + 512), so that a tap fetches record and voxel in one round trip
-    // instead of chasing the pointer (vr_trace.h tap_load).  A brick whose range is a single value keeps a zero block (its
-    // voxels never matter: rmin + u * 0), and so does a pointer outside the atlas (GL: undefined fetch).
+    // atlas: 3D texture of 8^3 blocks addressed through the indirection words -> brick-LINEAR blocks: the block of brick record i is bytes
+    // [640 i, 640 i + 640), five cache lines of [rmin, rdiff | 120 voxels] (vr_scene.h), so that a tap fetches range and voxel from one line
+    // instead of chasing the pointer (vr_trace.h tap_load).  A brick whose range is a single value keeps zero voxels (they never matter:
+    // rmin + u * 0), and so does a pointer outside the atlas (GL: undefined fetch); every line of every brick carries the range.
     const uvec3 ad = g->atlas.stride;
     const uint32_t sx = ad.x / 8, sy = ad.y / 8, sz = ad.z / 8;
     upload_range_words(out, nb, g->range, g->range_mipmaps);        // also fixes the padded majorant layout (mshift)
-    check_grid_bytes(brick_records(out) * (512 + sizeof(BrickRec) + 8), "the brick-linear atlas", out.nb);
+    check_grid_bytes(brick_records(out) * (kBrickBlockBytes + sizeof(BrickRec) + 8), "the brick-linear atlas", out.nb);
     std::vector<BrickRec> recs(brick_records(out), BrickRec{ 0u, 0.f, 0.f, 0u });
-    std::vector<uint8_t> atlas(recs.size() * 512, 0);
+    std::vector<uint8_t> atlas(recs.size() * (size_t)kBrickBlockBytes, 0);
     for (size_t i = 0; i < n_bricks; ++i) {
         const uint32_t ind = g->indirection.data[i], rg = g->range.data[i];
         const uint32_t px = ind >> 22, py = (ind >> 12) & 1023u, pz = (ind >> 2) & 1023u;
@@ -237,11 +237,15 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
         r.rdiff = hi - lo;
         r.range = rg;
         recs[idx] = r;
+        uint8_t* dst = &atlas[idx * (size_t)kBrickBlockBytes];
+        if (VR_BRICK_HEADERS)
+            for (uint32_t l = 0; l < 5; ++l) { memcpy(dst + l * 128u, &r.rmin, 4); memcpy(dst + l * 128u + 4u, &r.rdiff, 4); }
         if (r.rdiff != 0.f && px < sx && py < sy && pz < sz) {
-            uint8_t* dst = &atlas[idx * 512];
             for (uint32_t z = 0; z < 8; ++z)
-                for (uint32_t y = 0; y < 8; ++y)
-                    memcpy(dst + z * 64 + y * 8, &g->atlas.data[g->atlas.index(px * 8, py * 8 + y, pz * 8 + z)], 8);
+                for (uint32_t y = 0; y < 8; ++y) {
+                    const uint8_t* src = &g->atlas.data[g->atlas.index(px * 8, py * 8 + y, pz * 8 + z)];
+                    for (uint32_t x = 0; x < 8; ++x) dst[brick_voxel_byte(z * 64 + y * 8 + x)] = src[x];
+                }
         }
     }
     out.bricks = make_device_buffer(recs.size() * sizeof(BrickRec));
@@ -409,20 +413,20 @@ void RendererHIP::launch(int n) {
                 // decoded atlases of the other animation frames stay while they fit: a looping animation behind a transfer function (the reference cycles
                 // its frames) decodes every frame once, not at every frame change (hipFree synchronises the device).  Budget: half of what the device
                 // has free, and at the latest when the allocation fails, all others go (least recently decoded = lowest index first: no LRU bookkeeping)
-                const size_t want = g.atlas->size_bytes() * sizeof(float);
+                const size_t n_blocks = g.atlas->size_bytes() / kBrickBlockBytes, want = n_blocks * 512u * sizeof(float);
                 auto drop_others = [&] { for (BrickGridHIP& other : density_grids) if (&other != &g) other.atlas_f32.reset(); };
                 size_t free_b = 0, total_b = 0;
                 if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = ~(size_t)0; }
                 if (want > free_b / 2) drop_others();
                 try { g.atlas_f32 = make_device_buffer(want); }
                 catch (const std::exception&) { (void)hipGetLastError(); drop_others(); g.atlas_f32 = make_device_buffer(want); }
-                launch_decode_atlas(g.rng->as<float>(), g.atlas->as<uint8_t>(), g.atlas_f32->as<float>(), g.atlas->size_bytes() / 512, stream);
+                launch_decode_atlas(g.rng->as<float>(), g.atlas->as<uint8_t>(), g.atlas_f32->as<float>(), n_blocks, stream);
                 VR_HIP(hipGetLastError());
             } catch (const std::exception& e) {
                 (void)hipGetLastError();
                 g.atlas_f32.reset();
                 g.atlas_f32_failed = true;      // not retried per launch: a per-sample trace() loop would pay a failing multi-GB hipMalloc every call
-                std::cerr << "volren_amd: no room for the decoded float atlas (" << (g.atlas->size_bytes() * sizeof(float) >> 20) << " MiB): transfer-function taps read the byte atlas (" << e.what() << ")" << std::endl;
+                std::cerr << "volren_amd: no room for the decoded float atlas (" << (g.atlas->size_bytes() / kBrickBlockBytes * 2048u >> 20) << " MiB): transfer-function taps read the byte atlas (" << e.what() << ")" << std::endl;
             }
         }
         if (!transferfunc || !tf_float_atlas) { g.atlas_f32.reset(); g.atlas_f32_failed = false; }

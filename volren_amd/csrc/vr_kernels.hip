@@ -268,7 +268,7 @@ void launch_build_impmap(const float* envmap_rgba, int32_t env_w, int32_t env_h,
 // produce identical device arrays (tests compare checksums):
 //   1. encode_range_kernel : per brick, (min, max) over the brick dilated by 2 voxels, rounded outwards to fp16;
 //                            flag = the brick's voxels matter (max != min)
-//   2. encode_brick_kernel : per brick, BrickRec + 512 quantised voxels straight into its block of the brick-linear atlas
+//   2. encode_brick_kernel : per brick, BrickRec + 512 quantised voxels straight into its block of the brick-linear atlas (5 lines of range + 120 voxels: vr_scene.h)
 //   3. range_mip_kernel    : (min of mins, max of maxes) over 2x2x2 children, three levels
 __global__ void __launch_bounds__(256)
 encode_range_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int32_t nz, int32_t nbx, int32_t nby, int32_t nbz,
@@ -308,16 +308,17 @@ encode_brick_kernel(const float* __restrict__ dense, int32_t nx, int32_t ny, int
     const bool alloc = flag[brick] != 0u;                    // a brick whose range is one value keeps its zeroed block
     const size_t idx = ((size_t)bz * nby + by) * nbx + bx;            // brick-linear atlas: block index = record index = linear brick index
     if (lane == 0) { BrickRec r; r.slot = (uint32_t)idx; r.rmin = lo; r.rdiff = hi - lo; r.range = rg; recs[idx] = r; rng[2 * idx] = r.rmin; rng[2 * idx + 1] = r.rdiff; }
+    uint8_t* dst = atlas + idx * (size_t)kBrickBlockBytes;
+    if (VR_BRICK_HEADERS && lane < 5) { float* h = reinterpret_cast<float*>(dst + lane * 128); h[0] = lo; h[1] = hi - lo; }      // every line of every brick carries the range
     if (!alloc) return;
     const float inv = 255.0f / (hi - lo);
-    uint8_t* dst = atlas + idx * 512u;
     for (int32_t i = lane; i < 512; i += 64) {
         const int32_t x = bx * 8 + (i & 7), y = by * 8 + ((i >> 3) & 7), z = bz * 8 + (i >> 6);
         float v = 0.0f;
         if (x < nx && y < ny && z < nz) v = dense[((size_t)z * ny + y) * nx + x];
         float qv = floor_((v - lo) * inv + 0.5f);
         qv = qv < 0.0f ? 0.0f : (qv > 255.0f ? 255.0f : qv);
-        dst[i] = (uint8_t)qv;
+        dst[brick_voxel_byte((uint32_t)i)] = (uint8_t)qv;
     }
 }
 __global__ void __launch_bounds__(256)
@@ -357,7 +358,7 @@ decode_atlas_kernel(const float* __restrict__ rng, const uint8_t* __restrict__ a
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n_voxels) return;
     const size_t cell = i >> 9;
-    out[i] = rng[2 * cell] + unorm8(atlas[i]) * rng[2 * cell + 1];
+    out[i] = rng[2 * cell] + unorm8(atlas[cell * (size_t)kBrickBlockBytes + brick_voxel_byte((uint32_t)(i & 511u))]) * rng[2 * cell + 1];
 }
 void launch_decode_atlas(const float* rng, const uint8_t* atlas, float* out, size_t n_records, hipStream_t stream) {
     const size_t n = n_records * 512u;

@@ -47,6 +47,20 @@ VR_SCENE_HD uint32_t majorant_cell_index(uint32_t cx, uint32_t cy, uint32_t cz, 
     return (((cz << sy) + cy) << sx) + cx;
 }
 
+// Atlas block of one brick (round 4): FIVE cache lines of 128 bytes, each starting with the brick's decode range (rmin, rdiff: two floats, the
+// same in all five) followed by 120 of the brick's 512 u8 voxels in index order (x & 7) + 8 (y & 7) + 64 (z & 7); the last line holds 32.  A tap
+// reads the range and the voxel from ONE line -- until round 3 the range was a second gather, into a table of its own (8 bytes per brick, 16 MiB
+// for 1024^3 voxels: on BASELINE configs[4]'s grids a third of the kernel's misses beyond the L2; profiles/r4c_*).  Costs a quarter more atlas.
+// Build-time switch (-DVR_BRICK_HEADERS=0: 512-byte blocks and the separate table, as in round 3) for the A/B.
+#ifndef VR_BRICK_HEADERS
+#define VR_BRICK_HEADERS 1
+#endif
+constexpr uint32_t kBrickLineVoxels = VR_BRICK_HEADERS ? 120u : 128u, kBrickLineHeader = VR_BRICK_HEADERS ? 8u : 0u;
+constexpr uint32_t kBrickBlockBytes = VR_BRICK_HEADERS ? 640u : 512u;
+// line (0..4) that holds voxel `off` (0..511) of a brick, and the voxel's byte offset inside the block
+VR_SCENE_HD uint32_t brick_voxel_line(uint32_t off) { return VR_BRICK_HEADERS ? (off * 547u) >> 16 : off >> 7; }      // off / 120 for off < 512 (547 / 65536 = 1 / 119.81)
+VR_SCENE_HD uint32_t brick_voxel_byte(uint32_t off) { return off + kBrickLineHeader * (brick_voxel_line(off) + 1u); }  // = 128 line + 8 + (off - 120 line)
+
 // element index of voxel (x, y, z) in the blocked dense layout (see GridView::dense)
 VR_SCENE_HD size_t dense_blocked_index(uint32_t x, uint32_t y, uint32_t z, uint32_t blocks_x, uint32_t blocks_y) {
     return (((size_t)(z >> 2) * blocks_y + (y >> 2)) * blocks_x + (x >> 2)) * 64u + (((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u));
@@ -97,13 +111,13 @@ VR_SCENE_HD size_t env_cdf_table_floats(int32_t top) {
 
 struct GridView {
     const BrickRec* bricks;      // nb[0] * nb[1] * nb[2] records, x fastest (see above)
-    const uint8_t* atlas;        // one 512-byte block per brick record (same index), voxel (x&7) + 8*(y&7) + 64*(z&7)
+    const uint8_t* atlas;        // one kBrickBlockBytes block per brick record (same index): 5 lines of [rmin, rdiff | 120 voxels], voxel (x&7) + 8*(y&7) + 64*(z&7) (brick_voxel_byte)
     const float* majorant;       // all mips, padded (see above): "effective" majorant = density_scale * range.y, TF-remapped when a LUT is bound
     const uint16_t* majorant16;  // the same cells as raw fp16 range.y (0 outside): what the kernels WITHOUT a transfer function read --
                                  // density_scale * half2float(.) is one multiply, and the table is half as many cache lines
     const float* atlas_f32;      // optional: the atlas decoded to float (rmin + unorm8(b) * rdiff, 2 KiB per brick), built for transfer-function
                                  // renders -- their 8 corner taps then cost one 4-byte load each instead of record + byte; nullptr otherwise
-    const float* rng;            // (rmin, rdiff) per brick record, 8 bytes, same padded index as `bricks`: the part of a record a tap needs
+    const float* rng;            // (rmin, rdiff) per brick record, 8 bytes, same index as `bricks`: what decode_atlas_kernel reads (a tap reads the copy in its voxel's line)
     int32_t nb[3];               // bricks per axis (mip 0); mip m has ceil(nb / 2^m) cells per axis
     int32_t mshift[3];           // log2 of the padded level-0 majorant extent per axis (each >= 3)
     float mlim[3];               // the same extent in voxels, (float)(8 << mshift[i]): the inside test of the DDA compares against it

@@ -145,7 +145,7 @@ VR_HD void rng_skip9(uint32_t& s) {
 // Every fetch is split in three: where the voxel lives (tap_addr: arithmetic only) -> the loads (tap_load) -> the value
 // (tap_value).  The scheduler (vr_pathtrace.h) runs the first two for all lanes of a pass before anything waits, so that one
 // memory round trip serves the DDA steps and the collisions of the whole wavefront.  The brick atlas is brick-linear
-// (block of brick record i = bytes [512 i, 512 i + 512)): record and voxel are fetched together, no dependent pointer chase.
+// (block of brick record i = bytes [640 i, 640 i + 640), vr_scene.h): range and voxel come from one cache line, no dependent pointer chase.
 template <int DENSE>
 VR_HD bool grid_is_dense(const GridView& g) { return DENSE == 2 ? g.dense != nullptr : DENSE == 1; }
 struct TapAddr { uint32_t cell, off; bool in; };      // bricks: record index, byte inside the 8^3 block; dense: 4x4x4 block index, voxel inside it
@@ -180,11 +180,20 @@ VR_HD TapData tap_load(const GridView& g, TapAddr a) {
         d.rmin = 0.0f; d.rdiff = 0.0f;
         d.raw = g.dense[(size_t)a.cell * 64u + a.off];
     } else {
+#if VR_BRICK_HEADERS
+        // the voxel's line of the brick's block: [rmin, rdiff | 120 voxels] -- range and voxel come from one cache line
+        const uint32_t line = brick_voxel_line(a.off);
+        const uint8_t* ln = g.atlas + ((size_t)a.cell * kBrickBlockBytes + (size_t)(line * 128u));
+        const float* rec = reinterpret_cast<const float*>(ln);
+        d.rmin = rec[0]; d.rdiff = rec[1];
+        d.raw = ln[kBrickLineHeader + a.off - line * kBrickLineVoxels];
+#else
         const float* rec = g.rng + 2u * (size_t)a.cell;          // compact (rmin, rdiff) pairs: twice as many bricks per cache line as BrickRec
         d.rmin = rec[0]; d.rdiff = rec[1];
         d.raw = g.atlas[(size_t)a.cell * 512u + a.off];
+#endif
 #if defined(VR_DIAG_EXTRA_RNG) && defined(__HIP_DEVICE_COMPILE__)
-        {   // diagnostic (profiles/r4c_*): one more gather of the record's kind per tap, from the record of another brick -- what does such a gather cost?
+        {   // diagnostic (profiles/r4c_*): one more gather of the old range table's kind per tap, from the record of another brick -- what does such a gather cost?
             const uint32_t n_ = (uint32_t)g.nb[0] * (uint32_t)g.nb[1] * (uint32_t)g.nb[2];
             uint32_t c_ = a.cell * 2654435761u; c_ = c_ % n_;
             float x_ = g.rng[2u * (size_t)c_];
