@@ -81,9 +81,10 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
 }
 
 // Units of 8 samples x 64 pixels, except on the dense-grid kernel, whose long paths (128 bounces, every camera ray scatters) fill
-// the pools better from units of 4: c4 +1.3 %, c2 +-0, c3 -1 % (profiles/r2x_occupancy_recheck.txt)
+// the pools better from units of 4: c4 +1.3 %, c2 +-0, c3 -1 % (profiles/r2x_occupancy_recheck.txt) -- and, round 4, on the emission kernel:
+// c5cloud +1 %, c5full +0.5 % (profiles/r4d_*)
 constexpr int32_t kMaxSamplesPerUnit = 8;
-static int32_t samples_per_unit(const PathtraceTuning& T, int variant) { return T.samples_per_unit > 0 ? T.samples_per_unit : (variant == 1 ? 4 : kMaxSamplesPerUnit); }
+static int32_t samples_per_unit(const PathtraceTuning& T, int variant) { return T.samples_per_unit > 0 ? T.samples_per_unit : ((variant == 1 || variant == 2) ? 4 : kMaxSamplesPerUnit); }
 
 PathtraceTuning default_tuning() {
     static std::once_flag once;

@@ -666,7 +666,11 @@ VR_HD void hot_init(Hot& h) {
 // result of trace_path: vec4(L, clamp(n_paths, 0, 1)) -> the item's slot of the sample buffer
 VR_HD void write_sample(const WorkUnit& wu, uint32_t item, v3 L, uint32_t n_paths) {
     float* o = wu.out + 4u * (size_t)item;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(VR_SAMPLE_NT)
+    // build-time experiment (profiles/r4d_*): the sample pool is written once and read once by the accumulation pass -- non-temporal stores
+    typedef float vr_f4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(vr_f4{ L.x, L.y, L.z, n_paths > 0u ? 1.0f : 0.0f }, reinterpret_cast<vr_f4*>(o));
+#elif defined(__HIP_DEVICE_COMPILE__)
     *reinterpret_cast<float4*>(o) = make_float4(L.x, L.y, L.z, n_paths > 0u ? 1.0f : 0.0f);
 #else
     o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = n_paths > 0u ? 1.0f : 0.0f;
