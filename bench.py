@@ -225,6 +225,9 @@ class Bench:
                 r.fast_math = 1
             if pool_mb:
                 r.sample_pool_mb = int(pool_mb)
+            # a frame is split by the sample pool alone: no probe launch (the renderer's launch sizing by time, launch_target_ms, plans 2-second launches and
+            # none of these frames has a longer one), so that every launch of a kernel in the rocprofv3 statistics of this command is a whole (sub-)frame
+            r.launch_target_ms = 0
             stream = torch.cuda.Stream() if self.pipelined else torch.cuda.current_stream()
             r.set_stream(stream.cuda_stream)
             slot = dict(r=r, stream=stream)
