@@ -210,13 +210,14 @@ class Bench:
         self.shard = TileShard(w, h, world, rank)
         self.sharded = dist is not None                     # pack -> all_gather -> unpack per frame (every N > 1; N = 1 with --force-dist)
         self.staged = self.sharded and dist.get_backend() != "nccl"
-        # The fixed cost of a launch is the drain of the persistent wavefronts' path pools at its end (4-5 ms, set by the deepest
-        # paths): a few per cent of a whole frame on one GPU, 15 % of a rank's share of it on eight.  Consecutive frames are
-        # independent: two renderers on two streams let frame i+1's wavefronts move onto the CUs that frame i's draining workgroups
-        # free (profiles/r2_launch_overhead.txt).  Each has its own framebuffer, sample pool and tile buffers.  The SAME for every N
-        # (round 4: N = 1 used to run unpipelined, which made value(8) / value(1) compare two different things); the bench line
-        # also carries value_single_frame, one frame at a time, for every N.  VOLREN_PIPELINE=0 switches it off.
-        self.pipelined = (os.environ.get("VOLREN_PIPELINE", "1") != "0") if pipelined is None else bool(pipelined)
+        # `value` is K frames one after the other on ONE stream, for every N alike (round 4: rounds 2-3 pipelined the frames of N > 1 only, which made
+        # value(8) / value(1) compare two different things).  The fixed cost of a launch is the drain of the persistent wavefronts' path pools at its
+        # end (4-5 ms, set by the deepest paths): 2 % of a whole frame on one GPU, 15 % of a rank's share of it on eight.  Consecutive frames are
+        # independent, so two renderers on two streams let frame i+1's wavefronts move onto the CUs that frame i's draining workgroups free
+        # (profiles/r2_launch_overhead.txt): measured additionally as `value_pipelined` for N > 1 (VOLREN_PIPELINE=1: also for N = 1, where it is worth
+        # +0.5 % and makes the rocprofv3 durations of the overlapping kernels include their wait for the CUs; =0: never).
+        env_pipe = os.environ.get("VOLREN_PIPELINE")
+        self.pipelined = ((world > 1 and env_pipe != "0") or env_pipe == "1") if pipelined is None else bool(pipelined)
         pool_mb = os.environ.get("VOLREN_SAMPLE_POOL_MB")   # several ranks sharing one GPU (tests): a smaller radiance pool per renderer
         self.slots = []
         for k in range(2 if self.pipelined else 1):
@@ -242,9 +243,10 @@ class Bench:
             self.tiles_dev = torch.from_numpy(self.shard.pack_ids).cuda()
             self.all_tiles_dev = torch.from_numpy(self.shard.unpack_ids).cuda()
 
-    def step(self):
+    def step(self, alternate=False):
         torch = self.torch
-        slot = self.slots[self.frame % len(self.slots)]
+        slot = self.slots[self.frame % len(self.slots)] if alternate else self.slots[0]
+        self.last_slot = slot
         self.frame += 1
         r = slot["r"]
         with torch.cuda.stream(slot["stream"]):
@@ -267,7 +269,7 @@ class Bench:
         self.torch.cuda.synchronize()
 
     def last_renderer(self):
-        return self.slots[(self.frame - 1) % len(self.slots)]["r"]
+        return self.last_slot["r"]
 
     def frame_crc32(self):
         """CRC-32 of the RGBA32F frame the last step left on this rank (after the gather: the whole frame on every rank)."""
@@ -280,8 +282,11 @@ class Bench:
         torch, dist = self.torch, self.dist
         import gc
         gc.collect()                                                            # destructors of earlier renderers (16 GiB pools) run now, not inside the timed region
-        for _ in range(max(warmup, len(self.slots))):                           # every pipelined renderer has run once (pools allocated, launch rate measured)
+        for _ in range(max(warmup, 1)):
             self.step()
+        if self.pipelined:                                                      # the second renderer has run once too (its pools are allocated)
+            self.step(alternate=True)
+            self.step(alternate=True)
         self.barrier()
         for slot in self.slots:
             slot["r"].synchronize()
@@ -292,30 +297,29 @@ class Bench:
         elapsed = time.perf_counter() - t0
         for slot in self.slots:
             slot["r"].synchronize()                                             # also raises if the kernel watchdog tripped
-        # one frame at a time (what a single-frame render sees: BASELINE configs[3..4]); also gives the kernel's own duration, with
-        # nothing beside it on the GPU
-        n_single = min(steps, 2) if self.pipelined else 0
-        single = elapsed / steps
-        if n_single:
+        piped = None
+        if self.pipelined:                                                      # the same K frames alternating between the two renderers / streams
             self.barrier()
             t1 = time.perf_counter()
-            for _ in range(n_single):
-                self.step()
-                self.barrier()
-            single = (time.perf_counter() - t1) / n_single
+            for _ in range(steps):
+                self.step(alternate=True)
+            self.barrier()
+            piped = time.perf_counter() - t1
+            self.step()                                                         # the kernel's own duration: one more frame with nothing beside it
+            self.barrier()
         last_r = self.last_renderer()
         pt_ms = last_r.last_pathtrace_ms()                                      # HIP events around the path-tracing kernels alone, summed over the frame's sub-launches
         last_ms = last_r.last_kernel_ms()                                       # HIP events on the renderer's stream around the last frame's launches
         if dist is not None:
-            tmax = torch.tensor([elapsed, single], dtype=torch.float64, device="cuda" if not self.staged else "cpu")
+            tmax = torch.tensor([elapsed, piped or 0.0], dtype=torch.float64, device="cuda" if not self.staged else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed, single = float(tmax[0].item()), float(tmax[1].item())
+            elapsed, piped = float(tmax[0].item()), (float(tmax[1].item()) if piped else None)
         samples = float(self.w) * self.h * self.spp
         launches = max(1, last_r.last_launches)                                 # a frame is split so that a sub-launch fits the sample pool
         my_samples = len(self.shard.mine) * 256.0 * self.spp if self.world > 1 else samples
         # pt_ms is the sum over the frame's sub-launches (HIP events around each path-tracing kernel): kernel_ms = its AVERAGE launch duration,
         # samples_per_launch = the average samples of a launch -- what the rocprofv3 kernel statistics of the same run report
-        return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, value_single_frame=samples / single / 1e6, ms_single_frame=single * 1e3, kernel_ms=(pt_ms if pt_ms > 0 else last_ms) / launches, frame_gpu_ms=last_ms,
+        return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, value_pipelined=(samples * steps / piped / 1e6) if piped else None, kernel_ms=(pt_ms if pt_ms > 0 else last_ms) / launches, frame_gpu_ms=last_ms,
                     launches=launches, samples_per_launch=my_samples / launches)
 
     def roofline(self, m, counted):
@@ -449,14 +453,14 @@ def main():
             "metric": "Msamples/s (pixels x spp / s), volume path tracing",
             "value": m["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong",
-            # one frame at a time (barrier + device synchronisation around every frame): what a single-frame render sees; `value` overlaps the
-            # drain of frame i with the start of frame i+1 (two streams), for every N alike
-            "value_single_frame": m["value_single_frame"], "ms_single_frame": m["ms_single_frame"], "pipelined": bool(b.pipelined),
+            # `value`: K frames one after the other on one stream, for every N; value_pipelined (N > 1): the same frames alternating between two renderers
+            # on two streams, the drain of frame i overlapping the start of frame i+1
+            "value_pipelined": m["value_pipelined"], "pipelined": False,
             "frame_crc32": b.frame_crc32(),                    # of the RGBA32F frame on rank 0 after the last step: the same for every N
             "vs_baseline": None, "dtype": "f32", "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else
                                       "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
             "config": {"workload": workload_name(args.config, w, h, spp),
-                       "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, ", consecutive frames pipelined over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, %d fused launch(es)/frame (16 GiB sample pool)%s%s" % (m["launches"], ", consecutive frames pipelined over 2 streams" if b.pipelined else "", ", one-rank process group: pack_tiles -> all_gather -> unpack_tiles per frame" if dist is not None else "")},
+                       "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, "; value_pipelined: consecutive frames over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, %d fused launch(es)/frame (16 GiB sample pool)%s%s" % (m["launches"], "; value_pipelined: consecutive frames over 2 streams" if b.pipelined else "", ", one-rank process group: pack_tiles -> all_gather -> unpack_tiles per frame" if dist is not None else "")},
             "roofline": b.roofline(m, counted),
             "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
             "dist_backend": (dist.get_backend() if dist is not None else None),

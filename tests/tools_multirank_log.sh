@@ -15,8 +15,8 @@ run() {   # name, then the bench arguments
     python - "$OUT/$name.json" <<'PY'
 import json, sys
 j = json.load(open(sys.argv[1]))
-print("   n_gpus %d  rccl_ranks %d  backend %s  crc %08x  value %.1f  single-frame %.1f Msamples/s  pipelined %s" % (
-    j["n_gpus"], j["rccl_ranks"], j["dist_backend"], j["frame_crc32"], j["value"], j["value_single_frame"], j["pipelined"]))
+print("   n_gpus %d  rccl_ranks %d  backend %s  crc %08x  value %.1f  pipelined %s Msamples/s" % (
+    j["n_gpus"], j["rccl_ranks"], j["dist_backend"], j["frame_crc32"], j["value"], ("%.1f" % j["value_pipelined"]) if j["value_pipelined"] else "-"))
 PY
 }
 # small frame: N = 1, 2, 4 (what tests/test_gpu_multirank.py asserts)
