@@ -157,6 +157,9 @@ const char* vr_sharded_transport(vr_sharded* s);
 int vr_sharded_reset(vr_sharded* s);                      /* vr_reset on every part */
 int vr_sharded_render(vr_sharded* s, int spp);
 int vr_sharded_synchronize(vr_sharded* s);
+/* the tile deal itself (host only, needs no device): owner_out[t] = the part (0 .. n_parts-1) that renders raster tile t of a width x height frame,
+ * t = ty * ceil(width / 16) + tx, row 0 = bottom; n_tiles must be ceil(width / 16) * ceil(height / 16) */
+int vr_tile_owners(int width, int height, int n_parts, int32_t* owner_out, int n_tiles);
 /* the uniform block the next launch would use (struct vr::Uniforms of volren_amd/csrc/vr_scene.h, `bytes` must match) */
 int vr_get_uniforms(vr_renderer* r, void* out, int bytes);
 int vr_uniforms_size(void);

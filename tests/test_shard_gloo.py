@@ -29,6 +29,23 @@ def test_tile_ownership_is_a_partition():
             assert sorted(t for t in s.unpack_ids if t >= 0) == flat
 
 
+def test_product_tile_deal_equals_the_python_deal():
+    """The sharded renderer inside the library (volren_amd/csrc/sharded.cpp) and the torch.distributed path (volren_amd/shard.py) deal the tiles
+    identically: vr_tile_owners (host only) against tile_owner_lists, ragged frames and part counts up to 8 and beyond."""
+    import volren_amd
+    lib = volren_amd.load()
+    for w, h in ((1024, 1024), (1920, 1080), (2048, 2048), (70, 52), (16, 16), (17, 1)):
+        n_tiles = ((w + 15) // 16) * ((h + 15) // 16)
+        for n in (1, 2, 3, 5, 8, 13):
+            owner = np.full(n_tiles, -1, np.int32)
+            assert lib.vr_tile_owners(w, h, n, owner.ctypes.data, n_tiles) == 0
+            want = np.full(n_tiles, -1, np.int32)
+            for p, tiles in enumerate(tile_owner_lists(w, h, n)):
+                want[tiles] = p
+            assert np.array_equal(owner, want), (w, h, n)
+    assert lib.vr_tile_owners(64, 64, 2, None, 16) == 3 and lib.vr_tile_owners(64, 64, 2, np.zeros(15, np.int32).ctypes.data, 15) == 3      # VR_ERR_ARG
+
+
 def test_hashed_deal_is_a_balanced_partition():
     """The alternative tile deal (tiles in the order of a hash of their id, dealt round robin): a partition with counts within one.
     Measured load balance (profiles/r3_rank_balance.txt): diagonal max/mean <= 1.021, hashed 1.05-1.06 -- the diagonal deal is the default."""

@@ -523,6 +523,16 @@ int vr_sharded_synchronize(vr_sharded* s) {
     return guard([&] { s->impl->synchronize(); });
 }
 
+int vr_tile_owners(int width, int height, int n_parts, int32_t* owner_out, int n_tiles) {
+    if (!owner_out || width <= 0 || height <= 0 || n_parts <= 0) return fail(VR_ERR_ARG, "vr_tile_owners: bad arguments");
+    if (n_tiles != ((width + 15) / 16) * ((height + 15) / 16)) return fail(VR_ERR_ARG, "vr_tile_owners: n_tiles must be ceil(width / 16) * ceil(height / 16)");
+    return guard([&] {
+        const auto lists = vr::tile_owner_lists(width, height, n_parts);
+        for (size_t p = 0; p < lists.size(); ++p)
+            for (int32_t t : lists[p]) owner_out[t] = (int32_t)p;
+    });
+}
+
 int vr_uniforms_size(void) { return (int)sizeof(vr::Uniforms); }
 int vr_get_uniforms(vr_renderer* r, void* out, int bytes) {
     NEED(r);
