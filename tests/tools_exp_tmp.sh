@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/ -q -m gpu > gpurun_out/t_gpu_all.log 2>&1; echo "gpu tests rc $?"; tail -8 gpurun_out/t_gpu_all.log
-python tests/tools_variant_throughput.py 2>&1 | grep -v "^load\|Preparing\|Loading\|amdgpu.ids" > gpurun_out/r4_variant_throughput.txt; cat gpurun_out/r4_variant_throughput.txt
+export AB_CASES="c2:1024:256 c4:512:1024:64 c5full:2048:64 c5cloud:2048:64"
+bash tests/tools_ab.sh default w5 2>&1 | grep -v "^load\|Preparing\|Loading" > gpurun_out/r4e_five_waves.log
+cat gpurun_out/r4e_five_waves.log
