@@ -27,7 +27,7 @@ def _sharded(name, w, h, devices):
     return s
 
 
-@pytest.mark.parametrize("name,w,h,spp,parts", [("c1", 150, 90, 3, 3), ("c3", 96, 64, 4, 2), ("c2", 70, 52, 5, 5)])
+@pytest.mark.parametrize("name,w,h,spp,parts", [("c1", 150, 90, 3, 3), ("c3", 96, 64, 4, 2), ("c2", 70, 52, 5, 5), ("c5:32", 80, 48, 3, 4), ("c4:64", 64, 64, 3, 8)])
 def test_logical_shards_of_one_device_equal_the_unsharded_frame(name, w, h, spp, parts):
     ref = scenes.oracle_scene(name, w, h).render(spp)
     s = _sharded(name, w, h, [0] * parts)
