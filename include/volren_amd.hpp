@@ -5,7 +5,7 @@
 // library it includes <volren_amd.hpp> and the same code compiles: same class names, same public fields, same call protocol
 // (mutate fields -> commit() after changing the volume -> reset() -> trace() once per sample; result = running mean in
 // `color`, RGBA32F, row 0 at the bottom).  Additions only: render(n) (all samples in one fused launch), an explicit camera
-// and resolution (the reference reads cppgl globals), set_tiles() for multi-GPU sharding, fast_math, integrator.
+// and resolution (the reference reads cppgl globals), set_tiles() / ShardedRenderer for multi-GPU sharding, fast_math, integrator.
 // Build: hipcc (the headers include <hip/hip_runtime.h> for the device-buffer handles); link libvolren_amd.so.
 // FFI users bind the C ABI in volren_amd.h instead; INTEGRATION.md shows both.
 #pragma once
@@ -14,11 +14,13 @@
 #include "../volren_amd/csrc/environment.h"     // Environment
 #include "../volren_amd/csrc/transferfunc.h"    // TransferFunction
 #include "../volren_amd/csrc/grids.h"           // Volume, Grid, DenseGrid, DenseGridF16, BrickGrid, Buf3D
+#include "../volren_amd/csrc/sharded.h"         // ShardedRenderer: one frame on several devices (no reference counterpart)
 
 // the reference's names
 using RendererOpenGL = vr::RendererHIP;         // src/renderer.h:16
 using Environment = vr::Environment;            // src/environment.h:7
 using TransferFunction = vr::TransferFunction;  // src/transferfunc.h:9
+using ShardedRenderer = vr::ShardedRenderer;    // addition: N RendererOpenGL parts on N devices, one gather per frame
 namespace voldata {
 using Volume = vr::Volume;
 using Grid = vr::Grid;

@@ -151,6 +151,29 @@ int drive(const char* vol, const char* env, const char* lut) {
     renderer->draw();
     return renderer->sample;
 }
+// the offline loop of src/main.cpp:524-557 on several devices (ShardedRenderer: the scene calls replicated per part)
+int drive_sharded(const char* vol, const char* env, int n_devices) {
+    std::vector<std::shared_ptr<RendererOpenGL>> parts;
+    std::vector<RendererOpenGL*> raw;
+    std::vector<int> devices;
+    for (int d = 0; d < n_devices; ++d) {
+        VR_HIP(hipSetDevice(d));
+        auto r = std::make_shared<RendererOpenGL>();
+        r->resolution = { 64, 48 };
+        r->init();
+        r->volume = std::make_shared<voldata::Volume>(std::string(vol));
+        r->scale_and_move_to_unit_cube();
+        r->commit();
+        r->environment = std::make_shared<Environment>(std::string(env));
+        parts.push_back(r); raw.push_back(r.get()); devices.push_back(d);
+    }
+    ShardedRenderer shards(raw, devices);
+    shards.for_each([](RendererOpenGL& r, size_t) { r.bounces = 16; r.sppx = 8; });
+    shards.reset();
+    shards.render(parts[0]->sppx);
+    shards.synchronize();
+    return parts[0]->sample + (shards.transport() == "rccl" ? 0 : 1);      // the whole frame is in parts[0]->color
+}
 ''')
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-x", "hip", "-I", os.path.join(root, "include"), str(src)])
 
