@@ -94,7 +94,9 @@ int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
  *     "sample_pool_mb" (HBM budget of the per-sample radiance pool, default 16384)
  *     "launch_target_ms" (default 2000: a vr_render is split into sub-launches planned to take at most this long each, from the rate this
  *     renderer measured last -- a short probe launch, one synchronisation, when it has none for the current settings and the request is
- *     large; 0 = split by the sample pool alone.  Results never depend on the split) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
+ *     large; 0 = split by the sample pool alone.  Results never depend on the split)
+ *     "order_tiles" (default 1: a launch works through its tiles costliest first -- longest chord of the pixel rays through the volume's box --
+ *     so that short paths are what is left when its work queue runs empty; 0 = raster order.  Results never depend on the order) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
  *     "emission_scale" "vol_clip_min"(3) "vol_clip_max"(3) "env_strength" "env_transform"(9) "env_rot"(1, degrees about +y,
  *     main.cpp:382) "tf_window_left" "tf_window_width" "cam_pos"(3) "cam_dir"(3) "cam_up"(3) "cam_fov" "volume_transform"(16) (float) */
 int vr_set_int(vr_renderer* r, const char* name, int value);
@@ -176,6 +178,9 @@ int vr_grid_checksums(vr_renderer* r, uint64_t out[3]);
  * may be NULL) receives, per state, [block executions, active lanes], then [16] wave iterations, [17] waves, [18..24] cycles per
  * state, [25] summed wave lifetime, [26..31] summed pool occupancy */
 int vr_sched_stats(vr_renderer* r, int enable, unsigned long long* out);
+/* diagnostics: after an instrumented launch (vr_sched_stats enable), out[3 i .. 3 i + 2] = when wavefront i started, found the work queue empty and ended
+ * (ticks of the device's constant 100 MHz clock; 0 = no such wavefront); n_words <= 3 * 8192 */
+int vr_wave_timeline(vr_renderer* r, unsigned long long* out, int n_words);
 /* test hook: device allocations above `mb` MiB fail as if the device were out of memory (the fall-back paths can then be exercised on a
  * shared GPU); mb < 0 removes the cap.  Initial value: environment variable VR_TEST_MAX_ALLOC_MB, read once per process. */
 int vr_test_alloc_cap_mb(long long mb);

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export AB_CASES="c2:1024:256 c4:512:1024:64 c5full:2048:64 c5cloud:2048:64"
-bash tests/tools_ab.sh default w5 2>&1 | grep -v "^load\|Preparing\|Loading" > gpurun_out/r4e_five_waves.log
-cat gpurun_out/r4e_five_waves.log
+( python tests/tools_wave_timeline.py c2 1024 128 1; python tests/tools_wave_timeline.py c2 1024 1024 8; python tests/tools_wave_timeline.py c4:512 1024 64 1 ) 2>&1 | grep -v "^load\|Preparing\|Loading\|amdgpu" > gpurun_out/r4f_wave_timeline.log
+cat gpurun_out/r4f_wave_timeline.log

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -397,6 +398,56 @@ void RendererHIP::set_tiles(const std::vector<int32_t>& tile_ids) {
     tiles_dev_->upload(tile_ids.data(), tile_ids.size() * sizeof(int32_t));
 }
 
+// The order in which a launch works through its tiles.  The persistent wavefronts pull work units from a queue (vr_pathtrace.h) whose positions enumerate the
+// tile list front to back in 8 contiguous segments, one per XCD; when the queue runs empty every wavefront still has to finish the paths in its pool, and
+// the launch ends with its deepest path (4-5 ms on the bench scene: 2 % of a frame on one GPU, 15 % of a rank's share on eight).  With the costly tiles --
+// long chords through the volume's box -- at the FRONT of every segment and the tiles whose rays miss the box at its end, what is left at that point are
+// camera rays that escape at once.  Cost estimate: the longest chord of five rays of the tile (corners and centre, no jitter) through the clipped box.
+// Sorted (stably) inside each eighth of the list, so that an XCD keeps its band of tile rows.  Cached per (camera, box, frame size, tile set).
+const int32_t* RendererHIP::tile_order(const SceneParams& P, int n_tiles) {
+    const Uniforms& u = P.u;
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&key](const void* p, size_t nbytes) { const uint8_t* b = static_cast<const uint8_t*>(p); for (size_t i = 0; i < nbytes; ++i) { key ^= b[i]; key *= 1099511628211ull; } };
+    mix(u.cam_pos, sizeof u.cam_pos); mix(u.cam_transform, sizeof u.cam_transform); mix(&P.cam_z, sizeof P.cam_z);
+    mix(u.vol_bb_min, sizeof u.vol_bb_min); mix(u.vol_bb_max, sizeof u.vol_bb_max); mix(u.resolution, sizeof u.resolution); mix(&n_tiles, sizeof n_tiles);
+    if (!tiles_host_.empty()) mix(tiles_host_.data(), tiles_host_.size() * sizeof(int32_t));
+    key = key ? key : 1;
+    if (order_dev_ && order_key_ == key && order_dev_->size_bytes() == (size_t)n_tiles * sizeof(int32_t)) return order_dev_->as<int32_t>();
+    const int W = u.resolution[0], H = u.resolution[1], tiles_x = (W + 15) / 16;
+    std::vector<int32_t> ids(tiles_host_);
+    if (ids.empty()) { ids.resize((size_t)n_tiles); for (int i = 0; i < n_tiles; ++i) ids[(size_t)i] = i; }
+    auto chord = [&](float px, float py) {
+        float d[3] = { (px - 0.5f * (float)W) / (float)H, (py - 0.5f * (float)H) / (float)H, P.cam_z };
+        float w[3];
+        for (int i = 0; i < 3; ++i) w[i] = u.cam_transform[i] * d[0] + u.cam_transform[3 + i] * d[1] + u.cam_transform[6 + i] * d[2];      // direction up to its length: only t-ratios matter
+        const float len = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        float t0 = 0.f, t1 = FLT_MAX;
+        for (int i = 0; i < 3; ++i) {
+            const float inv = 1.f / (w[i] / len);
+            const float a = (u.vol_bb_min[i] - u.cam_pos[i]) * inv, b = (u.vol_bb_max[i] - u.cam_pos[i]) * inv;
+            t0 = std::fmax(t0, std::fmin(a, b)); t1 = std::fmin(t1, std::fmax(a, b));
+        }
+        return t1 > t0 ? t1 - t0 : 0.f;
+    };
+    std::vector<float> cost(ids.size());
+    for (size_t k = 0; k < ids.size(); ++k) {
+        const float x0 = (float)((ids[k] % tiles_x) * 16), y0 = (float)((ids[k] / tiles_x) * 16);
+        const float x1 = std::fmin(x0 + 16.f, (float)W), y1 = std::fmin(y0 + 16.f, (float)H);
+        cost[k] = std::fmax(std::fmax(std::fmax(chord(x0, y0), chord(x1, y0)), std::fmax(chord(x0, y1), chord(x1, y1))), chord(0.5f * (x0 + x1), 0.5f * (y0 + y1)));
+    }
+    std::vector<int32_t> perm(ids.size());
+    for (size_t k = 0; k < perm.size(); ++k) perm[k] = (int32_t)k;
+    const size_t seg = (ids.size() + 7) / 8;                                  // the queue's segments are eighths of the unit list = of the tile list
+    for (size_t b = 0; b < ids.size(); b += seg)
+        std::stable_sort(perm.begin() + (ptrdiff_t)b, perm.begin() + (ptrdiff_t)std::min(ids.size(), b + seg), [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
+    std::vector<int32_t> ordered(ids.size());
+    for (size_t k = 0; k < ids.size(); ++k) ordered[k] = ids[(size_t)perm[k]];
+    if (!order_dev_ || order_dev_->size_bytes() != ordered.size() * sizeof(int32_t)) order_dev_ = make_device_buffer(ordered.size() * sizeof(int32_t));
+    order_dev_->upload(ordered.data(), ordered.size() * sizeof(int32_t), stream);
+    order_key_ = key;
+    return order_dev_->as<int32_t>();
+}
+
 void RendererHIP::launch(int n) {
     if (n <= 0) return;
     if (!color) throw std::runtime_error("RendererHIP::trace: no framebuffer (call resize first)");
@@ -435,8 +486,8 @@ void RendererHIP::launch(int n) {
     fill_params(P);
     update_majorants(P, density_grids[volume->grid_frame_counter]);
     const int tiles_x = (resolution.x + 15) / 16, tiles_y = (resolution.y + 15) / 16;
-    const int32_t* tiles = tiles_dev_ ? tiles_dev_->as<int32_t>() : nullptr;
     const int n_tiles = tiles_dev_ ? (int)tiles_host_.size() : tiles_x * tiles_y;
+    const int32_t* tiles = order_tiles ? tile_order(P, n_tiles) : (tiles_dev_ ? tiles_dev_->as<int32_t>() : nullptr);
     // per-sample radiances live in a device pool; split the request so that one sub-launch fits the pool
     const size_t per_sample = pathtrace_pool_floats(tuning, n_tiles, 1) * sizeof(float);
     int per_launch = (int)std::max<size_t>(1, sample_pool_bytes / per_sample);
@@ -575,12 +626,21 @@ void RendererHIP::sched_stats(bool enable, unsigned long long out[32]) {
         if (stats_) { VR_HIP(hipStreamSynchronize(stream)); stats_->download(out, 32 * sizeof(unsigned long long), stream); }
     }
     if (enable) {
-        if (!stats_) stats_ = make_device_buffer(32 * sizeof(unsigned long long));
+        if (!stats_) stats_ = make_device_buffer((32 + 3 * 8192) * sizeof(unsigned long long));      // 32 counters + (begin, queue empty, end) per wavefront (vr_pathtrace.h kStatsWaveBase)
         VR_HIP(hipMemsetAsync(stats_->get(), 0, stats_->size_bytes(), stream));
         tuning.stats = stats_->as<unsigned long long>();
     } else {
         tuning.stats = nullptr;
     }
+}
+
+void RendererHIP::wave_timeline(unsigned long long* out, size_t n_words) {
+    if (!stats_) throw std::runtime_error("wave_timeline: statistics are not enabled");
+    VR_HIP(hipStreamSynchronize(stream));
+    const size_t have = stats_->size_bytes() / sizeof(unsigned long long) - 32;
+    std::vector<unsigned long long> all(32 + have);
+    stats_->download(all.data(), all.size() * sizeof(unsigned long long), stream);
+    for (size_t i = 0; i < n_words; ++i) out[i] = i < have ? all[32 + i] : 0ull;
 }
 
 void RendererHIP::synchronize() const { VR_HIP(hipStreamSynchronize(stream)); }

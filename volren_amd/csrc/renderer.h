@@ -114,6 +114,9 @@ struct RendererHIP {
     int integrator = 0;                               // 0: DDA tracking (both reference kernels), 1: global-majorant tracking (common.glsl:333-394),
                                                       // 2: direct volume rendering (:571-591, needs a LUT), 3: 64-step ray-marching trackers (:506-566)
     bool tf_float_atlas = true;                       // transfer-function renders decode the brick atlas to floats once (4x its size): one load per corner tap
+    bool order_tiles = true;                          // a launch works through its tiles costliest first (chord of the pixel rays through the volume's box), so that what
+                                                      // is left when the work queue runs empty are short paths: the drain of the persistent wavefronts' pools shrinks
+                                                      // (profiles/r4f_*).  Which tile runs when never changes a result
     bool fast_math = false;                           // opt-in tolerance mode: hardware log/sin/cos/rcp instead of the specified arithmetic
                                                       // (not bit-reproducible; without a transfer function within 1e-3 relative L2 of the default --
                                                       // with one bound the renderer refuses it: DESIGN.md 3)
@@ -132,7 +135,8 @@ struct RendererHIP {
     double last_kernel_ms();                                    // HIP-event time of the last trace()/render(): all sub-launches, path tracing + accumulation (waits for it)
     double last_pathtrace_ms();                                 // HIP-event time of the path-tracing kernel alone, summed over the sub-launches of the last trace()/render()
                                                                 // (0 when that call launched none: integrators 2 / 3)
-    void sched_stats(bool enable, unsigned long long out[32]);  // diagnostics: out (may be null) receives the counters gathered so far; enable starts (zeroed) or stops counting
+    void sched_stats(bool enable, unsigned long long out[32]);
+    void wave_timeline(unsigned long long* out, size_t n_words);  // diagnostics: the per-wavefront (begin, queue empty, end) triples of the last instrumented launch  // diagnostics: out (may be null) receives the counters gathered so far; enable starts (zeroed) or stops counting
     uint32_t watchdog_status();
     ~RendererHIP();
 
@@ -141,6 +145,10 @@ private:
     void launch(int n);
     std::vector<int32_t> tiles_host_;
     DeviceBufferPtr tiles_dev_;
+    // the launch's own order of those tiles: the costliest first (launch(): tile_order)
+    DeviceBufferPtr order_dev_;
+    uint64_t order_key_ = 0;
+    const int32_t* tile_order(const SceneParams& P, int n_tiles);
     DeviceBufferPtr status_;
     DeviceBufferPtr pool_;
     DeviceBufferPtr workspace_;

@@ -235,6 +235,7 @@ struct HotStoreT {                     // [slot][field]: a path's parked dwords 
 // path with everything in it: c4 +3.3 %, c2 +1.1 %, same bytes moved (profiles/r2y_ab_cold_64_byte_slots.txt).  Earlier experiments:
 // group-major [group][slot][4] (same speed, more traffic), non-temporal accesses (-21 %), everything in LDS (-28 ... -42 %: the
 // pool slots it costs), profiles/r2j_layout_experiments.txt, r2m_cold_state_in_lds_experiments.txt.
+constexpr uint32_t kStatsWaveBase = 32u;                 // statistics buffer: 32 counters, then (begin, queue empty, end) per wavefront of the launch
 constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state workspace is sized for this many resident 4-wavefront units = 8192 wavefronts (launch_pathtrace clamps the grid to it)
 struct ColdGlobal {
     float* base;                       // this slot's 16 floats in the wavefront's slice of the main array
@@ -486,6 +487,7 @@ pathtrace_kernel(const KernelArgs A) {
 #define VR_POOL ((int32_t)((thr_b >> 8) & 255u))
 #define VR_THR_COLLIDE ((int32_t)(thr_b >> 16))
     int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = pool;     // stack heights (wave-uniform)
+    int32_t rdy_head = 0;                                                               // READY ring: position of its oldest entry (wave-uniform)
     for (int32_t i = lane; i < pool; i += 64) q[Q_FREE * NS + i] = (uint8_t)i;
     __builtin_amdgcn_wave_barrier();
 
@@ -499,6 +501,7 @@ pathtrace_kernel(const KernelArgs A) {
     hot_init(l);
     int32_t slot = -1;                // path held in this lane's registers (-1: none)
 
+    const unsigned long long t_begin_rt = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t iters = 0u, idle_iters = 0u;     // scheduler iterations: in all (statistics), since the last finished path or pulled unit (watchdog)
     uint32_t t_last = (uint32_t)__builtin_readcyclecounter(), t_elapsed = 0u;
     uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
@@ -510,6 +513,7 @@ pathtrace_kernel(const KernelArgs A) {
     unsigned long long t_tail = 0ull;
 #endif
     unsigned long long occ[6] = { 0, 0, 0, 0, 0, 0 };      // summed per iteration: marching lanes, READY, NEE, POSTNEE, ESCAPE, FREE
+    unsigned long long t_exhausted = 0ull;                 // STATS: constant-rate clock (100 MHz) when this wavefront found the work queue empty
 #define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
 #define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
 // push the slots of all lanes where COND holds onto stack QI (wave-synchronous)
@@ -518,11 +522,26 @@ pathtrace_kernel(const KernelArgs A) {
         if (m_) { if (COND) q[(QI) * NS + (CNT) + (int32_t)lane_rank(m_)] = (uint8_t)(SLOTV); (CNT) += popc(m_); } \
     } while (0)
 
+// READY as a queue instead of a stack (build-time experiment, round 4, -DVR_READY_FIFO=1): a ring of NS bytes, oldest entry at rdy_head.  The hypothesis was
+// that paths parked early starve at the bottom of the stack until the end of the launch and ARE its 4-5 ms fixed cost.  They are not: the per-wavefront
+// timeline (tests/tools_wave_timeline.py, profiles/r4f_*) shows EVERY wavefront taking ~1.6 ms (c2) to finish its pool once the work queue is empty -- the
+// latency of the deepest of its 175 paths, ~40 bounces x ~12 scheduler passes x ~3 us, stack or queue -- and the queue measures -0.5 % on full frames.
+#ifndef VR_READY_FIFO
+#define VR_READY_FIFO 0
+#endif
+#if VR_READY_FIFO
+#define VR_PUSH_READY(COND, SLOTV) do { \
+        const uint64_t m_ = wave_ballot(COND); \
+        if (m_) { if (COND) { int32_t p_ = rdy_head + cnt_ready + (int32_t)lane_rank(m_); p_ = p_ >= NS ? p_ - NS : p_; q[Q_READY * NS + p_] = (uint8_t)(SLOTV); } cnt_ready += popc(m_); } \
+    } while (0)
+#else
+#define VR_PUSH_READY(COND, SLOTV) VR_PUSH(Q_READY, cnt_ready, COND, SLOTV)
+#endif
 // route the batch paths to the stack of their new state; an impossible state is reported and the slot recycled
 #define VR_ROUTE_ST(BS, STV) do { \
         /* one integer per lane (its new state, or -1 without a batch path): every ballot below is then a single v_cmp */ \
         const int32_t s_ = (BS) >= 0 ? (STV) : -1; \
-        VR_PUSH(Q_READY, cnt_ready, (uint32_t)(s_ - ST_MARCH) < 2u, BS);          /* ST_MARCH, ST_COLLIDE */ \
+        VR_PUSH_READY((uint32_t)(s_ - ST_MARCH) < 2u, BS);                        /* ST_MARCH, ST_COLLIDE */ \
         VR_PUSH(Q_NEE, cnt_nee, s_ == ST_NEE, BS); \
         VR_PUSH(Q_POST, cnt_post, s_ == ST_POSTNEE, BS); \
         VR_PUSH(Q_ESC, cnt_esc, s_ == ST_ESCAPE, BS); \
@@ -569,7 +588,12 @@ pathtrace_kernel(const KernelArgs A) {
                 if (slot < 0) {
                     const int32_t r = (int32_t)lane_rank(idle);
                     if (r < take) {
+#if VR_READY_FIFO
+                        int32_t p_ = rdy_head + r; p_ = p_ >= NS ? p_ - NS : p_;
+                        slot = q[Q_READY * NS + p_]; hs.load_resume(l, slot);
+#else
                         slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load_resume(l, slot);
+#endif
                         if (emission_on && !l.shadow) {              // EmissionCache (vr_trace.h Hot): the collisions of this segment add to L
                             if (kLazyEm && l.first) { l.ethr = v3{ 1.0f, 1.0f, 1.0f }; l.eL = hs.load_first_radiance(slot); }      // no cold line yet
                             else { const ColdT c = VR_COLD(slot); l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L); }
@@ -577,6 +601,9 @@ pathtrace_kernel(const KernelArgs A) {
                     }
                 }
                 cnt_ready -= take;
+#if VR_READY_FIFO
+                rdy_head += take; rdy_head = rdy_head >= NS ? rdy_head - NS : rdy_head;
+#endif
             }
         }
         VR_SECTION(0);                                                   // resume
@@ -763,7 +790,7 @@ pathtrace_kernel(const KernelArgs A) {
                         if (lo < hi && v < hi - lo) { j = lo + v; break; }
                         ++seg_tries;                                        // this segment is used up for good
                     }
-                    if (j == 0xFFFFFFFFu) exhausted = true;
+                    if (j == 0xFFFFFFFFu) { exhausted = true; if (STATS) t_exhausted = __builtin_amdgcn_s_memrealtime(); }
                     else { wu = make_unit(E.D, E.P.u.resolution[0], j, nullptr); cursor = 0u; idle_iters = 0u; t_elapsed = 0u; }
                 }
                 n = min(min(64, cnt_free), (int32_t)((uint32_t)wu.n_items - cursor));
@@ -839,6 +866,10 @@ pathtrace_kernel(const KernelArgs A) {
         atomicAdd(&stats[25], __builtin_readcyclecounter() - t_start);
 #pragma unroll
         for (int k = 0; k < 6; ++k) atomicAdd(&stats[26 + k], occ[k]);
+        // per wavefront (diagnostic, tests/tools_wave_timeline.py): when it started, found the queue empty and ended, on the GPU's constant 100 MHz clock
+        stats[kStatsWaveBase + 3u * wave_index] = t_begin_rt;
+        stats[kStatsWaveBase + 3u * wave_index + 1u] = t_exhausted;
+        stats[kStatsWaveBase + 3u * wave_index + 2u] = __builtin_amdgcn_s_memrealtime();
     }
 #undef VR_STAT
 #undef VR_COLD
@@ -852,6 +883,7 @@ pathtrace_kernel(const KernelArgs A) {
 #undef VR_STAT_END
 #undef VR_SECTION
 #undef VR_PUSH
+#undef VR_PUSH_READY
 #undef VR_ROUTE
 #undef VR_ROUTE_B
 #undef VR_ROUTE_ST

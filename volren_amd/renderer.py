@@ -7,7 +7,7 @@ import numpy as np
 from . import _lib
 
 _INT_FIELDS = ("sample", "sppx", "seed", "bounces", "show_environment", "tonemapping", "integrator", "grid_frame_counter",
-               "sample_pool_mb", "gpu_encoder", "fast_math", "tf_float_atlas", "launch_target_ms")
+               "sample_pool_mb", "gpu_encoder", "fast_math", "tf_float_atlas", "launch_target_ms", "order_tiles")
 _FLOAT_FIELDS = {"tonemap_exposure": 1, "tonemap_gamma": 1, "albedo": 3, "phase": 1, "density_scale": 1,
                  "emission_scale": 1, "vol_clip_min": 3, "vol_clip_max": 3, "env_strength": 1, "env_transform": 9,
                  "tf_window_left": 1, "tf_window_width": 1, "cam_pos": 3, "cam_dir": 3, "cam_up": 3, "cam_fov": 1,
@@ -267,6 +267,16 @@ class Renderer:
         d["wave_cycles"] = int(out[25])                                            # summed lifetime of all wavefronts
         d["occupancy"] = {n: int(out[26 + i]) / max(1, int(out[16])) for i, n in enumerate(("marching", "ready", "nee", "postnee", "escape", "free"))}
         return d
+
+    def wave_timeline(self, n_waves=8192):
+        """(begin, queue empty, end) per wavefront of the last instrumented launch, in seconds relative to the earliest begin; rows of wavefronts that did not run are dropped."""
+        out = np.zeros(3 * n_waves, np.uint64)
+        _lib.check(self._L.vr_wave_timeline(self._h, out.ctypes.data, out.size))
+        t = out.reshape(-1, 3)
+        t = t[t[:, 2] > 0].astype(np.float64)
+        t0 = t[:, 0].min() if len(t) else 0.0
+        t[:, 1] = np.where(t[:, 1] > 0, t[:, 1], t[:, 2])
+        return (t - t0) / 1e8
 
     def grid_checksums(self):
         out = (C.c_uint64 * 3)()
