@@ -487,7 +487,9 @@ pathtrace_kernel(const KernelArgs A) {
 #define VR_POOL ((int32_t)((thr_b >> 8) & 255u))
 #define VR_THR_COLLIDE ((int32_t)(thr_b >> 16))
     int32_t cnt_ready = 0, cnt_nee = 0, cnt_post = 0, cnt_esc = 0, cnt_free = pool;     // stack heights (wave-uniform)
+#if VR_READY_FIFO
     int32_t rdy_head = 0;                                                               // READY ring: position of its oldest entry (wave-uniform)
+#endif
     for (int32_t i = lane; i < pool; i += 64) q[Q_FREE * NS + i] = (uint8_t)i;
     __builtin_amdgcn_wave_barrier();
 
