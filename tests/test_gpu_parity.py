@@ -1344,6 +1344,43 @@ def test_results_do_not_depend_on_the_scheduler(config):
         assert np.array_equal(_bits(got), _bits(want)), ("scheduler setting", s)
 
 
+def test_tile_order_inside_a_launch_never_changes_the_image():
+    """order_tiles (default on): a launch works through its tiles costliest first -- by the chord of the pixel rays through the volume's box -- instead of in
+    raster order; with a tile subset (a rank's share) the subset is reordered.  Same image bit for bit; and the per-wavefront timeline of an instrumented
+    launch is sane (every wavefront starts, finds the queue empty, ends -- in that order)."""
+    from volren_amd.shard import TileShard
+    w, h, spp = 200, 136, 6
+    for config in ("c2", "c5:32"):
+        r = scenes.hip_scene(config, w, h)
+        assert r.order_tiles == 1
+        r.render(spp)
+        want = r.framebuffer().copy()
+        r.order_tiles = 0
+        r.reset(); r.render(spp)
+        assert np.array_equal(_bits(r.framebuffer()), _bits(want)), config
+        r.cam_pos = (0.1, 0.05, 0.12)                  # inside the box: every chord is positive; a new order is computed for the new camera
+        r.cam_dir = (-0.5, -0.3, -0.8)
+        r.reset(); r.render(spp)
+        inside = r.framebuffer().copy()
+        r.order_tiles = 1
+        r.reset(); r.render(spp)
+        assert np.array_equal(_bits(r.framebuffer()), _bits(inside)), config
+        sh = TileShard(w, h, 4, 1)
+        r.set_tiles(sh.mine)
+        r.reset(); r.render(spp)
+        part = r.framebuffer()
+        tx = (w + 15) // 16
+        for t in sh.mine:
+            y0, x0 = (t // tx) * 16, (t % tx) * 16
+            assert np.array_equal(_bits(part[y0:y0 + 16, x0:x0 + 16]), _bits(inside[y0:y0 + 16, x0:x0 + 16])), (config, t)
+    r = scenes.hip_scene("c2", 256, 256)
+    r.sched_stats(True)
+    r.render(16)
+    t = r.wave_timeline()
+    r.sched_stats(False)
+    assert len(t) > 0 and (t[:, 0] >= 0).all() and (t[:, 1] >= t[:, 0]).all() and (t[:, 2] >= t[:, 1]).all() and t[:, 2].max() < 1.0
+
+
 def test_tuning_state_is_per_renderer():
     """Scheduler thresholds and the statistics switch belong to ONE renderer (vr_set_sched / vr_sched_stats take it): a second renderer
     in the same process keeps the defaults and counts nothing while the first one runs instrumented with a 66-slot pool."""
