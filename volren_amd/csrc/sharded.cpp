@@ -6,6 +6,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
 #include <mutex>
 #include <set>
 
@@ -83,11 +84,19 @@ ShardedRenderer::ShardedRenderer(const std::vector<RendererHIP*>& parts, const s
         parts_[i]->stream = buf_[i].stream;
     }
     if (transport_ == "rccl") {
-        Rccl& R = rccl();
-        if (!R.error.empty()) throw std::runtime_error("ShardedRenderer: " + R.error + " (VR_SHARDED_TRANSPORT=copy uses peer copies instead)");
-        std::vector<ncclComm_t> comms(parts_.size());
-        rccl_check(R.CommInitAll(comms.data(), (int)parts_.size(), devices_.data()), "ncclCommInitAll");
-        for (ncclComm_t c : comms) comms_.push_back((void*)c);
+        // RCCL that cannot be opened or initialised is not fatal unless it was asked for by name: peer copies move the same buffers
+        try {
+            Rccl& R = rccl();
+            if (!R.error.empty()) throw std::runtime_error(R.error);
+            std::vector<ncclComm_t> comms(parts_.size());
+            rccl_check(R.CommInitAll(comms.data(), (int)parts_.size(), devices_.data()), "ncclCommInitAll");
+            for (ncclComm_t c : comms) comms_.push_back((void*)c);
+        } catch (const std::exception& e) {
+            if (forced == "rccl") throw std::runtime_error(std::string("ShardedRenderer: ") + e.what());
+            std::cerr << "volren_amd: RCCL is not available (" << e.what() << "): the tile buffers are exchanged with peer copies" << std::endl;
+            comms_.clear();
+            transport_ = "copy";
+        }
     }
 }
 
