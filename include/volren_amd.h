@@ -95,8 +95,9 @@ int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
  *     "launch_target_ms" (default 2000: a vr_render is split into sub-launches planned to take at most this long each, from the rate this
  *     renderer measured last -- a short probe launch, one synchronisation, when it has none for the current settings and the request is
  *     large; 0 = split by the sample pool alone.  Results never depend on the split)
- *     "order_tiles" (default 1: a launch works through its tiles costliest first -- longest chord of the pixel rays through the volume's box --
- *     so that short paths are what is left when its work queue runs empty; 0 = raster order.  Results never depend on the order) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
+ *     "order_tiles" (a launch works through its tiles costliest first -- longest chord of the pixel rays through the volume's box -- so that short
+ *     paths are what is left when its work queue runs empty: 0 = never (raster order), 1 = when a tile subset is set (vr_set_tiles / a sharded
+ *     renderer's parts; default), 2 = always.  Results never depend on the order) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
  *     "emission_scale" "vol_clip_min"(3) "vol_clip_max"(3) "env_strength" "env_transform"(9) "env_rot"(1, degrees about +y,
  *     main.cpp:382) "tf_window_left" "tf_window_width" "cam_pos"(3) "cam_dir"(3) "cam_up"(3) "cam_fov" "volume_transform"(16) (float) */
 int vr_set_int(vr_renderer* r, const char* name, int value);

@@ -1352,7 +1352,8 @@ def test_tile_order_inside_a_launch_never_changes_the_image():
     w, h, spp = 200, 136, 6
     for config in ("c2", "c5:32"):
         r = scenes.hip_scene(config, w, h)
-        assert r.order_tiles == 1
+        assert r.order_tiles == 1                       # default: tile subsets only
+        r.order_tiles = 2
         r.render(spp)
         want = r.framebuffer().copy()
         r.order_tiles = 0
@@ -1362,9 +1363,10 @@ def test_tile_order_inside_a_launch_never_changes_the_image():
         r.cam_dir = (-0.5, -0.3, -0.8)
         r.reset(); r.render(spp)
         inside = r.framebuffer().copy()
-        r.order_tiles = 1
+        r.order_tiles = 2
         r.reset(); r.render(spp)
         assert np.array_equal(_bits(r.framebuffer()), _bits(inside)), config
+        r.order_tiles = 1
         sh = TileShard(w, h, 4, 1)
         r.set_tiles(sh.mine)
         r.reset(); r.render(spp)

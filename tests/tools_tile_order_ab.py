@@ -18,7 +18,7 @@ for cfg, w, h, spp in (("c2", 1024, 1024, 1024), ("c3", 1024, 1024, 1024), ("c4:
         r.set_tiles(sh.mine if world > 1 else [])
         out = {}
         for mode in (0, 1, 0, 1):
-            r.order_tiles = mode
+            r.order_tiles = 2 * mode
             r.reset()
             r.render(spp)
             out.setdefault(mode, []).append(r.last_pathtrace_ms())

@@ -17,7 +17,7 @@ r.launch_target_ms = 0
 if world > 1:
     r.set_tiles(TileShard(w, h, world, 3 % world).mine)
 for order in (0, 1):
-    r.order_tiles = order
+    r.order_tiles = 2 * order
     r.reset(); r.render(spp)
     r.sched_stats(True)
     r.reset(); r.render(spp)

@@ -289,7 +289,7 @@ int vr_set_int(vr_renderer* r, const char* name, int v) {
         else if (n == "gpu_encoder") R.gpu_encoder = v != 0;
         else if (n == "sample_pool_mb") { if (v < 16 || v > 49152) throw std::runtime_error("sample_pool_mb must be in [16, 49152] (item indices of a sub-launch are 32-bit: < 2^32 RGBA32F items)"); R.sample_pool_bytes = (size_t)v << 20; }
         else if (n == "launch_target_ms") { if (v < 0) throw std::runtime_error("launch_target_ms must be >= 0 (0 = no sizing by time)"); R.launch_target_ms = v; }
-        else if (n == "order_tiles") R.order_tiles = v != 0;
+        else if (n == "order_tiles") { if (v < 0 || v > 2) throw std::runtime_error("order_tiles: 0 (never), 1 (tile subsets), 2 (always)"); R.order_tiles = v; }
         else if (n == "grid_frame_counter") {
             if (!R.volume || v < 0 || (size_t)v >= R.volume->n_grid_frames()) throw std::runtime_error("grid_frame_counter out of range");
             R.volume->grid_frame_counter = (size_t)v;
@@ -315,7 +315,7 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "gpu_encoder") *v = R.gpu_encoder ? 1 : 0;
         else if (n == "sample_pool_mb") *v = (int)(R.sample_pool_bytes >> 20);
         else if (n == "launch_target_ms") *v = R.launch_target_ms;
-        else if (n == "order_tiles") *v = R.order_tiles ? 1 : 0;
+        else if (n == "order_tiles") *v = R.order_tiles;
         else if (n == "grid_frame_counter") *v = R.volume ? (int)R.volume->grid_frame_counter : 0;
         else if (n == "n_grid_frames") *v = R.volume ? (int)R.volume->n_grid_frames() : 0;
         else if (n == "last_launches") *v = R.last_launches;

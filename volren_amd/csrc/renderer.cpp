@@ -487,7 +487,8 @@ void RendererHIP::launch(int n) {
     update_majorants(P, density_grids[volume->grid_frame_counter]);
     const int tiles_x = (resolution.x + 15) / 16, tiles_y = (resolution.y + 15) / 16;
     const int n_tiles = tiles_dev_ ? (int)tiles_host_.size() : tiles_x * tiles_y;
-    const int32_t* tiles = order_tiles ? tile_order(P, n_tiles) : (tiles_dev_ ? tiles_dev_->as<int32_t>() : nullptr);
+    const bool ordered = order_tiles >= 2 || (order_tiles == 1 && tiles_dev_);
+    const int32_t* tiles = ordered ? tile_order(P, n_tiles) : (tiles_dev_ ? tiles_dev_->as<int32_t>() : nullptr);
     // per-sample radiances live in a device pool; split the request so that one sub-launch fits the pool
     const size_t per_sample = pathtrace_pool_floats(tuning, n_tiles, 1) * sizeof(float);
     int per_launch = (int)std::max<size_t>(1, sample_pool_bytes / per_sample);

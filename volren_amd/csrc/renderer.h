@@ -114,9 +114,10 @@ struct RendererHIP {
     int integrator = 0;                               // 0: DDA tracking (both reference kernels), 1: global-majorant tracking (common.glsl:333-394),
                                                       // 2: direct volume rendering (:571-591, needs a LUT), 3: 64-step ray-marching trackers (:506-566)
     bool tf_float_atlas = true;                       // transfer-function renders decode the brick atlas to floats once (4x its size): one load per corner tap
-    bool order_tiles = true;                          // a launch works through its tiles costliest first (chord of the pixel rays through the volume's box), so that what
-                                                      // is left when the work queue runs empty are short paths: the drain of the persistent wavefronts' pools shrinks
-                                                      // (profiles/r4f_*).  Which tile runs when never changes a result
+    int order_tiles = 1;                              // a launch works through its tiles costliest first (chord of the pixel rays through the volume's box), so that what
+                                                      // is left when the work queue runs empty are short paths (profiles/r4f_*): 0 never, 1 when the renderer has a tile
+                                                      // subset (a rank's share: +0.5 ... +7 %), 2 always (full frames measure +-0.5 %: raster order stays their default).
+                                                      // Which tile runs when never changes a result
     bool fast_math = false;                           // opt-in tolerance mode: hardware log/sin/cos/rcp instead of the specified arithmetic
                                                       // (not bit-reproducible; without a transfer function within 1e-3 relative L2 of the default --
                                                       // with one bound the renderer refuses it: DESIGN.md 3)
