@@ -60,6 +60,9 @@ void RendererHIP::resize(uint32_t w, uint32_t h) {
 void RendererHIP::reset() { sample = 0; }
 
 // ---------------------------------------------------------------------------------------------------
+static void check_grid_bytes(size_t bytes, const char* what, const int32_t nb[3]);
+static size_t brick_records(const BrickGridHIP& g);
+
 void RendererHIP::commit() {
     rate_samples_per_ms_ = 0.0; rate_pending_samples_ = 0.0;      // a new volume: nothing measured yet
     density_grids.clear();
@@ -78,6 +81,25 @@ void RendererHIP::commit() {
         if (emission_grid) {
             emission_grids.push_back(grid_to_device(emission_grid));
             majorant_emission = std::max(majorant_emission, emission_grid->minorant_majorant().second);
+            // Both grids of the frame in brick form with the same brick layout: one paired atlas for the kernel compiled for that case (vr_scene.h).  The grids keep
+            // their own atlases too (float-atlas decoder, the run-time variant); when the paired one does not fit, the run-time variant serves the frame.
+            BrickGridHIP& gd = density_grids.back();
+            BrickGridHIP& ge = emission_grids.back();
+            if (VR_PAIRED_ATLAS && VR_BRICK_HEADERS && emission_grids.size() == density_grids.size() && gd.atlas && ge.atlas && !gd.dense && !ge.dense &&
+                gd.nb[0] == ge.nb[0] && gd.nb[1] == ge.nb[1] && gd.nb[2] == ge.nb[2]) {
+                try {
+                    const size_t n_rec = brick_records(gd);
+                    check_grid_bytes(n_rec * kPairBlockBytes, "the paired density + emission atlas", gd.nb);
+                    auto paired = make_device_buffer(n_rec * kPairBlockBytes);
+                    launch_pair_atlas(gd.atlas->as<uint8_t>(), ge.atlas->as<uint8_t>(), paired->as<uint8_t>(), n_rec, stream);
+                    VR_HIP(hipGetLastError());
+                    VR_HIP(hipStreamSynchronize(stream));
+                    gd.atlas_paired = ge.atlas_paired = paired;
+                } catch (const std::exception& e) {
+                    (void)hipGetLastError();
+                    std::cerr << "volren_amd: no room for the paired density + emission atlas (" << e.what() << "): the run-time kernel variant serves this frame" << std::endl;
+                }
+            }
         }
     }
 }
@@ -280,10 +302,10 @@ void RendererHIP::scale_and_move_to_unit_cube() {
 // ---------------------------------------------------------------------------------------------------
 static void copy3(float* dst, vec3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
 
-static GridView make_view(const BrickGridHIP& g) {
+static GridView make_view(const BrickGridHIP& g, bool paired = false) {
     GridView v;
     v.bricks = g.bricks ? g.bricks->as<BrickRec>() : nullptr;
-    v.atlas = g.atlas ? g.atlas->as<uint8_t>() : nullptr;
+    v.atlas = paired ? g.atlas_paired->as<uint8_t>() : (g.atlas ? g.atlas->as<uint8_t>() : nullptr);
     v.dense = g.dense ? g.dense->as<uint16_t>() : nullptr;
     for (int i = 0; i < 3; ++i) v.dim[i] = g.dim[i];
     for (int i = 0; i < 2; ++i) v.dblk[i] = g.dblk[i];
@@ -343,7 +365,10 @@ void RendererHIP::fill_params(SceneParams& P) {
         memcpy(u.vol_emission_inv_transform, eti.m, sizeof eti.m);
         const mat4 efd = eti * dt;
         memcpy(P.emission_from_density, efd.m, sizeof efd.m);
-        P.emission = make_view(emission);
+        // the kernel compiled for two brick grids (DDA trackers) reads them from their paired atlas; every other kernel reads each grid's own
+        P.paired = (integrator == 0 && density.atlas_paired && density.atlas_paired == emission.atlas_paired) ? 1 : 0;
+        if (P.paired) P.density = make_view(density, true);
+        P.emission = make_view(emission, P.paired != 0);
         u.has_emission = 1;
     }
     // transfer function

@@ -40,6 +40,8 @@ struct BrickGridHIP {
     DeviceBufferPtr rng;           // compact (rmin, rdiff) float pairs, same index as `bricks` (what a tap reads)
     DeviceBufferPtr atlas_f32;     // decoded float atlas, built on the first render with a transfer function (4x the atlas; dropped by commit())
     bool atlas_f32_failed = false; // its allocation failed once: not retried until commit() or a tf_float_atlas toggle (the byte atlas serves)
+    DeviceBufferPtr atlas_paired;  // this grid's voxels interleaved with those of the frame's other grid (density + emission grids of one brick layout: vr_scene.h);
+                                   // one buffer, held by both grids of the frame; built by commit()
     DeviceBufferPtr dense;         // dense fp16 voxels in 4x4x4 blocks (DenseGridF16), then bricks/atlas are empty
     int32_t dim[3] = { 0, 0, 0 };
     int32_t dblk[2] = { 0, 0 };            // 4x4x4 blocks per axis (x, y) of the dense layout

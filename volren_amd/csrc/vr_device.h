@@ -51,6 +51,9 @@ void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_
                           BrickRec* recs, float* rng, uint8_t* atlas, hipStream_t stream);      // rng: compact (rmin, rdiff) pairs, same index as recs
 void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream);
 
+// paired atlas of a density and an emission brick grid with the same brick layout (vr_scene.h kPairBlockBytes per brick); needs VR_BRICK_HEADERS blocks as input
+void launch_pair_atlas(const uint8_t* atlas_density, const uint8_t* atlas_emission, uint8_t* out, size_t n_records, hipStream_t stream);
+
 // decoded float atlas (one float per atlas byte: rmin + unorm8(b) * rdiff of its brick), used by transfer-function renders
 void launch_decode_atlas(const float* rng, const uint8_t* atlas, float* out, size_t n_records, hipStream_t stream);
 

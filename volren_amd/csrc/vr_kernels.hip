@@ -127,7 +127,8 @@ static const PtLaunch kPtLaunch[2][4] = { { vr_pt_launch_0, vr_pt_launch_1, vr_p
 // which compiled variant serves a scene (see vr_pathtrace.hip)
 static int pathtrace_variant(const SceneParams& P) {
     if (P.u.integrator != 0) return 3;
-    if (P.u.has_emission) return (P.density.dense || P.emission.dense) ? 3 : 2;      // variant 2: both grids in brick form
+    // variant 2: both grids in brick form -- and, when the kernels are built for the paired atlas, sharing one (same brick layout: RendererHIP::commit)
+    if (P.u.has_emission) return (P.density.dense || P.emission.dense || (VR_PAIRED_ATLAS && !P.paired)) ? 3 : 2;
     return P.density.dense ? 1 : 0;
 }
 
@@ -351,6 +352,30 @@ void launch_encode_bricks(const float* dense, const int32_t dim[3], const int32_
 void launch_range_mip(const uint32_t* src, const int32_t sdim[3], uint32_t* dst, const int32_t ddim[3], hipStream_t stream) {
     const int32_t n = ddim[0] * ddim[1] * ddim[2];
     hipLaunchKernelGGL(range_mip_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, sdim[0], sdim[1], sdim[2], dst, ddim[0], ddim[1], ddim[2]);
+}
+
+// paired atlas (vr_scene.h): the voxels of a density brick and of the emission brick at the same index, interleaved, with both decode ranges at the head of every line
+__global__ void __launch_bounds__(64)
+pair_atlas_kernel(const uint8_t* __restrict__ atlas_d, const uint8_t* __restrict__ atlas_e, uint8_t* __restrict__ out) {
+    const size_t rec = blockIdx.x;
+    const uint8_t* bd = atlas_d + rec * (size_t)kBrickBlockBytes;
+    const uint8_t* be = atlas_e + rec * (size_t)kBrickBlockBytes;
+    uint8_t* dst = out + rec * (size_t)kPairBlockBytes;
+    const int32_t lane = threadIdx.x;
+    if (lane < 10) {          // every line's header: (rmin, rdiff) of both bricks = the first 8 bytes of any line of their own blocks
+        const float* hd = reinterpret_cast<const float*>(bd);
+        const float* he = reinterpret_cast<const float*>(be);
+        float* h = reinterpret_cast<float*>(dst + lane * 128);
+        h[0] = hd[0]; h[1] = hd[1]; h[2] = he[0]; h[3] = he[1];
+    }
+    for (int32_t i = lane; i < 512; i += 64) {
+        dst[pair_voxel_byte((uint32_t)i, 0u)] = bd[brick_voxel_byte((uint32_t)i)];
+        dst[pair_voxel_byte((uint32_t)i, 1u)] = be[brick_voxel_byte((uint32_t)i)];
+    }
+}
+void launch_pair_atlas(const uint8_t* atlas_d, const uint8_t* atlas_e, uint8_t* out, size_t n_records, hipStream_t stream) {
+    if (n_records == 0) return;
+    hipLaunchKernelGGL(pair_atlas_kernel, dim3((unsigned)n_records), dim3(64), 0, stream, atlas_d, atlas_e, out);
 }
 
 // decoded float atlas for transfer-function renders: out[i*512 + v] = rmin_i + unorm8(atlas[i*512 + v]) * rdiff_i (common.glsl:268-275)

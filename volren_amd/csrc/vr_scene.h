@@ -61,6 +61,19 @@ constexpr uint32_t kBrickBlockBytes = VR_BRICK_HEADERS ? 640u : 512u;
 VR_SCENE_HD uint32_t brick_voxel_line(uint32_t off) { return VR_BRICK_HEADERS ? (off * 547u) >> 16 : off >> 7; }      // off / 120 for off < 512 (547 / 65536 = 1 / 119.81)
 VR_SCENE_HD uint32_t brick_voxel_byte(uint32_t off) { return off + kBrickLineHeader * (brick_voxel_line(off) + 1u); }  // = 128 line + 8 + (off - 120 line)
 
+// Paired atlas blocks (round 4, -DVR_PAIRED_ATLAS=0 switches it off): when a frame's density grid and its emission grid are both brick grids of the same brick
+// layout -- BASELINE configs[4] -- the kernel compiled for that case (variant 2) reads ONE atlas in which a brick's block is ten cache lines of
+// [rmin_d, rdiff_d, rmin_e, rdiff_e | 56 x (density voxel, emission voxel)]: the emission tap of a tentative collision (a second stochastic tricubic tap around the
+// same point) lands in the line the density tap fetched in 38 % of the cases (same brick and the same run of 56 voxels: profiles/r4g_*), instead of always
+// fetching a line of its own from a second atlas.  Same bytes per brick as two 640-byte blocks.
+#ifndef VR_PAIRED_ATLAS
+#define VR_PAIRED_ATLAS 1
+#endif
+constexpr uint32_t kPairLineVoxels = 56u, kPairLineHeader = 16u, kPairBlockBytes = 1280u;
+VR_SCENE_HD uint32_t pair_voxel_line(uint32_t off) { return (off * 1171u) >> 16; }                    // off / 56 for off < 512 (checked for all 512)
+// byte of voxel `off` of component c (0 density, 1 emission) inside the paired block
+VR_SCENE_HD uint32_t pair_voxel_byte(uint32_t off, uint32_t c) { const uint32_t l = pair_voxel_line(off); return l * 128u + kPairLineHeader + 2u * (off - l * kPairLineVoxels) + c; }
+
 // element index of voxel (x, y, z) in the blocked dense layout (see GridView::dense)
 VR_SCENE_HD size_t dense_blocked_index(uint32_t x, uint32_t y, uint32_t z, uint32_t blocks_x, uint32_t blocks_y) {
     return (((size_t)(z >> 2) * blocks_y + (y >> 2)) * blocks_x + (x >> 2)) * 64u + (((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u));
@@ -149,6 +162,7 @@ struct SceneParams {
     GridView density;
     GridView emission;
     float emission_from_density[16];   // vol_emission_inv_transform * vol_density_transform (common.glsl:325)
+    int32_t paired;                    // host side only (which kernel variant serves the scene): density.atlas and emission.atlas are ONE paired atlas (kPairBlockBytes per brick)
     const float* tf_lut;               // tf_size x vec4 (std430 SSBO binding 4)
     const float* envmap;               // env_w*env_h texels of kEnvTexelFloats floats (RGB), row 0 = v~0
     int32_t env_w, env_h;

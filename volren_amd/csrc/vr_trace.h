@@ -47,6 +47,8 @@ struct TraceCfg {
     static constexpr bool tf = TF;
     static constexpr int global = GLOBAL, emission = EMISSION, dense = DENSE;
     static constexpr int edense = EMISSION == 1 ? DENSE : 2;      // a kernel with a compiled-in emission grid takes it in the same form as the density grid
+    // that kernel, on brick grids, reads both grids from one paired atlas (vr_scene.h): component 1 = density, 2 = emission, 0 = a grid's own atlas
+    static constexpr int pair_d = (VR_PAIRED_ATLAS && EMISSION == 1 && DENSE == 0) ? 1 : 0, pair_e = pair_d ? 2 : 0;
 };
 
 // the pool of work items of one wavefront: pixel p = item & 63 of the 8x8 tile at (px0, py0), sample
@@ -173,9 +175,18 @@ VR_HD TapAddr tap_addr(const GridView& g, int32_t x, int32_t y, int32_t z) {
     if (!a.in) { a.cell = 0u; a.off = 0u; }       // the loads are unconditional: an outside tap reads cell 0 and is discarded
     return a;
 }
-template <int DENSE = 2>
+template <int DENSE = 2, int PAIR = 0>
 VR_HD TapData tap_load(const GridView& g, TapAddr a) {
     TapData d;
+    if (PAIR != 0) {
+        // paired atlas: ten lines of [rmin_d, rdiff_d, rmin_e, rdiff_e | 56 x (density, emission)] per brick
+        const uint32_t line = pair_voxel_line(a.off);
+        const uint8_t* ln = g.atlas + ((size_t)a.cell * kPairBlockBytes + (size_t)(line * 128u));
+        const float* rec = reinterpret_cast<const float*>(ln) + (PAIR == 2 ? 2 : 0);
+        d.rmin = rec[0]; d.rdiff = rec[1];
+        d.raw = ln[kPairLineHeader + 2u * (a.off - line * kPairLineVoxels) + (PAIR == 2 ? 1u : 0u)];
+        return d;
+    }
     if (grid_is_dense<DENSE>(g)) {
         d.rmin = 0.0f; d.rdiff = 0.0f;
         d.raw = g.dense[(size_t)a.cell * 64u + a.off];
@@ -299,7 +310,7 @@ VR_HD void trilinear_prep(const GridView& g, v3 ipos, TriIO& io) {
 }
 // The 8 corner loads.  With a decoded float atlas (GridView::atlas_f32, brick grids under a transfer function) a corner is ONE
 // 4-byte load of the value the byte path would compute (rmin + unorm8(b) * rdiff, evaluated once when the atlas is decoded).
-template <int DENSE = 2>
+template <int DENSE = 2, int PAIR = 0>
 VR_HD void trilinear_load(const GridView& g, TriIO& io) {
     if (!grid_is_dense<DENSE>(g) && g.atlas_f32) {
 #pragma unroll
@@ -307,7 +318,7 @@ VR_HD void trilinear_load(const GridView& g, TriIO& io) {
         return;
     }
 #pragma unroll
-    for (int n = 0; n < 8; ++n) io.d[n] = tap_load<DENSE>(g, io.a[n]);
+    for (int n = 0; n < 8; ++n) io.d[n] = tap_load<DENSE, PAIR>(g, io.a[n]);
 }
 VR_HD void trilinear_idle(TriIO& io) {           // addresses of a lane without a lookup: cell 0
 #pragma unroll
@@ -949,9 +960,9 @@ template <class K>
 VR_HD void collide_prep(Hot& h, const SceneParams& P, CollideIO<K>& io) { collide_prep<K>(h, P, P, io); }
 template <class K>
 VR_HD void collide_load(const SceneParams& P, const SceneParams& PE, CollideIO<K>& io) {      // unconditional, like march_load
-    if (K::tf) trilinear_load<K::dense>(P.density, io.tri);
-    else io.d = tap_load<K::dense>(P.density, io.a);
-    if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) io.ed = tap_load<K::edense>(PE.emission, io.ea);
+    if (K::tf) trilinear_load<K::dense, K::pair_d>(P.density, io.tri);
+    else io.d = tap_load<K::dense, K::pair_d>(P.density, io.a);
+    if (K::emission == 2 ? P.u.has_emission != 0 : K::emission == 1) io.ed = tap_load<K::edense, K::pair_e>(PE.emission, io.ea);
 }
 template <class K>
 VR_HD void collide_load(const SceneParams& P, CollideIO<K>& io) { collide_load<K>(P, P, io); }
