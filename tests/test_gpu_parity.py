@@ -300,6 +300,33 @@ def test_emission_grid_and_brick_upload():
     _assert_same(hip, o.render(8), "brick upload + emission")
 
 
+def test_emission_grid_with_a_different_brick_layout():
+    """A temperature grid of another resolution and transform than the density grid (40^3 voxels scaled 1.8x over a 72^3 density grid: 8^3 against 16^3
+    bricks): no paired atlas for this frame -- the kernel compiled for two brick grids of one layout is not the one that runs -- and emission_inv_transform *
+    density_transform is a real matrix.  Same image as the oracle bit for bit; then the same pair of grids at equal layout for contrast."""
+    from oracle import binding as ob
+    import encoder_ref
+    import volren_amd
+    dens = scenes.synthetic_density(72, blobs=12)
+    temp = np.clip(scenes.synthetic_density(40, seed=99) * 0.2, 0, None).astype(np.float32)
+    t_temp = np.diag([1.8, 1.8, 1.8, 1.0]).astype(np.float32).reshape(16)
+    ad, at = encoder_ref.encode_arrays(dens), encoder_ref.encode_arrays(temp, t_temp)
+    assert tuple(ad["n_bricks"]) == (16, 16, 16) and tuple(at["n_bricks"]) == (8, 8, 8)
+    r = volren_amd.Renderer(72, 56)
+    r.load_envmap(scenes.HDR)
+    r.set_volume_brick(ad["transform"], ad["n_bricks"], ad["min_maj"], ad["indirection"], ad["rng"], ad["atlas_dim"], ad["atlas"], ad["mips"], commit=False)
+    r.set_volume_brick(at["transform"], at["n_bricks"], at["min_maj"], at["indirection"], at["rng"], at["atlas_dim"], at["atlas"], at["mips"], name="temperature", commit=True)
+    o = ob.OracleRenderer(72, 56)
+    o.load_envmap(scenes.HDR)
+    o.set_volume(encoder_ref.encode(dens), emission=encoder_ref.encode(temp, t_temp), majorant_emission=at["min_maj"][1])
+    for x in (r, o):
+        x.cam_fov, x.bounces, x.albedo, x.emission_scale = 40.0, 8, (0.7, 0.8, 0.9), 50.0
+    r.render(6)
+    hip = r.framebuffer()
+    assert hip[..., :3].max() > 0
+    _assert_same(hip, o.render(6), "emission grid of another layout")
+
+
 def _crop_bricks(a, nbc):
     """Centred sub-block nbc = (cx, cy, cz) of an encode_arrays() brick grid: indirection/range cropped (the atlas pointers stay
     valid), range mips rebuilt with the ceil(n / 2) rule (min of mins, max of maxes over the existing children)."""
