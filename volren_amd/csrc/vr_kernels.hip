@@ -173,7 +173,8 @@ void launch_pathtrace(const PathtraceTuning& T, const SceneParams& P, float* fb,
     // lanes that must stand at a tentative collision before the collision code runs while others still march (vr_pathtrace.h):
     // measured optimum 24 (smoke.brick +0.5 %, dense +0.7 %, sparse + emission +2...3.5 %), 32 with a transfer function, whose
     // collision code (8 corner taps + LUT) is the dearest (+4.4 %); profiles/r2ab_collide_threshold.txt
-    if (S.thr[ST_COLLIDE] <= 0) S.thr[ST_COLLIDE] = P.u.use_tf ? 32 : 24;
+    // (round 4: 32 also with an emission grid, whose collision code carries two stochastic taps: c5cloud +0.8 %, c5full +1 %, profiles/r4a_*)
+    if (S.thr[ST_COLLIDE] <= 0) S.thr[ST_COLLIDE] = (P.u.use_tf || P.u.has_emission) ? 32 : 24;
     const bool tf = P.u.use_tf != 0, stats = T.stats != nullptr;
     const int mode = fast_math ? 1 : 0;
     const int blocks = resident_blocks(T, mode, variant, tf, stats);
