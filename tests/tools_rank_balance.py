@@ -14,6 +14,7 @@ H = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 SPP = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 schemes = (sys.argv[5] if len(sys.argv) > 5 else "diagonal,hashed").split(",")
 r = scenes.hip_scene(cfg, W, H)
+r.launch_target_ms = 0                      # no probe launch when the tile set changes: a rank's time is its launches' time
 r.render(min(SPP, 32))
 
 
