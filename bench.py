@@ -11,15 +11,23 @@ frame's 16x16 tiles are sharded over the ranks (diagonal interleave), every rank
 radiance is exchanged with ONE RCCL all_gather of the compact per-rank tile buffers per frame.  Total work is fixed, so
 scaling is "strong".
 
+`value` is K whole frames one after the other on one stream -- the same measurement for every N; for N > 1 `value_pipelined` adds the same frames
+alternating between two renderers / streams (the drain of one frame overlapping the start of the next).
+
 Adds to the JSON line:
-  roofline     -- algorithmic HBM bytes (SURVEY.md 8d formula, event counts from the oracle's instrumented counters on
-                  the same config) / HIP-event duration of the path-tracing kernel, vs 8 TB/s.
-  cpu_baseline -- the CPU oracle ("port") timed on the host cores on a bounded sample of the same workload, plus
-                  cpu_baseline_raymarch: the 64-step ray marcher (common.glsl:506-566) SURVEY 8d names.
-  configs      -- (N=1, headline config only) the same measurement for BASELINE configs[2] (c3) and configs[3]'s grid (c4,
-                  512^3 dense fp16) at 1024x1024 / 1024 spp, the resolution north_star quotes its 40 % target at, and for
-                  configs[3] / configs[4] at their own frames (c4 at 1920x1080 x 4096 spp; c5full = 1024^3 sparse brick grid +
-                  emission at 2048x2048 x 4096 spp), two timed frames each.
+  frame_crc32  -- CRC-32 of rank 0's RGBA32F frame after the last step: the same for every N (and equal to the oracle's frame).
+  roofline     -- algorithmic HBM bytes (SURVEY.md 8d formula; event counts from the oracle's instrumented counters on the same config, 8
+                  batches of one sample per pixel, their spread = bytes_per_sample_stderr) / HIP-event duration of the path-tracing kernel,
+                  vs 8 TB/s; `traffic` from the committed PMC profile of the same configuration at the same frame (profiles/r4_hbm_traffic.json,
+                  `stale` when the kernel sources changed since); roofline_issue: the resource that binds on the cached grids -- VALU
+                  wave-instructions per sample (same profile) x this run's rate against the SIMDs' issue rate, lane utilisation beside it.
+  cpu_baseline -- the CPU oracle ("port") timed on the host cores on a bounded sample of the same workload; cpu_baseline_raymarch: the
+                  64-step ray marcher (common.glsl:506-566) SURVEY 8d names; cpu_baseline_c1: BASELINE configs[0] itself (256x256, 16 spp,
+                  4 bounces) by the ray marcher and by the DDA trackers.
+  configs      -- (N=1, headline config only) the same measurement for BASELINE configs[2] (c3) and configs[3]'s grid (c4, 512^3 dense fp16)
+                  at 1024x1024 / 1024 spp, the resolution north_star quotes its 40 % target at, and for configs[3] / configs[4] at their own
+                  frames (c4 at 1920x1080 x 4096 spp; c5full and c5cloud = 1024^3 sparse brick grid + emission at 2048x2048 x 4096 spp: the
+                  rounds-1-3 stand-in and the grid at the occupancy SURVEY 8d names), two timed frames each.
   fast_math    -- (when built) the tolerance-mode kernels: speed and relative L2 against the bit-exact default.
 """
 import argparse
