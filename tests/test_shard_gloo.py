@@ -90,7 +90,10 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_render_equals_single_process():
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_render_equals_single_process(world):
+    """world_size 2 and 8 (the node size the north star names) over gloo: every rank renders its diagonal share with the oracle, ONE all_gather, every
+    rank's unshuffled frame equals the single-process frame bit for bit."""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -98,15 +101,15 @@ def test_two_rank_render_equals_single_process():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(rk, 2, port, q)) for rk in range(2)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, q)) for rk in range(world)]
     for p in procs:
         p.start()
-    frames = dict(q.get(timeout=300) for _ in range(2))
+    frames = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     ref = scenes.oracle_scene("c1", W, H).render(SPP)
-    for rk in (0, 1):
+    for rk in range(world):
         assert np.array_equal(frames[rk].view(np.uint32), ref.view(np.uint32)), "rank %d frame differs" % rk
 
 
