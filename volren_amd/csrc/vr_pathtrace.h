@@ -719,6 +719,10 @@ pathtrace_kernel(const KernelArgs A) {
             Hot b;
 #else
             const int32_t my_slot = slot;
+            // a lane that WAITS at a tentative collision (fewer than the collide threshold stand there) needs its step's majorant back after the batch: the parked
+            // hot state does not hold it (a parked path is never in that state).  Lost until round 4 -- the real / null decision then tested against 0: results
+            // of this variant depended on the scheduler's thresholds (found by test_emission_grid_with_a_different_brick_layout)
+            const float my_majorant = l.majorant;
             if (my_slot >= 0) { hs.save(l, my_slot); if (emission_on && !l.shadow) { ColdT c = VR_COLD(my_slot); st3(c, C_L, l.eL); } }
             __builtin_amdgcn_wave_barrier();
             Hot& b = l;
@@ -848,7 +852,7 @@ pathtrace_kernel(const KernelArgs A) {
             }
 #if !VR_BATCH_REGS
             __builtin_amdgcn_wave_barrier();
-            if (my_slot >= 0) { hs.load_resume(l, my_slot); if (emission_on && !l.shadow) { const ColdT c = VR_COLD(my_slot); l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L); } }
+            if (my_slot >= 0) { hs.load_resume(l, my_slot); l.majorant = my_majorant; if (emission_on && !l.shadow) { const ColdT c = VR_COLD(my_slot); l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L); } }
 #endif
         }
         VR_SECTION(3);                                                   // batch decision + event batches (the events' own cycles are in st_cyc)
