@@ -1373,15 +1373,24 @@ def test_no_path_depends_on_stale_cold_state(config, monkeypatch):
     _assert_same(r.framebuffer(), o.render(4), "poisoned workspace, " + config)
 
 
-@pytest.mark.parametrize("config", ["c2", "c3", "c4:64", "c5:32"])
+@pytest.mark.parametrize("config", ["c2", "c3", "c4:64", "c5:32", "c2+global", "c3+global", "c5:32+lut", "c5:32+global", "c4:64+lut"])
 def test_results_do_not_depend_on_the_scheduler(config):
     """Which lane runs which path when -- event-batch thresholds, the number of lanes that must stand at a collision before the
     collision code runs, the size of the path pool, the samples per work unit -- never changes a result: every setting below gives
     the image the default gives, bit for bit (and that one is the oracle's, asserted by the other tests)."""
     w, h, spp = 72, 56, 6
-    r = scenes.hip_scene(config, w, h)
+    name, _, mod = config.partition("+")              # +global: the global-majorant trackers (run-time kernel variant), +lut: a transfer function on top
+    r = scenes.hip_scene(name, w, h)
+    o = scenes.oracle_scene(name, w, h)
+    if mod == "global":
+        r.integrator = 1
+        o.integrator = 1
+    if mod == "lut":
+        r.load_transferfunc(scenes.LUT)
+        o.load_transferfunc(scenes.LUT)
     r.render(spp)
     want = r.framebuffer().copy()
+    _assert_same(want, o.render(spp), config)          # ... and that image is the oracle's
     # NEW, pool cap, hungry, collide threshold, NEE, POSTNEE, ESCAPE
     settings = [[64, 0, 56, 1, 60, 60, 64, 0], [64, 0, 56, 64, 60, 60, 64, 0], [8, 0, 8, 40, 8, 8, 8, 0], [64, 70, 56, 24, 64, 64, 64, 0],
                 [1, 66, 1, 1, 1, 1, 1, 0], [64, 0, 64, 63, 64, 64, 64, 0]]
@@ -1391,6 +1400,12 @@ def test_results_do_not_depend_on_the_scheduler(config):
         r.render(spp)
         got = r.framebuffer()
         assert np.array_equal(_bits(got), _bits(want)), ("scheduler setting", s)
+    r.set_sched([64, 0, 56, 0, 60, 60, 64, 0])
+    r.reset()
+    for _ in range(spp):                               # one launch per sample (the reference's trace() protocol): pools that never fill
+        r.trace()
+    r.synchronize()
+    assert np.array_equal(_bits(r.framebuffer()), _bits(want)), "trace() x spp"
 
 
 def test_tile_order_inside_a_launch_never_changes_the_image():
