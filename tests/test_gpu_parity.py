@@ -1361,13 +1361,19 @@ def test_dense_grid_kernel_variants(variant):
     _assert_same(r.framebuffer(), o.render(5), "dense grid: " + variant)
 
 
-@pytest.mark.parametrize("config", ["c1", "c3", "c5:32"])
+@pytest.mark.parametrize("config", ["c2", "c3", "c4:64", "c5:32", "c2+global", "c5:32+lut", "c5:32+global"])
 def test_no_path_depends_on_stale_cold_state(config, monkeypatch):
     """A new path writes no cold line before its first scatter event (FirstStash, vr_trace.h) and a path that never scatters
     none at all: whatever the workspace held before -- here NaN patterns (VR_TEST_POISON_WORKSPACE, renderer.cpp) -- must
     not reach a result.  c5: with an emission grid the collision code accumulates into the line from the first segment on."""
     monkeypatch.setenv("VR_TEST_POISON_WORKSPACE", "1")
-    r, o = scenes.hip_scene(config, 96, 64), scenes.oracle_scene(config, 96, 64)
+    name, _, mod = config.partition("+")          # +global / +lut as in test_results_do_not_depend_on_the_scheduler: the other kernel variants
+    r, o = scenes.hip_scene(name, 96, 64), scenes.oracle_scene(name, 96, 64)
+    for x in (r, o):
+        if mod == "global":
+            x.integrator = 1
+        if mod == "lut":
+            x.load_transferfunc(scenes.LUT)
     r.render(4)                                   # the workspace is allocated (and poisoned) by the first launch
     monkeypatch.delenv("VR_TEST_POISON_WORKSPACE")
     _assert_same(r.framebuffer(), o.render(4), "poisoned workspace, " + config)
@@ -1445,6 +1451,51 @@ def test_tile_order_inside_a_launch_never_changes_the_image():
     t = r.wave_timeline()
     r.sched_stats(False)
     assert len(t) > 0 and (t[:, 0] >= 0).all() and (t[:, 1] >= t[:, 0]).all() and (t[:, 2] >= t[:, 1]).all() and t[:, 2].max() < 1.0
+
+
+def test_scheduler_and_launch_fuzz_against_the_oracle():
+    """Seeded random combinations of what must never change an image -- scheduler thresholds, pool cap, sample-pool size (how a frame is cut into
+    sub-launches), launch sizing by time, tile order, a tile subset -- on every kernel variant, each against the oracle bit for bit.  (Round 4 found a
+    variant whose image depended on a threshold: test_emission_grid_with_a_different_brick_layout.)"""
+    from volren_amd.shard import TileShard
+    rs = np.random.RandomState(4242)
+    scenes_ = ["c2", "c3", "c4:64", "c5:32", "c2+global", "c3+global", "c5:32+lut", "c5:32+global", "c4:64+lut", "c5cloud:64"]
+    w, h, spp = 80, 48, 5
+    for trial in range(30):
+        config = scenes_[trial % len(scenes_)]
+        name, _, mod = config.partition("+")
+        r, o = scenes.hip_scene(name, w, h), scenes.oracle_scene(name, w, h)
+        for x in (r, o):
+            if mod == "global":
+                x.integrator = 1
+            if mod == "lut":
+                x.load_transferfunc(scenes.LUT)
+        cap = int(rs.choice([0, 0, 70, 100, 150]))
+        new = int(rs.randint(1, 65))
+        if cap:
+            new = min(new, cap)
+        thr = [new, cap, int(rs.randint(1, 65)), int(rs.randint(1, 65)), int(rs.randint(1, 65)), int(rs.randint(1, 65)), int(rs.randint(1, 65)), 0]
+        r.set_sched(thr)
+        r.sample_pool_mb = int(rs.choice([16, 16, 64, 16384]))
+        r.launch_target_ms = int(rs.choice([0, 1, 2000]))
+        r.order_tiles = int(rs.randint(0, 3))
+        ref = o.render(spp)
+        share = None
+        if rs.rand() < 0.5:
+            share = TileShard(w, h, int(rs.choice([2, 3, 8])), 0).mine
+            r.set_tiles(share)
+        k = int(rs.randint(1, spp))
+        r.render(k)                                   # a frame in two calls
+        r.render(spp - k)
+        fb = r.framebuffer()
+        what = "trial %d: %s thr %s pool %d MB target %d ms order %d tiles %s split %d" % (trial, config, thr, r.sample_pool_mb, r.launch_target_ms, r.order_tiles, "share" if share else "all", k)
+        if share is None:
+            _assert_same(fb, ref, what)
+        else:
+            tx = (w + 15) // 16
+            for t in share:
+                y0, x0 = (t // tx) * 16, (t % tx) * 16
+                assert np.array_equal(_bits(fb[y0:y0 + 16, x0:x0 + 16]), _bits(ref[y0:y0 + 16, x0:x0 + 16])), what + " tile %d" % t
 
 
 def test_tuning_state_is_per_renderer():
