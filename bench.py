@@ -14,7 +14,15 @@ scaling is "strong".
 `value` is K whole frames one after the other on one stream -- the same measurement for every N; for N > 1 `value_pipelined` adds the same frames
 alternating between two renderers / streams (the drain of one frame overlapping the start of the next).
 
+`python bench.py --gpus N --host sharded [--devices a,b,...]` measures the PRODUCT's multi-GPU host instead (include/volren_amd.h vr_sharded_*,
+csrc/sharded.cpp: ONE process, N renderers on N devices, one grouped ncclAllGather per frame through librccl) and prints the same line with
+`host: "sharded"`, `rccl_ranks: N`, `frame_crc32`.  Under the driver's torchrun command for N > 1 rank 0 also runs that mode as a child process once the
+ranks have finished (they have left the GPUs by then) and reports it as `value_sharded` / `sharded` beside the torch.distributed `value`.
+
 Adds to the JSON line:
+  value_trace_loop -- (N=1) the same frame driven the way the reference drives it, `while (sample < sppx) trace();` (src/main.cpp:533-537,
+                  src/bindings.cpp:124-132): spp x vr_trace + one vr_synchronize per step.  Consecutive trace() calls are coalesced into fused launches
+                  (csrc/renderer.h), so this is expected within a few per cent of `value`.
   frame_crc32  -- CRC-32 of rank 0's RGBA32F frame after the last step: the same for every N (and equal to the oracle's frame).
   roofline     -- algorithmic HBM bytes (SURVEY.md 8d formula; event counts from the oracle's instrumented counters on the same config, 8
                   batches of one sample per pixel, their spread = bytes_per_sample_stderr) / HIP-event duration of the path-tracing kernel,
@@ -63,6 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     ap.add_argument("--extra-configs", default=None, help="comma list of further configs measured at N=1 and reported under 'configs' (default: c3,c4 for the headline run; 'none' to skip)")
     ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: still initialise the process group (RCCL) and run the sharded flow pack_tiles -> all_gather -> unpack_tiles with one rank")
+    ap.add_argument("--host", default="dist", choices=("dist", "sharded"), help="dist: one process per GPU under torch.distributed (the contract's launcher); sharded: ONE process, the product's ShardedRenderer (vr_sharded_*) on --gpus devices")
+    ap.add_argument("--devices", default=None, help="--host sharded: comma list of device ordinals, one per part (repeats = logical shards of one device); default 0..gpus-1")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous and exchange one tile buffer (no rendering): checks the launcher path")
     return ap.parse_args(argv)
 
@@ -330,47 +340,80 @@ class Bench:
         return dict(value=samples * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, value_pipelined=(samples * steps / piped / 1e6) if piped else None, kernel_ms=(pt_ms if pt_ms > 0 else last_ms) / launches, frame_gpu_ms=last_ms,
                     launches=launches, samples_per_launch=my_samples / launches)
 
+    def measure_trace_loop(self, steps):
+        """The reference's own call protocol (src/main.cpp:533-537, src/bindings.cpp:124-132): reset(); while (sample < sppx) trace(); -- spp calls of
+        vr_trace and ONE vr_synchronize per frame, timed like measure()."""
+        r = self.slots[0]["r"]
+        torch = self.torch
+
+        def frame():
+            with torch.cuda.stream(self.slots[0]["stream"]):
+                r.reset()
+                for _ in range(self.spp):
+                    r.trace()
+                r.flush()
+        frame()
+        r.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            frame()
+        r.synchronize()
+        elapsed = time.perf_counter() - t0
+        return dict(value=float(self.w) * self.h * self.spp * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3, launches_per_step=max(1, r.last_launches),
+                    calls_per_step=self.spp, frame_crc32=self.frame_crc32())
+
     def roofline(self, m, counted):
-        counters, batches = counted
-        cfg = self.config
-        use_tf = cfg == "c3"
-        use_em = cfg.startswith("c5")
-        dense = cfg.startswith("c4")
-        b_sample, events = algorithmic_bytes_per_sample(counters, use_tf, use_em, dense=dense)
-        per_batch = [algorithmic_bytes_per_sample(b, use_tf, use_em, dense=dense)[0] for b in batches]
-        mean_b = sum(per_batch) / len(per_batch)
-        stderr = (sum((x - mean_b) ** 2 for x in per_batch) / max(1, len(per_batch) - 1)) ** 0.5 / len(per_batch) ** 0.5
-        events["oracle_samples"] = int(counters["samples"])
-        events["oracle_spp"] = len(batches)
-        achieved = b_sample * m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tp, tp_file, stale = traffic_profile(cfg, self.w, self.h)               # PMC passes (FETCH_SIZE / WRITE_SIZE), collected separately
-        if tp and "hbm_bytes_per_sample" in tp:
-            traffic = tp["hbm_bytes_per_sample"] * m["samples_per_launch"]
-            traffic_src = {"from_profile": tp_file, "stale": bool(stale),
-                           "note": "not measured by this run: rocprofv3 --pmc passes of %s (bytes = 2 x FETCH_SIZE + WRITE_SIZE: profiles/r3j_fetch_size_calibration.txt), scaled to this launch's samples%s" % (
-                               tp.get("command", "?"), "; the kernel sources have changed since that profile was taken" if stale else "")}
-        variant = "dense" if dense else ("emission" if use_em else "brick")
-        kernel_rate = m["samples_per_launch"] / (m["kernel_ms"] * 1e-3)         # samples/s of the kernel alone
-        # The resource that binds: vector-instruction issue at partial lane utilisation, not HBM.  VALU wave-instructions per sample come
-        # from the PMC profile (SQ_INSTS_VALU of the same kernel; `stale` when the kernel sources changed since), the rate is this run's: achieved =
-        # wave-instructions/s the kernel issued, peak = what 1024 SIMDs issue at 2.4 GHz when an instruction occupies a SIMD for 1.8 cycles.
-        issue = None
-        if tp and "per_sample" in tp and "valu" in tp["per_sample"]:
-            valu = tp["per_sample"]["valu"]
-            peak_issue = SIMDS * CLOCK_GHZ / CYCLES_PER_VALU_OP                 # G wave-instructions/s
-            ach_issue = valu * kernel_rate / 1e9
-            issue = {"bound": "valu_issue", "achieved": ach_issue, "peak": peak_issue, "unit": "G wave-instructions/s", "frac": ach_issue / peak_issue,
-                     "valu_wave_instructions_per_sample": valu, "lane_utilisation": tp.get("lane_utilisation"), "hbm_frac": achieved / HBM_PEAK_GBS,
-                     "cycles_per_valu_op": CYCLES_PER_VALU_OP, "cycles_source": "profiles/r2_valu_issue_rate.txt", "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
-                     "counts_source": tp_file, "stale": bool(stale),
-                     "summary": "hbm %.2f / issue %.2f / lanes %s" % (achieved / HBM_PEAK_GBS, ach_issue / peak_issue, ("%.2f" % tp["lane_utilisation"]) if tp.get("lane_utilisation") else "?")}
-        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "pathtrace_kernel<TraceCfg<tf=%s, %s>, false>" % ("true" if use_tf else "false", variant),
-                "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "samples_per_launch": m["samples_per_launch"],
-                "bytes_per_sample": b_sample, "bytes_per_sample_stderr": stderr, "events_per_sample": events, "roofline_issue": issue,
-                "note": "bytes = algorithmic (SURVEY 8d), event counts from %d oracle samples per pixel (stderr over the batches); the kernel is limited by its work per sample (vector instructions and fully divergent vector-memory accesses at ~74 %% lane utilisation: roofline_issue), not by HBM bandwidth nor by where its gathers hit (DESIGN.md 5, profiles/r3c_whatif_voxel_taps_in_cache.txt): 2-9 useful bytes per 128-byte line" % len(batches)}
+        return roofline_of(self.config, self.w, self.h, self.spp, m, counted)
+
+
+def roofline_of(config, w, h, spp, m, counted):
+    """The contract's roofline object for one configuration: m = measure()'s dict (kernel_ms, launches, samples_per_launch), counted = event_counters()."""
+    counters, batches = counted
+    cfg = config
+    use_tf = cfg == "c3"
+    use_em = cfg.startswith("c5")
+    dense = cfg.startswith("c4")
+    b_sample, events = algorithmic_bytes_per_sample(counters, use_tf, use_em, dense=dense)
+    per_batch = [algorithmic_bytes_per_sample(b, use_tf, use_em, dense=dense)[0] for b in batches]
+    mean_b = sum(per_batch) / len(per_batch)
+    stderr = (sum((x - mean_b) ** 2 for x in per_batch) / max(1, len(per_batch) - 1)) ** 0.5 / len(per_batch) ** 0.5
+    events["oracle_samples"] = int(counters["samples"])
+    events["oracle_spp"] = len(batches)
+    achieved = b_sample * m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    tp, tp_file, stale = traffic_profile(cfg, w, h)               # PMC passes (FETCH_SIZE / WRITE_SIZE), collected separately
+    if tp and "hbm_bytes_per_sample" in tp:
+        traffic = tp["hbm_bytes_per_sample"] * m["samples_per_launch"]
+        traffic_src = {"from_profile": tp_file, "stale": bool(stale),
+                       "note": "not measured by this run: rocprofv3 --pmc passes of %s (bytes = 2 x FETCH_SIZE + WRITE_SIZE: profiles/r3j_fetch_size_calibration.txt), scaled to this launch's samples%s" % (
+                           tp.get("command", "?"), "; the kernel sources have changed since that profile was taken" if stale else "")}
+    variant = "dense" if dense else ("emission" if use_em else "brick")
+    kernel_rate = m["samples_per_launch"] / (m["kernel_ms"] * 1e-3)         # samples/s of the kernel alone
+    # The resource that binds (DESIGN.md 5): vector-instruction issue at partial lane utilisation, not HBM.  VALU wave-instructions per sample come
+    # from the PMC profile (SQ_INSTS_VALU of the same kernel; `stale` when the kernel sources changed since), the rate is this run's: achieved =
+    # wave-instructions/s the kernel issued, peak = what 1024 SIMDs issue at 2.4 GHz when an instruction occupies a SIMD for 1.8 cycles.
+    issue = None
+    if tp and "per_sample" in tp and "valu" in tp["per_sample"]:
+        valu = tp["per_sample"]["valu"]
+        peak_issue = SIMDS * CLOCK_GHZ / CYCLES_PER_VALU_OP                 # G wave-instructions/s
+        ach_issue = valu * kernel_rate / 1e9
+        issue = {"bound": "valu_issue", "achieved": ach_issue, "peak": peak_issue, "unit": "G wave-instructions/s", "frac": ach_issue / peak_issue,
+                 "valu_wave_instructions_per_sample": valu, "lane_utilisation": tp.get("lane_utilisation"), "hbm_frac": achieved / HBM_PEAK_GBS,
+                 "cycles_per_valu_op": CYCLES_PER_VALU_OP, "cycles_source": "profiles/r2_valu_issue_rate.txt", "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
+                 "counts_source": tp_file, "stale": bool(stale),
+                 "summary": "hbm %.2f / issue %.2f / lanes %s" % (achieved / HBM_PEAK_GBS, ach_issue / peak_issue, ("%.2f" % tp["lane_utilisation"]) if tp.get("lane_utilisation") else "?")}
+    # the same with SURVEY 8d's FUSED framebuffer figure (B_fb = 16 B per pixel per frame = 16 / spp per sample) instead of the 32 B per sample this
+    # build's sample pool moves (16 B written by the path-tracing kernel, 16 B read back by the ordered accumulation pass): the pool is the build's own
+    # staging, so this is the fraction to hold against a renderer that accumulates in registers
+    b_fused = b_sample - 32.0 + 16.0 / max(1, spp)
+    achieved_fused = b_fused * m["samples_per_launch"] / (m["kernel_ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "frac_fused_fb": achieved_fused / HBM_PEAK_GBS, "bytes_per_sample_fused_fb": b_fused,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "pathtrace_kernel<TraceCfg<tf=%s, %s>, false>" % ("true" if use_tf else "false", variant),
+            "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "samples_per_launch": m["samples_per_launch"],
+            "bytes_per_sample": b_sample, "bytes_per_sample_stderr": stderr, "events_per_sample": events, "roofline_issue": issue,
+            "note": "bytes = algorithmic (SURVEY 8d), event counts from %d oracle samples per pixel (stderr over the batches); the kernel is limited by its work per sample (vector instructions and fully divergent vector-memory accesses at ~74 %% lane utilisation: roofline_issue), not by HBM bandwidth nor by where its gathers hit (DESIGN.md 5, profiles/r3c_whatif_voxel_taps_in_cache.txt): 2-9 useful bytes per 128-byte line" % len(batches)}
 
 
 def workload_name(config, w, h, spp):
@@ -381,9 +424,95 @@ def workload_name(config, w, h, spp):
     return "BASELINE configs[%d] '%s': %s%s%s, %dx%d, %d spp, seed 42, fov 40" % (CONFIG_INDEX.get(config[:2], -1), config, what, size, tf, w, h, spp)
 
 
+def run_sharded(args):
+    """--host sharded: the product's own multi-GPU host.  ONE process; volren_amd.ShardedRenderer = vr_sharded_* (csrc/sharded.cpp): a renderer per device,
+    the 16x16 tiles dealt diagonally, every part renders its tiles on its own stream, ONE grouped ncclAllGather per frame (librccl, opened at run time;
+    device-to-device copies when parts share a device), part 0 holds the frame.  Same step, same timing brackets, same line as the torch.distributed host."""
+    import zlib
+    import scenes
+    import volren_amd
+    w, h, spp = args.width, args.height, args.spp
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit("--devices names %d parts, --gpus %d" % (len(devices), args.gpus))
+    if volren_amd.load().vr_device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device: the renderer has no CPU path")
+    s = volren_amd.ShardedRenderer(w, h, devices)
+    s.each(lambda p: scenes.configure(p, args.config, False))
+    pool_mb = os.environ.get("VOLREN_SAMPLE_POOL_MB")
+    for p in s.parts:
+        p.launch_target_ms = 0                                  # as Bench: a frame is split by the sample pool alone, no probe launch
+        if pool_mb:
+            p.sample_pool_mb = int(pool_mb)
+
+    def step():
+        s.reset()
+        s.render(spp, sync=False)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    s.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    s.synchronize()
+    elapsed = time.perf_counter() - t0
+    samples = float(w) * h * spp
+    parts = []
+    for i, p in enumerate(s.parts):
+        launches = p.last_launches
+        pt = p.last_pathtrace_ms()
+        parts.append({"device": devices[i], "launches": launches, "pathtrace_ms": pt, "frame_gpu_ms": p.last_kernel_ms()})
+    n_tiles = ((w + 15) // 16) * ((h + 15) // 16)
+    own0 = sum(1 for t in range(n_tiles) if ((t % ((w + 15) // 16)) + (t // ((w + 15) // 16))) % len(devices) == 0)
+    l0 = max(1, parts[0]["launches"])
+    m = dict(value=samples * args.steps / elapsed / 1e6, ms_per_step=elapsed / args.steps * 1e3, kernel_ms=(parts[0]["pathtrace_ms"] or parts[0]["frame_gpu_ms"]) / l0,
+             launches=l0, samples_per_launch=(own0 * 256.0 * spp if len(devices) > 1 else samples) / l0)
+    crc = zlib.crc32(s.framebuffer().tobytes()) & 0xFFFFFFFF
+    transport = s.transport
+    s.close()
+    out = {
+        "metric": "Msamples/s (pixels x spp / s), volume path tracing",
+        "value": m["value"], "unit": "Msamples/s", "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "host": "sharded", "transport": transport,
+        "devices": devices, "distinct_devices": len(set(devices)),
+        "frame_crc32": crc, "vs_baseline": None, "dtype": "f32",
+        "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if args.config == "c3" else "")),
+        "config": {"workload": workload_name(args.config, w, h, spp),
+                   "parallelism": "ONE process, ShardedRenderer (vr_sharded_*): tiles16x16 diagonal-interleaved over %d part(s) on devices %s, 1 gather/frame by %s" % (len(devices), devices, transport)},
+        "rccl_ranks": len(devices) if transport == "rccl" else 0, "parts": parts,
+        "roofline": roofline_of(args.config, w, h, spp, m, event_counters(args.config, aspect=w / h)) if args.cpu_budget > 0 else None,
+    }
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def sharded_leg(args, world):
+    """Rank 0 of the torch.distributed run, after the ranks have left the GPUs: the product's one-process host on the same N devices, as a CHILD process
+    (a crash or hang in it must not lose the headline line).  Returns the child's line, or {"error": ...}."""
+    try:
+        import torch
+        n_dev = torch.cuda.device_count()
+        devices = list(range(world)) if n_dev >= world else [0] * world        # (a test box has one GPU: logical shards)
+        env = {k: v for k, v in os.environ.items() if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE",
+                                                                 "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "NCCL_ASYNC")))}
+        cmd = [sys.executable, os.path.abspath(__file__), "--host", "sharded", "--gpus", str(world), "--devices", ",".join(str(d) for d in devices), "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--config", args.config, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--cpu-budget", "0"]
+        proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("VOLREN_SHARDED_LEG_TIMEOUT", "240")))
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or not lines:
+            return {"error": "exit %d: %s" % (proc.returncode, (proc.stderr or proc.stdout)[-600:])}
+        return json.loads(lines[-1])
+    except Exception as e:                                     # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
+    if args.host == "sharded":
+        if world_env is not None and int(world_env) > 1:
+            raise SystemExit("--host sharded is ONE process driving all devices: run it without a launcher (python bench.py --gpus N --host sharded)")
+        sys.exit(run_sharded(args))
     if world_env is None and args.gpus > 1:
         sys.exit(spawn_ranks(args))                       # parent: children do the work, rank 0 prints the JSON line
     rank = int(os.environ.get("RANK", "0"))
@@ -449,6 +578,15 @@ def main():
     w, h, spp = args.width, args.height, args.spp
     b = Bench(args.config, w, h, spp, world, rank, local_rank, dist)
     m = b.measure(args.steps, args.warmup)
+    crc = b.frame_crc32() if rank == 0 else None
+    trace_loop = None
+    if world == 1 and dist is None:
+        try:
+            trace_loop = b.measure_trace_loop(args.steps)
+            trace_loop["same_frame"] = bool(trace_loop["frame_crc32"] == crc)
+            trace_loop["ratio_to_value"] = trace_loop["value"] / m["value"]
+        except Exception as e:                                 # noqa: BLE001
+            trace_loop = {"error": str(e)}
 
     out = None
     if rank == 0:
@@ -464,7 +602,10 @@ def main():
             # `value`: K frames one after the other on one stream, for every N; value_pipelined (N > 1): the same frames alternating between two renderers
             # on two streams, the drain of frame i overlapping the start of frame i+1
             "value_pipelined": m["value_pipelined"], "pipelined": False,
-            "frame_crc32": b.frame_crc32(),                    # of the RGBA32F frame on rank 0 after the last step: the same for every N
+            # the reference's protocol, `while (sample < sppx) trace();`: spp x vr_trace + one vr_synchronize per frame (coalesced into fused launches)
+            "value_trace_loop": (trace_loop or {}).get("value"), "trace_loop": trace_loop,
+            "host": "dist",
+            "frame_crc32": crc,                                # of the RGBA32F frame on rank 0 after the last step: the same for every N
             "vs_baseline": None, "dtype": "f32", "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else
                                       "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
             "config": {"workload": workload_name(args.config, w, h, spp),
@@ -518,11 +659,24 @@ def main():
                 del bx
             except Exception as e:                             # noqa: BLE001
                 out["configs"].append({"name": spec, "error": str(e)})
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # N > 1: the product's own multi-GPU host (vr_sharded_*, one process, RCCL through librccl) on the same devices, beside the torch.distributed value.
+        # The ranks have finished their collectives; this process gives its device memory back first.  VOLREN_SHARDED_LEG=0 skips it.
+        if world > 1 and os.environ.get("VOLREN_SHARDED_LEG", "1") != "0":
+            import gc
+            b = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            time.sleep(1.0)                                    # the other ranks are exiting
+            leg = sharded_leg(args, world)
+            out["sharded"] = leg
+            out["value_sharded"] = leg.get("value")
+            if "frame_crc32" in leg:
+                out["sharded_same_frame"] = bool(leg["frame_crc32"] == out["frame_crc32"])
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

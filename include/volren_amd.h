@@ -113,8 +113,17 @@ int vr_scale_and_move_to_unit_cube(vr_renderer* r);
 /* --- the hot path.  vr_trace = RendererOpenGL::trace (src/renderer.cpp:78-145): ONE more sample per pixel.
  *     vr_render = the Python binding's render(spp) loop (src/bindings.cpp:124-132) / the offline loop (src/main.cpp:533-537)
  *     fused into one launch: `spp` more samples per pixel (spp <= 0: up to sppx).  Both are asynchronous on the renderer's
- *     stream; vr_synchronize waits and reports a tripped kernel watchdog as an error. */
+ *     stream; vr_synchronize waits and reports a tripped kernel watchdog as an error.
+ *     The reference's own loop `while (sample < sppx) trace();` runs at vr_render's speed (round 5): a vr_trace records the launch
+ *     inputs it found ("sample" advances by one, invalid state is reported at the call) and consecutive calls that find the same
+ *     bytes are launched TOGETHER -- at the next call of this header that could observe or change the frame (vr_synchronize,
+ *     vr_framebuffer*, vr_draw / vr_display / vr_save_png, vr_render, vr_commit, vr_resize, vr_set_tiles, vr_pack_tiles /
+ *     vr_unpack_tiles, vr_set_stream, vr_last_*_ms, vr_sched_stats), at a vr_trace that finds changed inputs (any vr_set_*
+ *     in between: the recorded samples are launched with the values they were recorded with, as the reference's already issued
+ *     dispatches are), or when a full sub-launch has been recorded.  vr_flush launches what has been recorded without waiting;
+ *     vr_set_int "coalesce_trace" 0 makes every vr_trace its own launch again; vr_get_int "pending_samples" reads the count. */
 int vr_trace(vr_renderer* r);
+int vr_flush(vr_renderer* r);
 int vr_render(vr_renderer* r, int spp);
 int vr_synchronize(vr_renderer* r);
 /* duration of the last path-tracing launch in ms, measured with HIP events on the renderer's stream (waits for it) */

@@ -58,8 +58,17 @@ def test_bench_multirank_frames_equal_the_single_gpu_frame(oracle_crc):
     assert j1["n_gpus"] == 1 and j1["rccl_ranks"] == 1 and j1["dist_backend"] is None
     assert j1["frame_crc32"] == oracle_crc, "N=1 frame differs from the oracle's"
     assert j1["value"] > 0 and j1["value_pipelined"] is None            # one GPU: frames one after the other, nothing else measured
+    # the reference's protocol, spp x vr_trace + one vr_synchronize per frame: ONE fused launch, the same frame
+    tl = j1["trace_loop"]
+    assert j1["value_trace_loop"] == tl["value"] > 0 and tl["same_frame"] and tl["launches_per_step"] == 1 and tl["calls_per_step"] == SPP
+    assert j1["roofline"]["frac_fused_fb"] < j1["roofline"]["frac"]
     for n in (2, 3):
         j = run_bench(n, backend="gloo")
+        # the product's own host (vr_sharded_*, one process) runs as a child once the ranks are done: here as logical shards of device 0
+        leg = j["sharded"]
+        assert "error" not in leg, leg
+        assert leg["host"] == "sharded" and leg["n_gpus"] == n and leg["devices"] == [0] * n and leg["transport"] == "copy"
+        assert leg["frame_crc32"] == oracle_crc and j["sharded_same_frame"] and j["value_sharded"] == leg["value"] > 0
         assert j["n_gpus"] == n and j["rccl_ranks"] == n and j["dist_backend"] == "gloo"
         assert j["value_pipelined"] > 0 and j["scaling"] == "strong"    # N > 1: also the frames pipelined over two renderers / streams
         assert j["frame_crc32"] == oracle_crc, "N=%d frame differs from the N=1 frame" % n
@@ -84,3 +93,19 @@ def test_bench_pipelining_switch(oracle_crc, monkeypatch):
     monkeypatch.setenv("VOLREN_PIPELINE", "1")
     j = run_bench(1)
     assert j["value_pipelined"] > 0 and j["frame_crc32"] == oracle_crc
+
+
+@pytest.mark.timeout(900)
+def test_bench_host_sharded(oracle_crc):
+    """`bench.py --gpus N --host sharded`: the product's multi-GPU host under the bench (verdict r4 #4) -- one process, vr_sharded_*; on a one-GPU box
+    the parts are logical shards (`--devices 0,0,0`, copy transport) and RCCL carries a one-part group (VR_SHARDED_TRANSPORT=rccl)."""
+    j = run_bench(3, extra=["--host", "sharded", "--devices", "0,0,0"])
+    assert j["host"] == "sharded" and j["n_gpus"] == 3 and j["transport"] == "copy" and j["rccl_ranks"] == 0 and j["distinct_devices"] == 1
+    assert j["frame_crc32"] == oracle_crc and j["value"] > 0 and len(j["parts"]) == 3
+    assert all(p["launches"] >= 1 and p["pathtrace_ms"] > 0 for p in j["parts"])
+    os.environ["VR_SHARDED_TRANSPORT"] = "rccl"
+    try:
+        j = run_bench(1, extra=["--host", "sharded"])
+    finally:
+        del os.environ["VR_SHARDED_TRANSPORT"]
+    assert j["transport"] == "rccl" and j["rccl_ranks"] == 1 and j["frame_crc32"] == oracle_crc

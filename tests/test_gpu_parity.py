@@ -199,20 +199,115 @@ def test_zero_samples_and_tiny_frames():
 
 
 def test_trace_protocol_equals_fused_render():
-    """trace() x N (the reference protocol) == render(N) == render(a) + render(b)."""
+    """trace() x N (the reference protocol) == render(N) == render(a) + render(b); consecutive trace() calls are launched together."""
     a = scenes.hip_scene("c1", 48, 48)
-    for _ in range(6):
+    for k in range(6):
         a.trace()
+        assert a.sample == k + 1 and a.pending_samples == k + 1      # recorded, not launched
     a.synchronize()
+    assert a.pending_samples == 0 and a.last_launches == 1           # ONE launch for the six calls
     b = scenes.hip_scene("c1", 48, 48)
     b.render(6)
     c = scenes.hip_scene("c1", 48, 48)
     c.render(2)
     c.render(4)
-    fa, fb, fc = a.framebuffer(), b.framebuffer(), c.framebuffer()
-    assert a.sample == 6 and b.sample == 6 and c.sample == 6
+    d = scenes.hip_scene("c1", 48, 48)                               # round 4's protocol: one launch per call
+    d.coalesce_trace = 0
+    for _ in range(6):
+        d.trace()
+        assert d.pending_samples == 0
+    fa, fb, fc, fd = a.framebuffer(), b.framebuffer(), c.framebuffer(), d.framebuffer()
+    assert a.sample == 6 and b.sample == 6 and c.sample == 6 and d.sample == 6
     assert np.array_equal(_bits(fa), _bits(fb))
     assert np.array_equal(_bits(fa), _bits(fc))
+    assert np.array_equal(_bits(fa), _bits(fd))
+
+
+def test_coalesced_trace_sees_every_change_between_two_calls():
+    """The reference issues a dispatch per trace() (src/renderer.cpp:78-145), so a field changed between two calls applies to the later samples only.
+    Coalesced calls must give the same frame as one launch per call (coalesce_trace = 0) and as the oracle driven the same way -- for changes of
+    plain fields, of the camera, of the environment's strength, of the sample counter, and for a transfer function replaced between two calls."""
+    w, h = 56, 40
+    lut2 = np.array([[0.9, 0.2, 0.1, 0.0], [0.1, 0.8, 0.3, 0.4], [0.2, 0.3, 0.9, 1.0]], np.float32)
+
+    def drive(r, is_oracle):
+        frames = []
+        if is_oracle:                                                 # the oracle's protocol object has render(n) and .fb
+            r.trace = lambda: r.render(1)
+            r.framebuffer = lambda: r.fb
+            set_tf = r.set_transferfunc
+            r.set_transferfunc = lambda lut: set_tf(lut) if lut is not None else (setattr(r, "lut", None), setattr(r, "sample", 0))
+        def step(n):
+            for _ in range(n):
+                r.trace()
+        step(3)
+        r.albedo = [0.5, 0.6, 0.7]; step(2)                           # plain field
+        r.cam_pos = [0.9, 0.2, 1.1]; r.cam_dir = [-0.6, -0.1, -0.75]; step(2)     # camera
+        r.env_strength = 2.0; step(1)                                 # a field of the shared Environment object
+        r.density_scale = float(r.density_scale) * 0.5; step(2)       # majorant table is rebuilt: the recorded samples must not see the new one
+        frames.append(r.framebuffer().copy())                         # an observation flushes
+        step(2)
+        r.sample = 0; step(3)                                         # reset(): the running mean starts over (sample 1 overwrites)
+        frames.append(r.framebuffer().copy())
+        r.set_transferfunc(lut2); r.sample = 0; step(2)               # the LUT's device array is replaced between two calls
+        r.tf_window_left = 0.1; r.tf_window_width = 0.7; step(2)
+        r.set_transferfunc(None); step(1)
+        frames.append(r.framebuffer().copy())
+        return frames
+
+    ref = drive(scenes.oracle_scene("c1", w, h), True)
+    eager = scenes.hip_scene("c1", w, h)
+    eager.coalesce_trace = 0
+    fe = drive(eager, False)
+    lazy = scenes.hip_scene("c1", w, h)
+    fl = drive(lazy, False)
+    for k, (x, y, z) in enumerate(zip(ref, fe, fl)):
+        assert np.array_equal(_bits(y), _bits(z)), "coalesced != one launch per call at observation %d" % k
+        _assert_same(z, x, "trace protocol with changes, observation %d" % k)
+
+
+def test_coalesced_trace_flush_points():
+    """Everything that can observe or replace what recorded samples read launches them first."""
+    w, h = 48, 32
+    ref4 = scenes.oracle_scene("c1", w, h).render(4)
+    r = scenes.hip_scene("c1", w, h)
+    for _ in range(4):
+        r.trace()
+    assert r.pending_samples == 4
+    r.flush(); assert r.pending_samples == 0                         # vr_flush: launched, not waited for
+    _assert_same(r.framebuffer(), ref4, "flush")
+    for probe in ("draw", "last_kernel_ms", "framebuffer_device_ptr", "synchronize", "commit"):
+        r.reset()
+        for _ in range(4):
+            r.trace()
+        assert r.pending_samples == 4
+        getattr(r, probe)()
+        assert r.pending_samples == 0, probe
+        _assert_same(r.framebuffer(), ref4, probe)
+    # set_tiles between two trace() calls: the recorded samples cover the whole frame, the later ones the subset
+    r.reset()
+    r.trace(); r.trace()
+    r.set_tiles([0, 1])
+    assert r.pending_samples == 0
+    r.trace()
+    r.set_tiles([])
+    o = scenes.oracle_scene("c1", w, h)
+    full2 = o.render(2).copy()
+    full3 = o.render(1)
+    fb = r.framebuffer()
+    mask = np.zeros((h, w), bool); mask[0:16, 0:32] = True
+    assert np.array_equal(_bits(fb[mask]), _bits(full3[mask])) and np.array_equal(_bits(fb[~mask]), _bits(full2[~mask]))
+    # a render() after recorded trace() calls continues the same frame; resize drops what was recorded for the old framebuffer
+    r.reset(); r.trace(); r.render(3)
+    _assert_same(r.framebuffer(), ref4, "trace + render")
+    r.trace(); r.resize(32, 32); assert r.pending_samples == 0 and r.sample == 0
+    # a full sub-launch goes out by itself: with a 16 MiB pool this frame holds a few hundred samples per launch
+    r.resize(w, h); r.sample_pool_mb = 16
+    n = 0
+    while r.pending_samples == n and n < 5000:
+        r.trace(); n += 1
+    assert 32 <= n < 5000 and r.pending_samples == 0, n
+    r.synchronize()
 
 
 def test_ragged_resolution_and_tiles():

@@ -82,3 +82,38 @@ def test_cli_gpus_flag_writes_the_same_png(tmp_path):
     assert pngs["g1"] == pngs["plain"] and pngs["g3"] == pngs["plain"] and pngs["d2"] == pngs["plain"]
     bad = subprocess.run(base + ["--gpus", "2", "--devices", "0"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "disagree" in bad.stderr
+
+
+def test_rccl_that_cannot_be_opened_is_an_error_message_not_a_crash():
+    """ADVICE r4 (medium): the failing dlopen used to end in std::string + nullptr inside call_once.  VR_RCCL_LIBRARY names the library to open;
+    a name that does not exist must give a clean error when RCCL is asked for by name, and the copy transport when it is not (two devices)."""
+    def run(devices, env):
+        code = ("import sys\nsys.path.insert(0, %r)\nimport volren_amd\n"
+                "try:\n    s = volren_amd.ShardedRenderer(64, 48, %r)\n    print('TRANSPORT', s.transport)\n"
+                "except volren_amd.VolrenError as e:\n    print('ERROR:', e)\n") % (scenes.ROOT, devices)
+        out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.stdout[-500:], out.stderr[-2000:])
+        return out.stdout
+    env = dict(os.environ, VR_RCCL_LIBRARY="/nonexistent/librccl-not-here.so", VR_SHARDED_TRANSPORT="rccl")
+    text = run([0], env)
+    assert "ERROR:" in text and "could not be opened" in text and "librccl-not-here" in text, text
+    import volren_amd
+    if volren_amd.load().vr_device_count() >= 2:                  # not asked for by name: peer copies take over
+        env.pop("VR_SHARDED_TRANSPORT")
+        assert "TRANSPORT copy" in run([0, 1], env)
+
+
+def test_more_parts_than_tile_diagonals():
+    """8 parts on a 32x32 frame (2x2 tiles, 3 diagonals) -- five parts own no tile.  They must render nothing (an empty tile list means
+    the whole frame to set_tiles) and the frame must still be the unsharded one."""
+    w = h = 32
+    spp = 3
+    ref = scenes.oracle_scene("c1", w, h).render(spp)
+    s = _sharded("c1", w, h, [0] * 8)
+    s.render(spp)
+    assert np.array_equal(_bits(s.framebuffer()), _bits(ref))
+    assert all(p.sample == spp for p in s.parts)
+    idle = [p for i, p in enumerate(s.parts) if i >= 3]
+    assert all(p.last_launches == 0 for p in idle)                # nothing was launched for them
+    assert all(not p.framebuffer().any() for p in idle)
+    s.close()

@@ -144,3 +144,50 @@ def _have_gpu():
         return volren_amd.load().vr_device_count() > 0
     except Exception:
         return False
+
+
+def test_bench_host_sharded_argument_plumbing(monkeypatch):
+    """`bench.py --gpus N --host sharded [--devices ...]` (the product's one-process multi-GPU host under the bench) and the child leg rank 0 runs
+    after a torch.distributed measurement: arguments, device lists and the launcher variables that must NOT reach the child -- no GPU needed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    a = bench.parse_args(["--gpus", "3", "--host", "sharded", "--devices", "0,0,0"])
+    assert a.host == "sharded" and a.devices == "0,0,0" and bench.parse_args([]).host == "dist"
+    # the child leg: one device per former rank (logical shards where the box has fewer devices), launcher variables stripped, errors kept as data
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode, stdout, stderr = 0, 'noise\n{"value": 5.0, "frame_crc32": 7, "host": "sharded"}\n', ""
+        return R()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "4"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "1234"), ("TORCHELASTIC_RUN_ID", "x")):
+        monkeypatch.setenv(k, v)
+    leg = bench.sharded_leg(bench.parse_args(["--gpus", "4", "--steps", "2", "--config", "c3", "--spp", "16"]), 4)
+    assert leg == {"value": 5.0, "frame_crc32": 7, "host": "sharded"}
+    cmd = seen["cmd"]
+    assert cmd[cmd.index("--host") + 1] == "sharded" and cmd[cmd.index("--gpus") + 1] == "4" and cmd[cmd.index("--config") + 1] == "c3" and cmd[cmd.index("--spp") + 1] == "16"
+    assert len(cmd[cmd.index("--devices") + 1].split(",")) == 4
+    assert not any(k in seen["env"] for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+
+    def failing_run(cmd, env=None, **kw):
+        class R:
+            returncode, stdout, stderr = 3, "", "boom"
+        return R()
+    monkeypatch.setattr(bench.subprocess, "run", failing_run)
+    assert "error" in bench.sharded_leg(bench.parse_args(["--gpus", "2"]), 2)
+    monkeypatch.undo()
+    # under a launcher with more than one rank the mode refuses (it is ONE process driving all devices); without a device it says so
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--host", "sharded"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "ONE process" in out.stderr
+    if not _have_gpu():
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--host", "sharded", "--devices", "0,0"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "HIP device" in (out.stderr + out.stdout)

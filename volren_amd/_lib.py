@@ -15,7 +15,7 @@ SYMBOLS = [
     "vr_last_error", "vr_version", "vr_device_count", "vr_create", "vr_destroy", "vr_resize",
     "vr_load_volume", "vr_set_volume_path", "vr_volume_aabb", "vr_volume_minorant_majorant", "vr_load_envmap", "vr_load_transferfunc", "vr_set_volume_dense", "vr_set_volume_dense_f16", "vr_set_volume_brick",
     "vr_set_envmap", "vr_set_transferfunc", "vr_set_int", "vr_get_int", "vr_set_float", "vr_get_float",
-    "vr_commit", "vr_reset", "vr_scale_and_move_to_unit_cube", "vr_trace", "vr_render", "vr_synchronize",
+    "vr_commit", "vr_reset", "vr_scale_and_move_to_unit_cube", "vr_trace", "vr_flush", "vr_render", "vr_synchronize",
     "vr_last_kernel_ms", "vr_last_pathtrace_ms", "vr_framebuffer", "vr_framebuffer_device", "vr_draw", "vr_display", "vr_save_png",
     "vr_set_tiles", "vr_set_stream", "vr_pack_tiles", "vr_unpack_tiles", "vr_get_uniforms", "vr_uniforms_size",
     "vr_volume_add_grid_frame_dense", "vr_volume_update_grid_frame_dense", "vr_volume_n_grid_frames", "vr_impmap_floats", "vr_get_impmap", "vr_test_alloc_cap_mb", "vr_set_sched", "vr_sched_stats", "vr_grid_checksums", "vr_math_probe", "vr_encode_dense_stats", "vr_write_brick_from_dense", "vr_write_dense",

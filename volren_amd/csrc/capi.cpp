@@ -285,6 +285,7 @@ int vr_set_int(vr_renderer* r, const char* name, int v) {
         else if (n == "tonemapping") R.tonemapping = v != 0;
         else if (n == "integrator") R.integrator = v;
         else if (n == "fast_math") R.fast_math = v != 0;
+        else if (n == "coalesce_trace") { R.flush_pending(); R.coalesce_trace = v != 0; }
         else if (n == "tf_float_atlas") R.tf_float_atlas = v != 0;
         else if (n == "gpu_encoder") R.gpu_encoder = v != 0;
         else if (n == "sample_pool_mb") { if (v < 16 || v > 49152) throw std::runtime_error("sample_pool_mb must be in [16, 49152] (item indices of a sub-launch are 32-bit: < 2^32 RGBA32F items)"); R.sample_pool_bytes = (size_t)v << 20; }
@@ -311,6 +312,8 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "tonemapping") *v = R.tonemapping ? 1 : 0;
         else if (n == "integrator") *v = R.integrator;
         else if (n == "fast_math") *v = R.fast_math ? 1 : 0;
+        else if (n == "coalesce_trace") *v = R.coalesce_trace ? 1 : 0;
+        else if (n == "pending_samples") *v = R.pending_samples();
         else if (n == "tf_float_atlas") *v = R.tf_float_atlas ? 1 : 0;
         else if (n == "gpu_encoder") *v = R.gpu_encoder ? 1 : 0;
         else if (n == "sample_pool_mb") *v = (int)(R.sample_pool_bytes >> 20);
@@ -383,6 +386,7 @@ int vr_reset(vr_renderer* r) { NEED(r); return guard([&] { r->impl.reset(); }); 
 int vr_scale_and_move_to_unit_cube(vr_renderer* r) { NEED(r); return guard([&] { r->impl.scale_and_move_to_unit_cube(); }); }
 
 int vr_trace(vr_renderer* r) { NEED(r); return guard([&] { use_device(r); r->impl.trace(); }); }
+int vr_flush(vr_renderer* r) { NEED(r); return guard([&] { use_device(r); r->impl.flush_pending(); }); }
 int vr_render(vr_renderer* r, int spp) { NEED(r); return guard([&] { use_device(r); r->impl.render(spp); }); }
 
 int vr_synchronize(vr_renderer* r) {
@@ -414,7 +418,7 @@ int vr_framebuffer(vr_renderer* r, float* out) {
 int vr_framebuffer_device(vr_renderer* r, void** p) {
     NEED(r);
     if (!p) return fail(VR_ERR_ARG, "null argument");
-    return guard([&] { if (!r->impl.color) throw std::runtime_error("no framebuffer"); *p = r->impl.color->get(); });
+    return guard([&] { if (!r->impl.color) throw std::runtime_error("no framebuffer"); use_device(r); r->impl.flush_pending(); *p = r->impl.color->get(); });
 }
 int vr_draw(vr_renderer* r) { NEED(r); return guard([&] { use_device(r); r->impl.draw(); }); }
 int vr_display(vr_renderer* r, float* out) {
@@ -446,7 +450,7 @@ int vr_set_tiles(vr_renderer* r, const int32_t* ids, int n) {
         r->impl.set_tiles(t);
     });
 }
-int vr_set_stream(vr_renderer* r, void* s) { NEED(r); r->impl.stream = (hipStream_t)s; return VR_OK; }
+int vr_set_stream(vr_renderer* r, void* s) { NEED(r); return guard([&] { use_device(r); r->impl.flush_pending(); r->impl.stream = (hipStream_t)s; }); }
 
 int vr_pack_tiles(vr_renderer* r, const int32_t* ids_dev, int n, void* packed) {
     NEED(r);
@@ -454,6 +458,7 @@ int vr_pack_tiles(vr_renderer* r, const int32_t* ids_dev, int n, void* packed) {
         use_device(r);
         auto& R = r->impl;
         if (!R.color) throw std::runtime_error("no framebuffer");
+        R.flush_pending();
         vr::launch_pack_tiles(R.color->as<float>(), R.resolution.x, R.resolution.y, ids_dev, n, (float*)packed, R.stream);
         VR_HIP(hipGetLastError());
     });
@@ -464,6 +469,7 @@ int vr_unpack_tiles(vr_renderer* r, const int32_t* ids_dev, int n, const void* p
         use_device(r);
         auto& R = r->impl;
         if (!R.color) throw std::runtime_error("no framebuffer");
+        R.flush_pending();
         vr::launch_unpack_tiles((const float*)packed, ids_dev, n, R.color->as<float>(), R.resolution.x, R.resolution.y, R.stream);
         VR_HIP(hipGetLastError());
     });

@@ -13,6 +13,7 @@
 namespace vr {
 
 inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) (void)hipGetLastError();      // the failed call is reported HERE: it must not stay behind as the thread's "last error" and fail the next launch check
     if (e != hipSuccess)
         throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " (" + file + ":" + std::to_string(line) + ")");
 }

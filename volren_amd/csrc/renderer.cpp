@@ -26,6 +26,7 @@ mat3 Camera::view_inverse() const {
 }
 
 RendererHIP::~RendererHIP() {
+    // samples recorded by trace() and never looked at are dropped with the framebuffer
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     for (hipEvent_t e : pt_events_) (void)hipEventDestroy(e);
@@ -50,6 +51,7 @@ void RendererHIP::init() {
 
 void RendererHIP::resize(uint32_t w, uint32_t h) {
     if (w == 0 || h == 0) throw std::runtime_error("RendererHIP::resize: empty framebuffer");
+    pending_n_ = 0; pending_ = LaunchInputs{};                   // samples recorded for the framebuffer that goes: nobody can see them any more
     resolution = { (int)w, (int)h };
     color = make_device_buffer((size_t)w * h * 4 * sizeof(float));
     display.reset();
@@ -64,6 +66,7 @@ static void check_grid_bytes(size_t bytes, const char* what, const int32_t nb[3]
 static size_t brick_records(const BrickGridHIP& g);
 
 void RendererHIP::commit() {
+    flush_pending();                                              // recorded samples read the device grids that are about to be replaced
     rate_samples_per_ms_ = 0.0; rate_pending_samples_ = 0.0;      // a new volume: nothing measured yet
     density_grids.clear();
     emission_grids.clear();
@@ -304,6 +307,7 @@ static void copy3(float* dst, vec3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z
 
 static GridView make_view(const BrickGridHIP& g, bool paired = false) {
     GridView v;
+    memset(&v, 0, sizeof v);                     // padding bytes too: launch inputs are compared byte by byte (LaunchInputs::same_launch_as)
     v.bricks = g.bricks ? g.bricks->as<BrickRec>() : nullptr;
     v.atlas = paired ? g.atlas_paired->as<uint8_t>() : (g.atlas ? g.atlas->as<uint8_t>() : nullptr);
     v.dense = g.dense ? g.dense->as<uint16_t>() : nullptr;
@@ -395,22 +399,18 @@ void RendererHIP::fill_params(SceneParams& P) {
     u.integrator = integrator;
 }
 
-void RendererHIP::update_majorants(const SceneParams& P, BrickGridHIP& g) {
-    MajKey k;
-    k.density_scale = density_scale;
-    k.tf_version = transferfunc ? transferfunc->version : 0;
-    k.wl = transferfunc ? transferfunc->window_left : 0.f;
-    k.ww = transferfunc ? transferfunc->window_width : 0.f;
-    k.frame = volume->grid_frame_counter;
+void RendererHIP::update_majorants(const LaunchInputs& in, BrickGridHIP& g) {
+    const MajKey& k = in.maj;
     if (k.density_scale == maj_key_.density_scale && k.tf_version == maj_key_.tf_version &&
         k.wl == maj_key_.wl && k.ww == maj_key_.ww && k.frame == maj_key_.frame)
         return;
-    launch_majorants(P, g.range_words->as<uint32_t>(), g.nb, g.mip_off, g.n_mips, g.mshift, g.majorant->as<float>(), g.majorant16->as<uint16_t>(), stream);
+    launch_majorants(in.P, g.range_words->as<uint32_t>(), g.nb, g.mip_off, g.n_mips, g.mshift, g.majorant->as<float>(), g.majorant16->as<uint16_t>(), in.stream);
     VR_HIP(hipGetLastError());
     maj_key_ = k;
 }
 
 void RendererHIP::set_tiles(const std::vector<int32_t>& tile_ids) {
+    flush_pending();
     tiles_host_ = tile_ids;
     tiles_dev_.reset();
     if (tile_ids.empty()) return;
@@ -473,18 +473,31 @@ const int32_t* RendererHIP::tile_order(const SceneParams& P, int n_tiles) {
     return order_dev_->as<int32_t>();
 }
 
-void RendererHIP::launch(int n) {
-    if (n <= 0) return;
+bool RendererHIP::LaunchInputs::same_launch_as(const LaunchInputs& o) const {
+    return memcmp(&P, &o.P, sizeof P) == 0 && frame == o.frame && maj.density_scale == o.maj.density_scale && maj.tf_version == o.maj.tf_version &&
+           maj.wl == o.maj.wl && maj.ww == o.maj.ww && memcmp(tuning.thr, o.tuning.thr, sizeof tuning.thr) == 0 && tuning.stats == o.tuning.stats &&
+           tuning.samples_per_unit == o.tuning.samples_per_unit && tuning.blocks_per_cu == o.tuning.blocks_per_cu && order_tiles == o.order_tiles &&
+           launch_target_ms == o.launch_target_ms && fast_math == o.fast_math && sample_pool_bytes == o.sample_pool_bytes && stream == o.stream;
+}
+
+// What a launch reads from the renderer's public, freely mutable state -- taken when trace() / render() is CALLED (the reference issues its dispatch at that
+// point: src/renderer.cpp:78-145), used when the samples are launched.
+void RendererHIP::capture(LaunchInputs& in) {
     if (!color) throw std::runtime_error("RendererHIP::trace: no framebuffer (call resize first)");
     if (integrator == 2 && !transferfunc) throw std::runtime_error("RendererHIP::trace: integrator 2 (direct volume rendering) needs a transfer function");
     if (integrator < 0 || integrator > 3) throw std::runtime_error("RendererHIP::trace: unknown integrator");
     // the tolerance mode is offered where it stays within 1e-3 relative L2 of the reference's kernels; behind a transfer function it does
     // not (a dark image carried by a few bright pixels: 1.9e-3 at 64x48x1024 spp), so it is refused there rather than shipped
     if (fast_math && transferfunc) throw std::runtime_error("RendererHIP::trace: fast_math is not available while a transfer function is bound (it misses the 1e-3 bound there); set fast_math 0");
+    if (!volume || volume->grids.empty() || density_grids.empty()) throw std::runtime_error("RendererHIP::trace: no volume committed");
+    if (volume->grid_frame_counter >= density_grids.size()) throw std::runtime_error("RendererHIP::trace: grid_frame_counter out of range (commit() after changing the volume)");
     {   // transfer-function renders of brick grids read a decoded float atlas (vr_trace.h trilinear_load): build it on first use.
         // 4 bytes per voxel of every brick; when that does not fit, the byte atlas keeps serving (same values either way).
-        BrickGridHIP& g = density_grids.at(volume->grid_frame_counter);
-        if (transferfunc && tf_float_atlas && !g.dense && g.atlas && g.rng && !g.atlas_f32 && !g.atlas_f32_failed) {
+        BrickGridHIP& g = density_grids[volume->grid_frame_counter];
+        const bool build = transferfunc && tf_float_atlas && !g.dense && g.atlas && g.rng && !g.atlas_f32 && !g.atlas_f32_failed;
+        const bool drop = (!transferfunc || !tf_float_atlas) && (g.atlas_f32 || g.atlas_f32_failed);
+        if (build || drop) flush_pending();                          // recorded samples may read the atlas that goes, or need the memory that comes
+        if (build) {
             try {
                 // decoded atlases of the other animation frames stay while they fit: a looping animation behind a transfer function (the reference cycles
                 // its frames) decodes every frame once, not at every frame change (hipFree synchronises the device).  Budget: half of what the device
@@ -505,26 +518,51 @@ void RendererHIP::launch(int n) {
                 std::cerr << "volren_amd: no room for the decoded float atlas (" << (g.atlas->size_bytes() / kBrickBlockBytes * 2048u >> 20) << " MiB): transfer-function taps read the byte atlas (" << e.what() << ")" << std::endl;
             }
         }
-        if (!transferfunc || !tf_float_atlas) { g.atlas_f32.reset(); g.atlas_f32_failed = false; }
+        if (drop) { g.atlas_f32.reset(); g.atlas_f32_failed = false; }
     }
-    SceneParams P;
-    fill_params(P);
-    update_majorants(P, density_grids[volume->grid_frame_counter]);
-    const int tiles_x = (resolution.x + 15) / 16, tiles_y = (resolution.y + 15) / 16;
-    const int n_tiles = tiles_dev_ ? (int)tiles_host_.size() : tiles_x * tiles_y;
-    const bool ordered = order_tiles >= 2 || (order_tiles == 1 && tiles_dev_);
-    const int32_t* tiles = ordered ? tile_order(P, n_tiles) : (tiles_dev_ ? tiles_dev_->as<int32_t>() : nullptr);
-    // per-sample radiances live in a device pool; split the request so that one sub-launch fits the pool
-    const size_t per_sample = pathtrace_pool_floats(tuning, n_tiles, 1) * sizeof(float);
-    int per_launch = (int)std::max<size_t>(1, sample_pool_bytes / per_sample);
+    fill_params(in.P);
+    in.frame = volume->grid_frame_counter;
+    in.maj = MajKey{};
+    in.maj.density_scale = density_scale;
+    in.maj.tf_version = transferfunc ? transferfunc->version : 0;
+    in.maj.wl = transferfunc ? transferfunc->window_left : 0.f;
+    in.maj.ww = transferfunc ? transferfunc->window_width : 0.f;
+    in.maj.frame = in.frame;
+    in.tuning = tuning;
+    in.order_tiles = order_tiles; in.launch_target_ms = launch_target_ms; in.fast_math = fast_math ? 1 : 0;
+    in.sample_pool_bytes = sample_pool_bytes;
+    in.stream = stream;
+    in.env = environment; in.tf = transferfunc;
+    in.keep[0] = environment->envmap; in.keep[1] = environment->impmap; in.keep[2] = environment->cdf;
+    in.keep[3] = transferfunc ? transferfunc->lut_ssbo : DeviceBufferPtr();
+}
+
+// samples of one sub-launch as the sample pool and the 32-bit item indices allow (before any sizing by time)
+int RendererHIP::samples_per_launch(const LaunchInputs& in, int n_tiles) const {
+    const size_t per_sample = pathtrace_pool_floats(in.tuning, n_tiles, 1) * sizeof(float);
+    int per_launch = (int)std::max<size_t>(1, in.sample_pool_bytes / per_sample);
     // item indices inside a sub-launch are 32-bit (WorkUnit::base, C_ITEM): keep n_tiles * 256 * per_launch below 2^32
     per_launch = (int)std::min<size_t>((size_t)per_launch, std::max<size_t>(1, ((size_t)1 << 32) / ((size_t)n_tiles * 256u) - 32u));
     if (per_launch > 32) per_launch -= per_launch % 32;          // whole sample chunks (32 is a multiple of every unit size)
-    per_launch = std::min(per_launch, n);
+    return per_launch;
+}
+
+void RendererHIP::submit(const LaunchInputs& in, int first, int n) {
+    if (n <= 0) return;
+    const SceneParams& P = in.P;
+    hipStream_t stream = in.stream;                              // (shadows the member: the launch goes where it was recorded for)
+    const bool has_tf = P.u.use_tf != 0;
+    update_majorants(in, density_grids.at(in.frame));
+    const int tiles_x = (P.u.resolution[0] + 15) / 16, tiles_y = (P.u.resolution[1] + 15) / 16;
+    const int n_tiles = tiles_dev_ ? (int)tiles_host_.size() : tiles_x * tiles_y;
+    const bool ordered = in.order_tiles >= 2 || (in.order_tiles == 1 && tiles_dev_);
+    const int32_t* tiles = ordered ? tile_order(P, n_tiles) : (tiles_dev_ ? tiles_dev_->as<int32_t>() : nullptr);
+    // per-sample radiances live in a device pool; split the request so that one sub-launch fits the pool
+    int per_launch = std::min(samples_per_launch(in, n_tiles), n);
     for (;;) {                                                   // a pool that does not fit the free HBM: halve the sub-launch, never fail for it
-        const size_t need = pathtrace_pool_floats(tuning, n_tiles, per_launch) * sizeof(float);
+        const size_t need = pathtrace_pool_floats(in.tuning, n_tiles, per_launch) * sizeof(float);
         if (pool_ && pool_->size_bytes() >= need) break;
-        pool_.reset();
+        if (pool_) { VR_HIP(hipStreamSynchronize(stream)); pool_.reset(); }
         try { pool_ = make_device_buffer(need); break; }
         catch (const std::exception&) {
             (void)hipGetLastError();
@@ -538,7 +576,8 @@ void RendererHIP::launch(int n) {
         // test hook: no path may depend on what its cold line held before the path wrote it (tests/test_gpu_parity.py)
         if (const char* e = std::getenv("VR_TEST_POISON_WORKSPACE"); e && *e == '1') VR_HIP(hipMemsetAsync(workspace_->get(), 0xFF, workspace_->size_bytes(), stream));
     }
-    const bool pt_kernel = !(integrator == 3 || (integrator == 2 && transferfunc));      // launch_pathtrace records the events around the path-tracing kernel only
+    const int integ = P.u.integrator;
+    const bool pt_kernel = !(integ == 3 || (integ == 2 && has_tf));      // launch_pathtrace records the events around the path-tracing kernel only
     // Launch sizing by time (round 4): no sub-launch is PLANNED to take longer than launch_target_ms.  The plan uses the rate of this renderer's last
     // finished sub-launch; when there is none for the current settings and the request is large, a short probe launch measures it first (one
     // synchronisation, once per change of settings).  A plan can still be off -- the rate is a property of the scene AND the view -- which costs nothing
@@ -551,19 +590,19 @@ void RendererHIP::launch(int n) {
         mix(&u.bounces, sizeof u.bounces); mix(u.vol_albedo, sizeof u.vol_albedo); mix(&u.vol_phase_g, sizeof u.vol_phase_g); mix(&u.vol_density_scale, sizeof u.vol_density_scale);
         mix(&u.use_tf, sizeof u.use_tf); mix(&u.tf_window_left, sizeof u.tf_window_left); mix(&u.tf_window_width, sizeof u.tf_window_width); mix(&u.integrator, sizeof u.integrator);
         mix(&u.has_emission, sizeof u.has_emission); mix(u.resolution, sizeof u.resolution); mix(u.vol_bb_min, sizeof u.vol_bb_min); mix(u.vol_bb_max, sizeof u.vol_bb_max);
-        const size_t frame = volume->grid_frame_counter; mix(&frame, sizeof frame); mix(&n_tiles, sizeof n_tiles);
-        const uint64_t tfv = transferfunc ? transferfunc->version : 0; mix(&tfv, sizeof tfv);
+        const size_t frame = in.frame; mix(&frame, sizeof frame); mix(&n_tiles, sizeof n_tiles);
+        const uint64_t tfv = in.maj.tf_version; mix(&tfv, sizeof tfv);
         return h ? h : 1ull;
     }();
     auto cap_by_rate = [&](int planned) {
-        if (launch_target_ms <= 0 || rate_samples_per_ms_ <= 0.0) return planned;
-        const double cap = rate_samples_per_ms_ * (double)launch_target_ms / px_samples;
+        if (in.launch_target_ms <= 0 || rate_samples_per_ms_ <= 0.0) return planned;
+        const double cap = rate_samples_per_ms_ * (double)in.launch_target_ms / px_samples;
         int c = cap >= (double)planned ? planned : std::max(1, (int)cap);
         if (c > 32) c -= c % 32;
         return c;
     };
     int probe = 0;
-    if (pt_kernel && launch_target_ms > 0) {
+    if (pt_kernel && in.launch_target_ms > 0) {
         harvest_rate(false);
         const bool known = rate_samples_per_ms_ > 0.0 && rate_key_ == key;
         if (!known && px_samples * (double)std::min(per_launch, n) > (double)(1u << 26)) {
@@ -584,7 +623,7 @@ void RendererHIP::launch(int n) {
             eb = pt_events_[pt_events_used_]; ee = pt_events_[pt_events_used_ + 1];
             pt_events_used_ += 2;
         }
-        launch_pathtrace(tuning, P, color->as<float>(), pool_->as<float>(), workspace_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, sample + 1 + done, m, status_->as<uint32_t>(), stream, fast_math, eb, ee);
+        launch_pathtrace(in.tuning, P, color->as<float>(), pool_->as<float>(), workspace_->as<float>(), status_->as<uint32_t>() + 1, tiles, n_tiles, first + 1 + done, m, status_->as<uint32_t>(), stream, in.fast_math != 0, eb, ee);
         VR_HIP(hipGetLastError());
         done += m;
         if (pt_kernel) { rate_pending_samples_ = px_samples * (double)m; rate_pending_key_ = key; }
@@ -596,7 +635,6 @@ void RendererHIP::launch(int n) {
     }
     VR_HIP(hipEventRecord(ev1_, stream));
     timing_pending_ = true;
-    sample += n;
 }
 
 // rate of the last path-tracing sub-launch that was enqueued, if it has finished (wait: block until it has)
@@ -612,14 +650,46 @@ void RendererHIP::harvest_rate(bool wait) {
     rate_pending_samples_ = 0.0;
 }
 
-void RendererHIP::trace() { launch(1); }
+// One more sample (src/renderer.cpp:78-145).  The reference issues one dispatch per call; here a call records its launch inputs and consecutive calls that
+// record the same bytes are launched together (renderer.h).  What a caller can observe is unchanged: `sample` advances by one per call, invalid
+// state throws at the call, and every way of looking at the frame launches the recorded samples first -- with the values they were recorded with.
+void RendererHIP::trace() {
+    if (!coalesce_trace) { flush_pending(); LaunchInputs in; capture(in); submit(in, sample, 1); sample += 1; return; }
+    LaunchInputs now;
+    capture(now);
+    if (pending_n_ > 0 && (sample != pending_first_ + pending_n_ || !now.same_launch_as(pending_))) flush_pending();
+    if (pending_n_ == 0) {
+        pending_ = std::move(now);
+        pending_first_ = sample;
+        const int n_tiles = tiles_dev_ ? (int)tiles_host_.size() : ((resolution.x + 15) / 16) * ((resolution.y + 15) / 16);
+        pending_cap_ = samples_per_launch(pending_, n_tiles);      // a full sub-launch goes out at once: the GPU works while the caller keeps calling
+    }
+    ++pending_n_;
+    ++sample;
+    if (pending_n_ >= pending_cap_) flush_pending();
+}
+
+void RendererHIP::flush_pending() {
+    if (pending_n_ <= 0) return;
+    const int n = pending_n_, first = pending_first_;
+    pending_n_ = 0;                                              // (first: submit may throw, and must not be retried with half of it enqueued)
+    LaunchInputs in = std::move(pending_);
+    pending_ = LaunchInputs{};
+    submit(in, first, n);
+}
 
 void RendererHIP::render(int n) {
+    flush_pending();
     if (n <= 0) n = sppx - sample;
-    launch(n);
+    if (n <= 0) return;
+    LaunchInputs in;
+    capture(in);
+    submit(in, sample, n);
+    sample += n;
 }
 
 void RendererHIP::draw() {
+    flush_pending();
     if (!color) return;
     if (!display || display->size_bytes() != color->size_bytes()) display = make_device_buffer(color->size_bytes());
     VR_HIP(hipMemcpyAsync(display->get(), color->get(), color->size_bytes(), hipMemcpyDeviceToDevice, stream));
@@ -630,6 +700,7 @@ void RendererHIP::draw() {
 }
 
 double RendererHIP::last_kernel_ms() {
+    flush_pending();
     if (timing_pending_) {
         VR_HIP(hipEventSynchronize(ev1_));
         float ms = 0.f;
@@ -647,6 +718,7 @@ double RendererHIP::last_kernel_ms() {
 double RendererHIP::last_pathtrace_ms() { (void)last_kernel_ms(); return last_pathtrace_ms_; }
 
 void RendererHIP::sched_stats(bool enable, unsigned long long out[32]) {
+    flush_pending();
     if (out) {
         for (int i = 0; i < 32; ++i) out[i] = 0ull;
         if (stats_) { VR_HIP(hipStreamSynchronize(stream)); stats_->download(out, 32 * sizeof(unsigned long long), stream); }
@@ -662,6 +734,7 @@ void RendererHIP::sched_stats(bool enable, unsigned long long out[32]) {
 
 void RendererHIP::wave_timeline(unsigned long long* out, size_t n_words) {
     if (!stats_) throw std::runtime_error("wave_timeline: statistics are not enabled");
+    flush_pending();
     VR_HIP(hipStreamSynchronize(stream));
     const size_t have = stats_->size_bytes() / sizeof(unsigned long long) - 32;
     std::vector<unsigned long long> all(32 + have);
@@ -669,10 +742,11 @@ void RendererHIP::wave_timeline(unsigned long long* out, size_t n_words) {
     for (size_t i = 0; i < n_words; ++i) out[i] = i < have ? all[32 + i] : 0ull;
 }
 
-void RendererHIP::synchronize() const { VR_HIP(hipStreamSynchronize(stream)); }
+void RendererHIP::synchronize() { flush_pending(); VR_HIP(hipStreamSynchronize(stream)); }
 
-void RendererHIP::download(float* rgba) const {
+void RendererHIP::download(float* rgba) {
     if (!color) throw std::runtime_error("RendererHIP::download: no framebuffer");
+    flush_pending();
     color->download(rgba, color->size_bytes(), stream);
 }
 void RendererHIP::download_display(float* rgba) const {
@@ -683,6 +757,7 @@ void RendererHIP::download_display(float* rgba) const {
 uint32_t RendererHIP::watchdog_status() {
     // bit 0: a wavefront gave up (iteration / shader-clock budget), bit 1: a path ended in an impossible state.
     // Read-and-clear, so that one bad launch does not poison the renderer.
+    flush_pending();
     uint32_t s = 0;
     status_->download(&s, sizeof s, stream);
     if (s != 0) {

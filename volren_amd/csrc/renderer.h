@@ -3,7 +3,12 @@
 // trace() once per sample, result = running mean in `color`, RGBA32F, row 0 at the bottom).  Differences that
 // are visible to a caller are additions only:
 //   * render(spp): all remaining samples in ONE fused launch (what bindings.cpp:124-132 loops over trace());
-//     trace() itself still advances by exactly one sample,
+//   * trace() still advances `sample` by exactly one, but consecutive trace() calls on an unchanged scene are COALESCED
+//     (round 5): the call records what it would launch -- a byte snapshot of every launch input -- and a following
+//     trace() that finds the same bytes only adds to a count; the samples go out as ONE fused launch at the next
+//     point where anyone could observe or change the frame (flush_pending()).  The reference's loop
+//     `while (sample < sppx) trace();` (src/main.cpp:533-537, src/bindings.cpp:124-132) therefore runs at render(n)
+//     speed, with the same bits,
 //   * the camera and the resolution are explicit members instead of cppgl globals
 //     (current_camera(), Context::resolution(): renderer.cpp:47,93-95,137),
 //   * set_tiles(): restrict a renderer to a subset of 16x16 framebuffer tiles (multi-GPU sharding).
@@ -132,10 +137,19 @@ struct RendererHIP {
 
     void set_tiles(const std::vector<int32_t>& tile_ids);     // empty = whole frame
     void fill_params(SceneParams& P);                          // renderer.cpp:88-138
-    void download(float* rgba) const;                          // color -> host
+    void download(float* rgba);                                // color -> host
     void download_display(float* rgba) const;
-    void synchronize() const;
-    double last_kernel_ms();                                    // HIP-event time of the last trace()/render(): all sub-launches, path tracing + accumulation (waits for it)
+    void synchronize();
+    // Launches the samples that coalesced trace() calls have recorded (no-op without any).  Every member function that reads or replaces the
+    // framebuffer, the device grids, the tile set or the timing state calls it first (render, draw, download, synchronize, commit, resize,
+    // set_tiles, last_*_ms, sched_stats, watchdog_status, ...); a caller that reads `color` through its raw device pointer calls it itself
+    // (the C ABI does: vr_framebuffer_device, vr_pack_tiles, vr_unpack_tiles, vr_set_stream).  Changes of PUBLIC FIELDS between two trace()
+    // calls need no flush by the caller: the next trace() sees bytes that differ from the recorded ones and launches the recorded samples first,
+    // with the values they were recorded with.
+    void flush_pending();
+    int pending_samples() const { return pending_n_; }         // samples recorded by trace() and not launched yet
+    bool coalesce_trace = true;                                // false: every trace() is its own launch (round 4's behaviour; A/B and tests)
+    double last_kernel_ms();                                    // HIP-event time of the last launch (a render(), or the trace() calls coalesced into one): all sub-launches, path tracing + accumulation (waits for it)
     double last_pathtrace_ms();                                 // HIP-event time of the path-tracing kernel alone, summed over the sub-launches of the last trace()/render()
                                                                 // (0 when that call launched none: integrators 2 / 3)
     void sched_stats(bool enable, unsigned long long out[32]);
@@ -144,8 +158,30 @@ struct RendererHIP {
     ~RendererHIP();
 
 private:
-    void update_majorants(const SceneParams& P, BrickGridHIP& g);
-    void launch(int n);
+    // majorant cache key
+    struct MajKey { float density_scale = -1.f; uint64_t tf_version = ~0ull; float wl = 0, ww = 0; size_t frame = ~(size_t)0; };   // tf_version: TransferFunction::version (unique per upload), 0 = no LUT
+    // Everything a launch reads from the renderer's mutable state, as one trace()/render() call found it.  `P` is zero-filled before it is written
+    // (fill_params), so two snapshots are compared byte by byte; the handles keep alive what P points into (a caller may replace the environment or
+    // re-upload the LUT between two trace() calls: the recorded samples still see the old arrays, as the reference's already issued dispatches do).
+    struct LaunchInputs {
+        SceneParams P;
+        MajKey maj;
+        size_t frame = 0;
+        PathtraceTuning tuning;
+        int order_tiles = 0, launch_target_ms = 0, fast_math = 0;
+        size_t sample_pool_bytes = 0;
+        hipStream_t stream = nullptr;
+        std::shared_ptr<Environment> env;
+        std::shared_ptr<TransferFunction> tf;
+        DeviceBufferPtr keep[4];               // envmap, impmap, env_cdf, lut
+        bool same_launch_as(const LaunchInputs& o) const;
+    };
+    void capture(LaunchInputs& in);            // validates, builds the decoded float atlas when a LUT needs it, fills `in` from the current fields
+    void submit(const LaunchInputs& in, int first, int n);      // samples first+1 .. first+n
+    int samples_per_launch(const LaunchInputs& in, int n_tiles) const;
+    LaunchInputs pending_;
+    int pending_n_ = 0, pending_first_ = 0, pending_cap_ = 0;
+    void update_majorants(const LaunchInputs& in, BrickGridHIP& g);
     std::vector<int32_t> tiles_host_;
     DeviceBufferPtr tiles_dev_;
     // the launch's own order of those tiles: the costliest first (launch(): tile_order)
@@ -166,8 +202,7 @@ private:
     uint64_t rate_key_ = 0, rate_pending_key_ = 0;
     double rate_pending_samples_ = 0.0;               // samples of the last sub-launch enqueued (its events: the last pair of pt_events_)
     void harvest_rate(bool wait);
-    // majorant cache key
-    struct MajKey { float density_scale = -1.f; uint64_t tf_version = ~0ull; float wl = 0, ww = 0; size_t frame = ~(size_t)0; } maj_key_;   // tf_version: TransferFunction::version (unique per upload), 0 = no LUT
+    MajKey maj_key_;
 };
 
 using Renderer = RendererHIP;

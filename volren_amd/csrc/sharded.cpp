@@ -7,8 +7,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <exception>
 #include <mutex>
 #include <set>
+#include <thread>
 
 #include "vr_device.h"
 
@@ -39,11 +41,18 @@ Rccl& rccl() {
     static Rccl R;
     static std::once_flag once;
     std::call_once(once, [] {
+        // VR_RCCL_LIBRARY names the library to open instead of the usual candidates (a site's own build; the tests use it to take RCCL away)
+        const char* override_name = std::getenv("VR_RCCL_LIBRARY");
+        std::string why;
         for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+            if (override_name && *override_name) name = override_name;
             R.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (R.handle) break;
+            const char* e = dlerror();                      // ONE call: it returns the message and clears it
+            if (why.empty()) why = e ? e : "?";
+            if (override_name && *override_name) break;
         }
-        if (!R.handle) { R.error = std::string("librccl.so.1 could not be opened: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!R.handle) { R.error = std::string(override_name && *override_name ? override_name : "librccl.so.1") + " could not be opened: " + why; return; }
         auto sym = [&](const char* n) { void* p = dlsym(R.handle, n); if (!p && R.error.empty()) R.error = std::string("librccl lacks ") + n; return p; };
         R.CommInitAll = reinterpret_cast<decltype(R.CommInitAll)>(sym("ncclCommInitAll"));
         R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
@@ -57,6 +66,13 @@ Rccl& rccl() {
 void rccl_check(ncclResult_t r, const char* what) {
     if (r != ncclSuccess) throw std::runtime_error(std::string("RCCL error: ") + rccl().GetErrorString(r) + " in " + what);
 }
+// ncclGroupStart ... ncclGroupEnd, closed on every way out: a group left open would swallow the next RCCL call of this thread
+struct RcclGroup {
+    bool open = false;
+    RcclGroup() { rccl_check(rccl().GroupStart(), "ncclGroupStart"); open = true; }
+    void end() { open = false; rccl_check(rccl().GroupEnd(), "ncclGroupEnd"); }
+    ~RcclGroup() { if (open) (void)rccl().GroupEnd(); }
+};
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -77,10 +93,14 @@ ShardedRenderer::ShardedRenderer(const std::vector<RendererHIP*>& parts, const s
     else if (forced == "copy" || distinct.size() != devices_.size()) transport_ = "copy";
     else transport_ = "rccl";
     buf_.resize(parts_.size());
+    prev_streams_.resize(parts_.size(), nullptr);
+    try {
     for (size_t i = 0; i < parts_.size(); ++i) {
         VR_HIP(hipSetDevice(devices_[i]));
         VR_HIP(hipStreamCreateWithFlags(&buf_[i].stream, hipStreamNonBlocking));
         VR_HIP(hipEventCreateWithFlags(&buf_[i].packed_ready, hipEventDisableTiming));
+        parts_[i]->flush_pending();
+        prev_streams_[i] = parts_[i]->stream;
         parts_[i]->stream = buf_[i].stream;
     }
     if (transport_ == "rccl") {
@@ -98,22 +118,37 @@ ShardedRenderer::ShardedRenderer(const std::vector<RendererHIP*>& parts, const s
             transport_ = "copy";
         }
     }
+    } catch (...) {                                   // the destructor does not run for a constructor that throws: give everything back here
+        release();
+        throw;
+    }
 }
 
-ShardedRenderer::~ShardedRenderer() {
+// streams, events, buffers and communicators of this object; the parts get the streams back that they had before
+void ShardedRenderer::release() {
     for (size_t i = 0; i < parts_.size(); ++i) {
         (void)hipSetDevice(devices_[i]);
         if (buf_[i].stream) (void)hipStreamSynchronize(buf_[i].stream);
     }
     for (void* c : comms_) (void)rccl().CommDestroy((ncclComm_t)c);
+    comms_.clear();
     for (size_t i = 0; i < parts_.size(); ++i) {
         (void)hipSetDevice(devices_[i]);
-        if (parts_[i]->stream == buf_[i].stream) parts_[i]->stream = nullptr;
+        if (buf_[i].stream && parts_[i]->stream == buf_[i].stream) parts_[i]->stream = prev_streams_[i];
         buf_[i].pack_ids.reset(); buf_[i].packed.reset(); buf_[i].gathered.reset();
         if (i == 0) unpack_ids_.reset();
         if (buf_[i].packed_ready) (void)hipEventDestroy(buf_[i].packed_ready);
         if (buf_[i].stream) (void)hipStreamDestroy(buf_[i].stream);
+        buf_[i].packed_ready = nullptr; buf_[i].stream = nullptr;
     }
+}
+
+ShardedRenderer::~ShardedRenderer() {
+    for (size_t i = 0; i < parts_.size(); ++i) {
+        (void)hipSetDevice(devices_[i]);
+        try { parts_[i]->flush_pending(); } catch (...) { }       // recorded trace() calls go out on the stream that is about to be destroyed, or not at all
+    }
+    release();
 }
 
 void ShardedRenderer::setup(int width, int height) {
@@ -132,6 +167,7 @@ void ShardedRenderer::setup(int width, int height) {
     for (size_t i = 0; i < n; ++i) {
         VR_HIP(hipSetDevice(devices_[i]));
         parts_[i]->set_tiles(lists[i]);
+        buf_[i].n_own = (int)lists[i].size();        // 0 (more parts than tile diagonals): the part renders nothing -- an empty list would mean the WHOLE frame to set_tiles
         // pack list: own tiles, padded by repeating the last one (any valid tile: its slot is ignored on unpack)
         std::vector<int32_t> pack(lists[i]);
         pack.resize((size_t)n_max_, lists[i].empty() ? 0 : lists[i].back());
@@ -161,24 +197,36 @@ void ShardedRenderer::render(int spp) {
     if (n_samples <= 0) return;
     const size_t n = parts_.size();
     const size_t count = (size_t)n_max_ * 256u * 4u;             // floats a part contributes
-    for (size_t i = 0; i < n; ++i) {                             // every part: all samples of its tiles, then its compact tile buffer
+    // Every part: all samples of its tiles, then its compact tile buffer -- issued from one host thread per part.  A part's first render() on new settings
+    // waits for its probe launch (RendererHIP::submit, launch_target_ms); issued one after the other the parts' first frames ran staggered (round 4).
+    auto issue = [&](size_t i) {
         VR_HIP(hipSetDevice(devices_[i]));
         RendererHIP& p = *parts_[i];
         if (p.stream != buf_[i].stream) throw std::runtime_error("ShardedRenderer::render: a part's stream was changed behind the sharded renderer");
-        p.render(n_samples);
-        if (transport_ == "none") continue;
+        if (transport_ == "none" || buf_[i].n_own > 0) p.render(n_samples);
+        else { p.flush_pending(); p.sample += n_samples; }        // no tile of its own: nothing to render, the sample count keeps step
+        if (transport_ == "none") return;
         launch_pack_tiles(p.color->as<float>(), width_, height_, buf_[i].pack_ids->as<int32_t>(), n_max_, buf_[i].packed->as<float>(), buf_[i].stream);
         VR_HIP(hipGetLastError());
+    };
+    if (n == 1) issue(0);
+    else {
+        std::vector<std::exception_ptr> errors(n);
+        std::vector<std::thread> threads;
+        for (size_t i = 1; i < n; ++i) threads.emplace_back([&, i] { try { issue(i); } catch (...) { errors[i] = std::current_exception(); } });
+        try { issue(0); } catch (...) { errors[0] = std::current_exception(); }
+        for (std::thread& t : threads) t.join();
+        for (const std::exception_ptr& e : errors) if (e) std::rethrow_exception(e);
     }
     if (transport_ == "none") return;
     if (transport_ == "rccl") {
         Rccl& R = rccl();
-        rccl_check(R.GroupStart(), "ncclGroupStart");
+        RcclGroup group;
         for (size_t i = 0; i < n; ++i) {
             VR_HIP(hipSetDevice(devices_[i]));
             rccl_check(R.AllGather(buf_[i].packed->get(), buf_[i].gathered->get(), count, ncclFloat, (ncclComm_t)comms_[i], buf_[i].stream), "ncclAllGather");
         }
-        rccl_check(R.GroupEnd(), "ncclGroupEnd");
+        group.end();
     } else {
         // logical shards of one device (or VR_SHARDED_TRANSPORT=copy): every part copies its buffer into part 0's gathered buffer on its
         // own stream, and part 0's stream waits for all of them.  The copies of frame k+1 must not overtake part 0's unpack of frame k,

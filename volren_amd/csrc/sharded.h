@@ -41,14 +41,17 @@ struct ShardedRenderer {
         for (size_t i = 0; i < parts_.size(); ++i) { VR_HIP(hipSetDevice(devices_[i])); fn(*parts_[i], i); }
     }
     void reset();                         // every part: sample = 0
-    // `spp` more samples per pixel (<= 0: up to sppx): every part renders its tiles (asynchronously, its own stream), then the gather;
-    // returns when everything is enqueued.  The whole frame is in part(0).color once synchronize() returns.
+    // `spp` more samples per pixel (<= 0: up to sppx): every part renders its tiles (asynchronously, its own stream; issued from one host thread
+    // per part), then the gather; returns when everything is enqueued -- the first frame on new settings after every part's probe launch has been
+    // waited for (launch_target_ms; all parts at once, set the parts' launch_target_ms to 0 to have none).  The whole frame is in part(0).color once
+    // synchronize() returns.  More parts than the frame has tile diagonals: the surplus parts own no tile and render nothing.
     void render(int spp = 0);
     void synchronize();                   // waits for all parts; throws if a kernel watchdog tripped
     const std::string& transport() const { return transport_; }      // "rccl" | "copy" | "none" (one part, nothing to exchange)
 
 private:
     void setup(int width, int height);   // tile deal + buffers for the current resolution
+    void release();                       // everything this object created; the parts get their previous streams back
     std::vector<RendererHIP*> parts_;
     std::vector<int> devices_;
     std::string transport_;
@@ -56,11 +59,13 @@ private:
     struct PartBuffers {
         hipStream_t stream = nullptr;     // owned
         hipEvent_t packed_ready = nullptr;
+        int n_own = 0;                    // tiles this part renders
         DeviceBufferPtr pack_ids, packed, gathered;      // gathered: rccl transport on every part, copy transport on part 0 only
     };
     std::vector<PartBuffers> buf_;
     DeviceBufferPtr unpack_ids_;          // on part 0's device: every part's tile ids in part order, -1 = padding
     std::vector<void*> comms_;            // ncclComm_t per part (rccl transport)
+    std::vector<hipStream_t> prev_streams_;      // what the parts' `stream` fields held before this object took them
 };
 
 }  // namespace vr

@@ -7,7 +7,7 @@ import numpy as np
 from . import _lib
 
 _INT_FIELDS = ("sample", "sppx", "seed", "bounces", "show_environment", "tonemapping", "integrator", "grid_frame_counter",
-               "sample_pool_mb", "gpu_encoder", "fast_math", "tf_float_atlas", "launch_target_ms", "order_tiles")
+               "sample_pool_mb", "gpu_encoder", "fast_math", "tf_float_atlas", "launch_target_ms", "order_tiles", "coalesce_trace")
 _FLOAT_FIELDS = {"tonemap_exposure": 1, "tonemap_gamma": 1, "albedo": 3, "phase": 1, "density_scale": 1,
                  "emission_scale": 1, "vol_clip_min": 3, "vol_clip_max": 3, "env_strength": 1, "env_transform": 9,
                  "tf_window_left": 1, "tf_window_width": 1, "cam_pos": 3, "cam_dir": 3, "cam_up": 3, "cam_fov": 1,
@@ -49,7 +49,7 @@ class Renderer:
 
     # ---- fields ----
     def __getattr__(self, name):
-        if name in _INT_FIELDS or name in ("n_grid_frames", "last_launches"):
+        if name in _INT_FIELDS or name in ("n_grid_frames", "last_launches", "pending_samples"):
             v = C.c_int()
             _lib.check(self._L.vr_get_int(self._h, name.encode(), C.byref(v)))
             return bool(v.value) if name in ("show_environment", "tonemapping") else v.value
@@ -180,7 +180,12 @@ class Renderer:
 
     # ---- rendering ----
     def trace(self):
+        """One more sample (RendererOpenGL::trace).  Consecutive calls on an unchanged scene are launched together (include/volren_amd.h)."""
         _lib.check(self._L.vr_trace(self._h))
+
+    def flush(self):
+        """Launch the samples recorded by trace() without waiting for them."""
+        _lib.check(self._L.vr_flush(self._h))
 
     def render(self, spp=0, sync=True):
         """`spp` more samples per pixel in one fused launch (the reference loops trace(); bindings.cpp:124-132)."""
