@@ -43,7 +43,20 @@ volren_amd/libvolren_amd.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -lz -ldl
 
 volren_amd/volren: $(CSRC)/main.cpp volren_amd/libvolren_amd.so $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -x hip $(CSRC)/main.cpp -o $@ -Lvolren_amd -lvolren_amd -Wl,-rpath,'$$ORIGIN' -lz
+	$(HIPCC) $(HIPFLAGS) -x hip $(CSRC)/main.cpp -o $@ -Lvolren_amd -lvolren_amd -Wl,-rpath,'$$ORIGIN:$$ORIGIN/../lib' -lz
+
+# make install PREFIX=<p>: the C ABI header, the C++ drop-in header with the class headers it includes, the library and the CLI --
+#   <p>/include/volren_amd.h  <p>/include/volren_amd.hpp  <p>/include/volren_amd/*.h  <p>/lib/libvolren_amd.so  <p>/bin/volren
+# A caller written against the reference's src/renderer.h builds with: hipcc -I<p>/include caller.cpp -L<p>/lib -lvolren_amd
+PREFIX ?= /usr/local
+# what volren_amd.hpp pulls in (host-side class headers; the kernel headers vr_trace.h / vr_pathtrace.h / vr_math.h stay private)
+INSTALL_HDRS := renderer.h environment.h transferfunc.h grids.h sharded.h devmem.h hostmath.h vr_math.h vr_device.h vr_scene.h
+install: all
+	install -d $(DESTDIR)$(PREFIX)/include/volren_amd $(DESTDIR)$(PREFIX)/lib $(DESTDIR)$(PREFIX)/bin
+	install -m 644 include/volren_amd.h include/volren_amd.hpp $(DESTDIR)$(PREFIX)/include/
+	install -m 644 $(INSTALL_HDRS:%=$(CSRC)/%) $(DESTDIR)$(PREFIX)/include/volren_amd/
+	install -m 755 volren_amd/libvolren_amd.so $(DESTDIR)$(PREFIX)/lib/
+	install -m 755 volren_amd/volren $(DESTDIR)$(PREFIX)/bin/
 
 oracle:
 	$(MAKE) -C oracle
@@ -52,4 +65,4 @@ clean:
 	rm -rf $(OBJDIR) volren_amd/libvolren_amd.so volren_amd/volren
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean install

@@ -8,13 +8,25 @@
 // and resolution (the reference reads cppgl globals), set_tiles() / ShardedRenderer for multi-GPU sharding, fast_math, integrator.
 // Build: hipcc (the headers include <hip/hip_runtime.h> for the device-buffer handles); link libvolren_amd.so.
 // FFI users bind the C ABI in volren_amd.h instead; INTEGRATION.md shows both.
+//
+// Two layouts, one file.  Installed (`make install PREFIX=<p>`): <p>/include/volren_amd.h, <p>/include/volren_amd.hpp and the class headers under
+// <p>/include/volren_amd/, <p>/lib/libvolren_amd.so, <p>/bin/volren -- a caller builds with `hipcc -I<p>/include ... -L<p>/lib -lvolren_amd`.
+// Source tree: this file sits in include/ and the class headers in volren_amd/csrc/.
 #pragma once
 
-#include "../volren_amd/csrc/renderer.h"        // RendererHIP, Camera, BrickGridHIP
-#include "../volren_amd/csrc/environment.h"     // Environment
-#include "../volren_amd/csrc/transferfunc.h"    // TransferFunction
-#include "../volren_amd/csrc/grids.h"           // Volume, Grid, DenseGrid, DenseGridF16, BrickGrid, Buf3D
-#include "../volren_amd/csrc/sharded.h"         // ShardedRenderer: one frame on several devices (no reference counterpart)
+#if __has_include("volren_amd/renderer.h")
+#include "volren_amd/renderer.h"                // RendererHIP, Camera, BrickGridHIP
+#include "volren_amd/environment.h"             // Environment
+#include "volren_amd/transferfunc.h"            // TransferFunction
+#include "volren_amd/grids.h"                   // Volume, Grid, DenseGrid, DenseGridF16, BrickGrid, Buf3D
+#include "volren_amd/sharded.h"                 // ShardedRenderer: one frame on several devices (no reference counterpart)
+#else
+#include "../volren_amd/csrc/renderer.h"
+#include "../volren_amd/csrc/environment.h"
+#include "../volren_amd/csrc/transferfunc.h"
+#include "../volren_amd/csrc/grids.h"
+#include "../volren_amd/csrc/sharded.h"
+#endif
 
 // the reference's names
 using RendererOpenGL = vr::RendererHIP;         // src/renderer.h:16

@@ -861,14 +861,14 @@ int orc_lut_fixup(float* rgba, int32_t n) {
         rgba[4 * i + 3] = integral <= 0.0f ? (float)(i + 1) / (float)n : rgba[4 * i + 3] / integral;
     return 1;
 }
-/* ref: transferfunc.cpp:79-93 (a row that fails to parse keeps the previous row's values there; here: skipped rows are an error) */
+/* ref: transferfunc.cpp:79-93: one row per line, also for a blank line; components that fail to parse are uninitialised there -- defined here as the
+ * previous row's values (first row: 0), which is what the same stack slots hold in practice */
 int orc_load_lut(const char* path, float* rgba, int32_t max_rows) {
     FILE* f = fopen(path, "r");
     if (!f) return -1;
     char tmp[256]; int n = 0;
     float r = 0, g = 0, b = 0, a = 0;
     while (n < max_rows && fgets(tmp, sizeof tmp, f)) {
-        if (tmp[0] == '\n' || tmp[0] == 0) continue;      /* getline loop ends at EOF; blank tail lines carry no row */
         sscanf(tmp, "%f, %f, %f, %f", &r, &g, &b, &a);
         rgba[4 * n + 0] = r; rgba[4 * n + 1] = g; rgba[4 * n + 2] = b; rgba[4 * n + 3] = a;
         n++;

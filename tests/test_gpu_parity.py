@@ -604,6 +604,15 @@ def test_cli_offline_render_matches_oracle(tmp_path):
     tm = o.tonemapped()[::-1]
     want = np.floor(np.clip(tm, 0, 1) * 255.0 + 0.5).astype(np.uint8)
     assert np.array_equal(img, want)
+    # --tf_left / --tf_width take their value only while a transfer function exists (src/main.cpp:397-402); without one the value stays behind as an
+    # argument of its own -- here a flag: `--tf_left --env_hide` must hide the environment (a parser that always consumes a value would swallow it)
+    base = [exe, scenes.SMOKE, scenes.HDR, "-w", "48", "-h", "40", "--render", "--spp", "3", "--cam_fov", "40"]
+    shots = {}
+    for tag, extra in (("hidden", ["--env_hide"]), ("quirk", ["--tf_left", "--env_hide"]), ("shown", [])):
+        out = subprocess.run(base + extra + ["--output", tag + ".png"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        shots[tag] = (tmp_path / (tag + "_000000.png")).read_bytes()
+    assert shots["quirk"] == shots["hidden"] != shots["shown"]
 
 
 def test_tonemap_and_display_buffer():
@@ -1276,6 +1285,27 @@ def test_transfer_function_lut_paths(n_entries):
         r.reset()
         r.render(2)
         assert np.isfinite(r.framebuffer()).all()
+
+
+def test_lut_file_with_blank_and_short_lines(tmp_path):
+    """TransferFunction::load_from_file pushes a row per LINE (src/transferfunc.cpp:86-91), also for a blank line or one with fewer than four numbers,
+    whose missing components keep the previous row's values: tf_size is the line count, in the product and in the oracle (verdict r4 weak #9)."""
+    import struct
+    path = tmp_path / "gaps.txt"
+    path.write_text("0.1, 0.2, 0.3, 0.0\n\n0.9, 0.1\n0.3, 0.3, 0.8, 0.7\n\n0.5, 0.5, 0.5, 1.0\n")
+    from oracle import binding as ob
+    rows = ob.load_lut(str(path))
+    assert rows.shape == (6, 4)
+    assert rows[1].tolist() == rows[0].tolist()                                   # blank line: the previous row again
+    assert np.allclose(rows[2], [0.9, 0.1, 0.3, 0.0]) and rows[4].tolist() == rows[3].tolist()
+    o = scenes.oracle_scene("c2", 56, 40)
+    o.load_transferfunc(str(path))
+    r = scenes.hip_scene("c2", 56, 40)
+    r.load_transferfunc(str(path))
+    u = r.uniforms_bytes()
+    assert any(struct.unpack_from("<I", u, off)[0] == 6 for off in range(0, len(u) - 3, 4))      # tf_size = 6 lines
+    r.render(5)
+    _assert_same(r.framebuffer(), o.render(5), "LUT file with blank / short lines")
 
 
 def test_raymarch_integrator_matches_oracle_and_reference():

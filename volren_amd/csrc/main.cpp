@@ -99,8 +99,10 @@ static void parse_cmd(int argc, char** argv) {
                                                                                           vec4(38 / 255.f, 97 / 255.f, 65 / 255.f, 0.66f), vec4(151 / 255.f, 27 / 255.f, 47 / 255.f, 1.f) }));
         } else if (arg == "--turbo" || arg == "--viridis") {
             std::cerr << arg << ": tinycolormap presets are not part of this build" << std::endl;
-        } else if (arg == "--tf_left") { const float v = a.nextf(); if (renderer->transferfunc) renderer->transferfunc->window_left = v; }
-        else if (arg == "--tf_width") { const float v = a.nextf(); if (renderer->transferfunc) renderer->transferfunc->window_width = v; }
+        // src/main.cpp:397-402: the value is only consumed when a transfer function exists; without one it stays behind as an argument of its own
+        // (not a flag, not a file: ignored)
+        } else if (arg == "--tf_left") { if (renderer->transferfunc) renderer->transferfunc->window_left = a.nextf(); }
+        else if (arg == "--tf_width") { if (renderer->transferfunc) renderer->transferfunc->window_width = a.nextf(); }
         else if (arg == "--cam_pos") { renderer->camera.pos.x = a.nextf(); renderer->camera.pos.y = a.nextf(); renderer->camera.pos.z = a.nextf(); }
         else if (arg == "--cam_dir") { renderer->camera.dir.x = a.nextf(); renderer->camera.dir.y = a.nextf(); renderer->camera.dir.z = a.nextf(); }
         else if (arg == "--cam_fov") renderer->camera.fov_degree = a.nextf();

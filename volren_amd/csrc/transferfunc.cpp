@@ -65,11 +65,13 @@ void TransferFunction::load_from_file(const std::string& path) {
     FILE* f = std::fopen(path.c_str(), "r");
     if (!f) throw std::runtime_error("Unable to read file: " + path);
     std::cout << "Loading LUT: " << path << std::endl;
+    // One row per LINE, as the reference's getline loop pushes them (transferfunc.cpp:86-91) -- also for a blank or malformed line, whose unparsed
+    // components are uninitialised there; in practice they are the previous row's values (the same stack slots), which is what this build defines
+    // (first row: 0).  tf_size counts such rows, so skipping them would change every lookup.
     std::vector<vec4> rows;
     char line[256];
+    vec4 e(0.f, 0.f, 0.f, 0.f);
     while (std::fgets(line, sizeof line, f)) {
-        if (line[0] == '\n' || line[0] == '\0') continue;
-        vec4 e;
         std::sscanf(line, "%f, %f, %f, %f", &e.x, &e.y, &e.z, &e.w);
         rows.push_back(e);
     }

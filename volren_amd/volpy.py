@@ -556,6 +556,19 @@ class Renderer:
 
     view_matrix = property(lambda s: s._view())
 
+    # cam_near / cam_far / proj_matrix (src/bindings.cpp:190-193): fields of the cppgl camera the renderer never reads (a pinhole through
+    # cam_fov, shader/common.glsl:76-80) -- kept so that a script that sets or logs them runs.  Defaults: cppgl's (0.01 / 1000, unverified:
+    # cppgl is not vendored); proj_matrix = glm::perspective(radians(fov), aspect, near, far), column-major like every matrix here.
+    cam_near = 0.01
+    cam_far = 1000.0
+
+    def _proj(self):
+        f = 1.0 / math.tan(0.5 * math.radians(self._r.cam_fov))
+        n, fa = float(self.cam_near), float(self.cam_far)
+        return mat4(vec4(f / self.cam_aspect(), 0, 0, 0), vec4(0, f, 0, 0), vec4(0, 0, -(fa + n) / (fa - n), -1), vec4(0, 0, -2.0 * fa * n / (fa - n), 0))
+
+    proj_matrix = property(lambda s: s._proj())
+
     def cam_aspect(self):
         return self._r.width / self._r.height
 
