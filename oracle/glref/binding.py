@@ -236,15 +236,17 @@ class GLSLReference:
             self.programs[key] = _ck(self.L.glref_program(text.encode()))
         return self.programs[key]
 
-    def render(self, spp, first_sample=1, variant=None):
-        """`spp` dispatches of pathtracer_brick.glsl (or _tf with a LUT) = RendererOpenGL::trace() x spp. Returns RGBA [H][W][4], row 0 = bottom."""
+    def render(self, spp, first_sample=1, variant=None, params=None):
+        """`spp` dispatches of pathtracer_brick.glsl (or _tf with a LUT) = RendererOpenGL::trace() x spp. Returns RGBA [H][W][4], row 0 = bottom.
+        params: the uniform values to feed instead of the scene's own params() (round 5: values derived independently of the oracle,
+        tests/golden/host_rows.py)."""
         s = self.scene
         L = self.L
         prog = self._variant_program(variant) if variant else self._program("pathtracer_brick_tf.glsl" if s.lut is not None else "pathtracer_brick.glsl")
         color = _ck(L.glref_tex2d_empty(s.w, s.h, 4))
         _ck(L.glref_use(prog))
         _ck(L.glref_bind_image(0, color, 4, 0))
-        self.bind_scene(prog, s.params())
+        self.bind_scene(prog, params if params is not None else s.params())
         set_uniform(prog, "resolution", "2i", (s.w, s.h))
         for k in range(spp):
             set_uniform(prog, "current_sample", "i", first_sample + k)

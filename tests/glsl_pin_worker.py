@@ -217,6 +217,25 @@ def main():
     for name, m in M3["images"].items():
         o = emission_scene(W, H) if m["config"] == "emission" else scenes.oracle_scene(m["config"], W, H)
         res["r3"][name] = image_metrics(G3[name], o.render(m["spp"]))
+    # round-5 goldens: three more views rendered by the reference's kernels with uniform values derived INDEPENDENTLY of this oracle
+    # (tests/golden/host_rows.py, make_golden_glsl.py --r5): the oracle's own host rows (unit cube, AABB + crop, lookAt, env rotation, density scale)
+    # must lead to the same frames, and its uniform values must be the hand-derived ones
+    G5 = np.load(os.path.join(HERE, "golden", "glsl_golden_r5.npz"))
+    M5 = json.load(open(os.path.join(HERE, "golden", "glsl_golden_r5.json")))
+    res["r5"] = {}
+    for name in M5["scenes"]:
+        o = scenes.configure_r5(ob.OracleRenderer(W, H), name, True)
+        p5 = o.params()
+        worst = 0.0
+        for key in G5.files:
+            if key.startswith("u_%s_" % name):
+                field = key[len("u_%s_" % name):]
+                mine = np.asarray(getattr(p5, field), np.float64).reshape(-1)
+                want = G5[key].astype(np.float64).reshape(-1)
+                worst = max(worst, float((np.abs(mine - want) / np.maximum(np.abs(want), 1.0)).max()))      # absolute below 1, relative above
+        res["r5"][name] = dict(uniform_max_rel=worst, img=image_metrics(G5["img_" + name], o.render(SPP)))
+        o = scenes.configure_r5(ob.OracleRenderer(W, H), name, True)
+        res["r5"][name]["hi"] = image_metrics(G5["hi_" + name], o.render(M5["hi_spp"]))
     print(json.dumps(res))
 
 

@@ -183,8 +183,57 @@ def main_r3():
     print("wrote glsl_golden_r3.npz (%d arrays)" % len(out))
 
 
+def r5_scene(name, w=W, h=H):
+    """config c2 with the fields of host_rows.R5_SCENES[name] set on an OracleRenderer (arrays for the GL objects; its params() is NOT what the GLSL gets)."""
+    from oracle import binding as ob
+    return scenes.configure_r5(ob.OracleRenderer(w, h), name, True)
+
+
+def r5_hand_derived(o, name):
+    """the uniforms of scene `name` from tests/golden/host_rows.py (numpy, glm's documented formulas): dict name -> value"""
+    import host_rows as hr
+    s = hr.R5_SCENES[name]
+    g = o.density
+    extent = getattr(g, "extent", None) or tuple(int(n) * 8 for n in g.n_bricks)
+    return hr.derive(np.asarray(g.transform, np.float32).reshape(16), extent, g.min_maj[0], g.min_maj[1], s["cam_pos"], hr.scene_dir(s), s["cam_up"],
+                     s.get("density"), s.get("env_rot"), s.get("vol_crop_min", (0, 0, 0)), s.get("vol_crop_max", (1, 1, 1)))
+
+
+def main_r5():
+    """Round-5 additions, written to glsl_golden_r5.npz: a second pin for the HOST rows.  Three further views of smoke.brick -- another
+    camera (position, target, tilted up vector, field of view), a rotated and scaled environment, a cropped volume at another density scale -- rendered by the
+    reference's kernels on llvmpipe with uniform values that do NOT come from the oracle: cam_transform, vol_bb_*, vol_density_transform and its inverse,
+    vol_minorant / majorant / inv_majorant, vol_density_scale, env_transform and its inverse are derived in tests/golden/host_rows.py from glm's documented
+    formulas and src/renderer.cpp:88-131,227-242, src/main.cpp:379-382,417-428.  The tests set the same scenes up through the product's C ABI setters
+    (and the oracle's fields) and compare the frames; the derived values themselves are stored too (u_<scene>_<uniform>)."""
+    sys.path.insert(0, HERE)
+    import host_rows as hr
+    out = {}
+    meta = {"width": W, "height": H, "spp": SPP, "hi_spp": HI_SPP, "spec_math": True, "scenes": {k: {kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in v.items()} for k, v in hr.R5_SCENES.items()}}
+    for name in hr.R5_SCENES:
+        o = r5_scene(name)
+        d = r5_hand_derived(o, name)
+        p = o.params()
+        for k, v in d.items():
+            out["u_%s_%s" % (name, k)] = np.asarray(v, np.float32).reshape(-1)
+            if hasattr(getattr(p, k), "__len__"):
+                getattr(p, k)[:] = [float(x) for x in np.asarray(v, np.float32).reshape(-1)]
+            else:
+                setattr(p, k, float(v))
+        g = gb.GLSLReference(o, spec_math=True)
+        meta["gl"] = g.info
+        out["img_" + name] = g.render(SPP, params=p)
+        out["hi_" + name] = g.render(HI_SPP, params=p)
+        print(name, "done", flush=True)
+    np.savez_compressed(os.path.join(HERE, "glsl_golden_r5.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "glsl_golden_r5.json"), "w"), indent=1)
+    print("wrote glsl_golden_r5.npz (%d arrays)" % len(out))
+
+
 if __name__ == "__main__":
-    if "--r3" in sys.argv:
+    if "--r5" in sys.argv:
+        main_r5()
+    elif "--r3" in sys.argv:
         main_r3()
     elif "--r2" in sys.argv:
         main_r2()

@@ -1,6 +1,7 @@
 """Scene set-ups shared by the tests, bench.py and smoke(): the BASELINE.json configs on the oracle renderer and on
 the HIP renderer, configured identically."""
 import os
+import sys
 
 import numpy as np
 
@@ -136,6 +137,27 @@ def configure(r, name, is_oracle):
     if "exposure" in cfg:
         r.tonemap_exposure = cfg["exposure"]
         r.tonemap_gamma = cfg["gamma"]
+    return r
+
+
+def configure_r5(r, name, is_oracle):
+    """Round 5's extra views of smoke.brick (tests/golden/host_rows.py R5_SCENES): config c2 plus another camera / a rotated environment / a cropped
+    volume, applied through the renderer's setters in the reference's command-line order (src/main.cpp:360-435)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import host_rows as hr
+    s = hr.R5_SCENES[name]
+    configure(r, "c2", is_oracle)
+    r.cam_pos, r.cam_dir, r.cam_up, r.cam_fov = s["cam_pos"], tuple(float(x) for x in hr.scene_dir(s)), s["cam_up"], s["cam_fov"]
+    if "env_rot" in s:
+        if is_oracle:
+            r.set_env_rot(s["env_rot"])
+        else:
+            r.env_rot = s["env_rot"]
+        r.env_strength = s["env_strength"]
+    if "density" in s:
+        r.density_scale = s["density"]
+    if "vol_crop_min" in s:
+        r.vol_clip_min, r.vol_clip_max = s["vol_crop_min"], s["vol_crop_max"]
     return r
 
 

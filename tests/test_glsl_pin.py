@@ -129,6 +129,28 @@ def test_unmodified_kernel_text(standard, unfused):
         assert s[name]["within_1e3"] > 0.9 and s[name]["rel_l2"] < 5e-2 and abs(s[name]["mean_ratio"] - 1.0) < 1e-3, (name, s[name])      # 8 spp: a flipped path is a pixel
 
 
+def test_host_rows_second_pin(standard, unfused):
+    """Round 5 (glsl_golden_r5.npz; verdict r4 #5): SURVEY 8 rows a17 / a18 -- the host marshalling -- rested on one JPEG.  Three more views (another camera
+    with a tilted up vector and another field of view; an environment rotated by 135 degrees at strength 2; a cropped volume at another density scale) were
+    rendered by the reference's kernels on llvmpipe with uniforms derived in tests/golden/host_rows.py from glm's documented formulas, NOT by this oracle.
+    The oracle's own uniform values equal the hand-derived ones to one rounding, and its frames -- set up through its fields only -- are the reference's."""
+    for name in ("cam_b", "env_rot", "crop"):
+        for res in (standard, unfused):
+            r = res["r5"][name]
+            assert r["uniform_max_rel"] < 3e-7, (name, r["uniform_max_rel"])          # lookAt / inverse: the last bit may differ, nothing else
+            assert r["hi"]["rel_l2"] <= 1e-3, (name, r["hi"])                        # the north star's bar at 1024 spp
+        u, s = unfused["r5"][name]["img"], standard["r5"][name]["img"]
+        assert u["within_1e5"] > 0.99 and u["rel_l2"] < 2e-2 and abs(u["mean_ratio"] - 1.0) < 1e-3, (name, u)      # 8 spp: a flipped path is a pixel
+        assert s["within_1e5"] > 0.99 and s["rel_l2"] < 5e-2 and abs(s["mean_ratio"] - 1.0) < 1e-3, (name, s)
+    # the three views really differ from config c2's frame (a pin that any frame passes pins nothing)
+    import numpy as np
+    g5 = np.load(os.path.join(HERE, "golden", "glsl_golden_r5.npz"))
+    g2 = np.load(os.path.join(HERE, "golden", "glsl_golden_r2.npz"))
+    for name in ("cam_b", "env_rot", "crop"):
+        a, b = g5["hi_" + name][..., :3].astype(np.float64), g2["hi_c2_hdr_spec"][..., :3].astype(np.float64)
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) > 0.05, name
+
+
 def test_raymarch_trackers_reproduce_reference_text(standard, unfused):
     """trace_path with sample_volume_raymarch / transmittance_raymarch (common.glsl:506-566, integrator 3) against the
     reference's text run on llvmpipe."""
