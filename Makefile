@@ -9,7 +9,7 @@ CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unu
 HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 OBJDIR   := build
 SRCS_CPP := grids.cpp imageio.cpp environment.cpp transferfunc.cpp renderer.cpp sharded.cpp capi.cpp
-PT_VARIANTS := 0 1 2 3
+PT_VARIANTS := 0 1 2 3 4
 OBJS     := $(OBJDIR)/vr_kernels.o $(PT_VARIANTS:%=$(OBJDIR)/vr_pathtrace_%.o) $(PT_VARIANTS:%=$(OBJDIR)/vr_ptfast_%.o) $(SRCS_CPP:%.cpp=$(OBJDIR)/%.o)
 # tolerance-mode kernels (opt-in, vr_math.h VR_FAST_MATH): hardware transcendentals, reciprocal division, contraction allowed
 FASTFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result -Iinclude -DVR_FAST_MATH=1

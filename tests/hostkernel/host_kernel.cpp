@@ -5,6 +5,7 @@
 // oracle, and run under ASan/UBSan, in the GPU-less build container.  It is built and loaded by
 // tests/test_host_kernel.py only; the product library (libvolren_amd.so) has no CPU path.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -128,7 +129,9 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
     SceneParams P{};
     P.u = u;
     HostGrid dg, eg;
-    build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true, VR_MAJORANT_BLOCKED != 0 && density->dense != nullptr);
+    build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true,
+               // the majorant table's levels 0-1 in 4x4x4-cell blocks (a per-grid choice of the product since round 5; the lane code reads the view's flag at run time here)
+               std::getenv("VR_HOST_MAJ_BLOCKED") != nullptr && std::getenv("VR_HOST_MAJ_BLOCKED")[0] == '1');
     P.density = dg.view;
     std::vector<uint16_t> blocked;                 // == dense_grid_to_device: 4x4x4 blocks
     if (density->dense) {
@@ -218,7 +221,7 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
                         live = true;
                         if (l.state == ST_NEW) for (float& v : cold[i].v) v = nan_();         // a new path must not depend on what its cold line held
                         if (g_trace && (l.state == ST_MARCH || l.state == ST_COLLIDE)) trace_access(l, P);
-                        if (u.use_tf) lane_step<TraceCfg<true, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]); else lane_step<TraceCfg<false, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]);
+                        if (u.use_tf) lane_step<TraceCfg<true, 2, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]); else lane_step<TraceCfg<false, 2, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]);
                         if (++steps > (1ll << 40)) return -1;
                     }
                 }

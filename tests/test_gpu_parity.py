@@ -1056,6 +1056,7 @@ def test_c5_full_size_sparse_1024():
     fb = r.framebuffer()
     assert fb[..., :3].max() > 0 and fb[..., 3].max() > 0
     _assert_same(fb, o.render(4), "c5 1024^3 sparse + emission")
+    assert r.majorant_blocked == 0                                 # 65 k active bricks: commit() keeps the linear majorant table (round 5)
     # a second view from inside the grid's corner region: large brick indices on every axis
     for x in (r, o):
         x.cam_pos = (0.45, 0.4, 0.48)
@@ -1090,6 +1091,13 @@ def test_c5_cloud_at_the_occupancy_the_survey_names():
     fb = r.framebuffer()
     assert fb[..., :3].max() > 0 and fb[..., 3].mean() > 0.2
     _assert_same(fb, o.render(4), "c5cloud 1024^3")
+    # 352 k active bricks: commit() chose the majorant table with levels 0-1 in 4x4x4-cell blocks (kernel variant 4); the linear one gives the same frame
+    assert r.majorant_blocked == 1
+    r.majorant_layout = 0
+    assert r.majorant_blocked == 0
+    r.reset(); r.render(4)
+    _assert_same(r.framebuffer(), fb, "c5cloud 1024^3, linear majorant table")
+    r.majorant_layout = -1
     for x in (r, o):                                               # from inside the cloud's body
         x.cam_pos = (0.05, -0.02, 0.1)
         x.cam_dir = (-0.5, 0.3, -0.81)
@@ -1180,6 +1188,36 @@ def test_emission_kernel_variants(variant):
     fb = r.framebuffer()
     assert np.isfinite(fb).all() and fb[..., :3].max() > 0
     _assert_same(fb, o.render(spp), "emission: " + variant)
+
+
+@pytest.mark.parametrize("lut", [False, True])
+def test_majorant_layout_is_a_per_grid_choice(lut):
+    """Round 5 (verdict r4 #3): the majorant table's levels 0-1 linear or in 4x4x4-cell blocks -- a property of the grid, chosen at commit() for the frames the
+    two-brick-grid kernel serves (compiled for both: variants 2 and 4) and overridable (vr_set_int "majorant_layout").  Same frame either way, with and
+    without a transfer function (whose majorants are TF-remapped floats), after switching back and forth (the table is rebuilt), under the global-majorant
+    trackers (run-time variant), and on scenes that have no second layout (the setting is ignored there)."""
+    w, h, spp = 72, 56, 5
+    r, o = _hip_emission_scene(w, h), _oracle_emission_scene(w, h)
+    if lut:
+        r.load_transferfunc(scenes.LUT); o.load_transferfunc(scenes.LUT)
+    want = o.render(spp).copy()
+    assert r.majorant_blocked == 0                                  # a 40^3-voxel grid: far below the threshold
+    for layout in (1, 0, 1, -1):
+        r.majorant_layout = layout
+        assert r.majorant_blocked == (1 if layout == 1 else 0)
+        r.reset(); r.render(spp)
+        _assert_same(r.framebuffer(), want, "emission scene, majorant layout %d, lut %s" % (layout, lut))
+    r.majorant_layout = 1
+    r.integrator = 1; o.integrator = 1; o.sample = 0
+    r.reset(); r.render(spp)
+    _assert_same(r.framebuffer(), o.render(spp), "global trackers with majorant_layout 1")
+    c = scenes.hip_scene("c3" if lut else "c2", w, h)               # one brick grid: no blocked variant, the request changes nothing
+    c.majorant_layout = 1
+    assert c.majorant_blocked == 0
+    c.render(spp)
+    _assert_same(c.framebuffer(), scenes.oracle_scene("c3" if lut else "c2", w, h).render(spp), "single grid ignores majorant_layout")
+    with pytest.raises(Exception):
+        r.majorant_layout = 2
 
 
 def test_hip_against_unmodified_reference_kernel_text():
@@ -1663,6 +1701,7 @@ def test_scheduler_and_launch_fuzz_against_the_oracle():
         r.sample_pool_mb = int(rs.choice([16, 16, 64, 16384]))
         r.launch_target_ms = int(rs.choice([0, 1, 2000]))
         r.order_tiles = int(rs.randint(0, 3))
+        r.majorant_layout = int(rs.randint(-1, 2))                # per grid / linear / 4x4x4-cell blocks: only the two-brick-grid kernel has both, the others ignore it
         ref = o.render(spp)
         share = None
         if rs.rand() < 0.5:
@@ -1672,7 +1711,7 @@ def test_scheduler_and_launch_fuzz_against_the_oracle():
         r.render(k)                                   # a frame in two calls
         r.render(spp - k)
         fb = r.framebuffer()
-        what = "trial %d: %s thr %s pool %d MB target %d ms order %d tiles %s split %d" % (trial, config, thr, r.sample_pool_mb, r.launch_target_ms, r.order_tiles, "share" if share else "all", k)
+        what = "trial %d: %s thr %s pool %d MB target %d ms order %d majorants %d tiles %s split %d" % (trial, config, thr, r.sample_pool_mb, r.launch_target_ms, r.order_tiles, r.majorant_layout, "share" if share else "all", k)
         if share is None:
             _assert_same(fb, ref, what)
         else:

@@ -121,6 +121,17 @@ def test_emission_grid():
     assert _same(got, want)
 
 
+def test_blocked_majorant_layout(monkeypatch):
+    """Round 5: the majorant table's levels 0-1 in 4x4x4-cell blocks (vr_scene.h majorant_cell_index), a per-grid layout choice of the product.  The lane code
+    compiled for the host reads the layout flag at run time; the frame must not depend on it (the table is a permutation of the same cells)."""
+    monkeypatch.setenv("VR_HOST_MAJ_BLOCKED", "1")
+    o = scenes.oracle_scene("c1", 40, 32)
+    want = o.render(4).copy()
+    got, _ = hk.render(o, 4)
+    assert _same(got, want)
+    test_emission_grid()
+
+
 def test_dense_fp16_grid():
     """Dense fp16 voxels + macro-cell majorants (no brick indirection): product device code vs oracle."""
     import encoder_ref

@@ -7,7 +7,7 @@ name=$1; shift
 out=build/exp_$name; mkdir -p $out
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -Iinclude"
 pids=""
-for v in 0 1 2 3; do
+for v in 0 1 2 3 4; do
   /opt/rocm/bin/hipcc $FLAGS -fno-slp-vectorize -DVR_PT_VARIANT=$v "$@" -Rpass-analysis=kernel-resource-usage -c volren_amd/csrc/vr_pathtrace.hip -o $out/vr_pathtrace_$v.o 2> $out/res_$v.txt &
   pids="$pids $!"
 done
@@ -17,10 +17,10 @@ pids="$pids $!"
 pids="$pids $!"
 /opt/rocm/bin/hipcc $FLAGS "$@" -x hip -c volren_amd/csrc/environment.cpp -o $out/environment.o 2>/dev/null &
 pids="$pids $!"
-for v in 0 1 2 3; do
+for v in 0 1 2 3 4; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result -Iinclude -DVR_FAST_MATH=1 -fno-slp-vectorize -DVR_PT_VARIANT=$v "$@" -c volren_amd/csrc/vr_pathtrace.hip -o $out/vr_pathtrace_fast_$v.o 2>/dev/null &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libvolren_amd.so $out/vr_kernels.o $out/vr_pathtrace_0.o $out/vr_pathtrace_1.o $out/vr_pathtrace_2.o $out/vr_pathtrace_3.o $out/vr_pathtrace_fast_0.o $out/vr_pathtrace_fast_1.o $out/vr_pathtrace_fast_2.o $out/vr_pathtrace_fast_3.o build/grids.o build/imageio.o $out/environment.o build/transferfunc.o $out/renderer.o build/sharded.o build/capi.o -lz -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libvolren_amd.so $out/vr_kernels.o $out/vr_pathtrace_0.o $out/vr_pathtrace_1.o $out/vr_pathtrace_2.o $out/vr_pathtrace_3.o $out/vr_pathtrace_4.o $out/vr_pathtrace_fast_0.o $out/vr_pathtrace_fast_1.o $out/vr_pathtrace_fast_2.o $out/vr_pathtrace_fast_3.o $out/vr_pathtrace_fast_4.o build/grids.o build/imageio.o $out/environment.o build/transferfunc.o $out/renderer.o build/sharded.o build/capi.o -lz -ldl
 grep -h -A8 "TraceCfgILb0ELi0ELi0ELi[01]EEELb0E" $out/res_0.txt $out/res_1.txt | grep -E "VGPRs:|ScratchSize|Occupancy|LDS" | sed 's/.*remark: [^ ]* *//; s/ \[-R.*//' | paste - - - - 

@@ -86,13 +86,35 @@ def scheduler_sections(path):
     names = {0: "sched:resume", 1: "sched:hot-pair glue", 2: "sched:park", 3: "sched:batches+decision"}
     out, prev = [], loop
     for i, k in marks:
-        out.append((prev, i, names[k]))
+        if k == 3:
+            # the decision logic, then the four event batches (each with its routing code: VR_ROUTE_B expands at its call line)
+            cuts = [(prev, "sched:decision")]
+            for key, nm in (("if (want_esc) {", "batch:escape"), ("if (want_post) {", "batch:postnee"), ("if (want_new) {", "batch:new"), ("if (want_nee) {", "batch:nee")):
+                cuts.append((next(j for j, ln in enumerate(lines, 1) if prev <= j <= i and ln.strip().startswith(key)), nm))
+            cuts.append((next(j for j, ln in enumerate(lines, 1) if prev <= j <= i and ln.startswith("#if !VR_BATCH_REGS") and j > cuts[-1][0]), "sched:decision"))
+            for (a, nm), (b, _) in zip(cuts, cuts[1:] + [(i + 1, None)]):
+                out.append((a, b - 1, nm))
+        else:
+            out.append((prev, i, names[k]))
         prev = i + 1
     end = next(i for i, ln in enumerate(lines, 1) if i > prev and "every path of the pool has finished" in ln)
     out.append((prev, end, "sched:tail"))
     out.append((1, loop - 1, "prologue"))
     out.append((end + 1, len(lines), "epilogue"))
     return out
+
+
+def pathtrace_ranges():
+    """vr_pathtrace.h: helper functions above the kernel keep their names, the kernel body is cut into the scheduler's sections"""
+    path = os.path.join(ROOT, "volren_amd/csrc/vr_pathtrace.h")
+    lines = open(path).read().split("\n")
+    kline = next(i for i, ln in enumerate(lines, 1) if ln.startswith("pathtrace_kernel(const KernelArgs A)"))
+    funcs = function_ranges(path)
+    out = []
+    for a, b, n in funcs:
+        if a < kline:
+            out.append((a, min(b, kline - 1), "helper:" + n))
+    return out + [(max(a, kline), b, n) for a, b, n in scheduler_sections(path) if b >= kline]
 
 
 def region_of(fileno_name, line, tr_ranges, pt_ranges):
@@ -122,8 +144,7 @@ def main():
     pt_secs = scheduler_sections(os.path.join(ROOT, "volren_amd/csrc/vr_pathtrace.h"))
     kernel_start = min(a for a, b, n in pt_secs if n == "prologue")
     # helper functions above the kernel keep their names; the kernel body is cut into sections
-    kline = next(a for a, b, n in pt_funcs if n == "pathtrace_kernel") if any(n == "pathtrace_kernel" for _, _, n in pt_funcs) else 0
-    pt_ranges = [(a, b, "helper:" + n) for a, b, n in pt_funcs if b < kline or kline == 0] + [(max(a, kline), b, n) for a, b, n in pt_secs if b >= kline]
+    pt_ranges = pathtrace_ranges()
     m = None
     for mm in re.finditer(r"\n(_ZN2vr[a-z_0-9]*16pathtrace_kernelINS[^\n:]*):[^\n]*\n", txt):
         if want in mm.group(1) and "Lb0EEEv" in mm.group(1):          # non-STATS instance

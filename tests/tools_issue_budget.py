@@ -1,0 +1,237 @@
+"""Issue-cycle budget of the path-tracing kernel per scheduler section (verdict r4 #2a): static ISA x execution counts x per-opcode issue cost.
+
+  static ISA      the kernel's device assembly compiled with -gline-tables-only (same code as the production build), cut into basic blocks (labels and
+                  branches); every block is attributed to one top-level block of the scheduler loop -- resume / march / collide / park / decision / the four
+                  event batches / loop head and tail -- by the source lines its instructions carry (tests/tools_isa_sections.py); blocks that only hold
+                  inlined library code (vr_math.h, rng, rcp3_exact, ...) belong to the block before them (the layout follows the source order);
+  execution count how often a top-level block runs per scheduler iteration: the STATS kernels' counters (tests/tools_sched_stats.py --json: executions per
+                  state, iterations), loop trip counts (TEA: 8 x 4 rounds, the environment warp: 3 pairs), and ~0 for the blocks that exist for rare lanes
+                  (the exact filter path behind the guard band, the division fall-back of rcp3_exact, the watchdog, the work-queue pull);
+  issue cost      SIMD cycles a wave64 instruction occupies with four resident wavefronts: profiles/r5_instruction_costs.txt (tests/tools_valu_rate3.hip)
+                  -- 1.73-1.9 for the plain fp32 / integer ALU forms with VGPR, inline or literal operands, +0.9 for an SGPR source, 2.5-2.9 for min / max /
+                  med3, left shifts, 24-bit multiplies, conversions, three-operand integer forms, 3.2 for compares, 2.8 for v_cndmask with an SGPR mask,
+                  5.1-5.3 for the transcendental unit.
+Output: per section, wave-instructions and issue cycles per iteration and per sample, their sum against (a) SQ_INSTS_VALU of the PMC profile and (b) the
+kernel time (SIMD cycles available per sample = SIMDs x clock / samples per second).
+
+usage: tools_issue_budget.py build/asm/ptg_0.s --stats stats.json [--kernel TraceCfgILb0E] [--valu-per-sample 145] [--msamples 4690] [--blocks]
+"""
+import collections
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import tools_isa_sections as T  # noqa: E402
+
+ROOT = T.ROOT
+# issue cycles per wave64 instruction, 4 wavefronts per SIMD (tests/tools_valu_rate3.hip on MI355X, profiles/r5_instruction_costs.txt)
+COST = {"simple": 1.75, "fma": 1.85, "vop3": 2.75, "cvt": 2.65, "cmp": 3.2, "cnd_vcc": 1.7, "cnd_sgpr": 2.8, "trans": 5.2, "div": 3.3, "lane": 3.0, "minmax": 2.55, "lshl": 2.65,
+        "mul24": 2.6, "u64": 2.86, "pk": 2.86, "sgpr_src": 0.9}
+TOP = {   # innermost function / section -> top-level block (None: inherit from the block before)
+    "march": ("march_prep", "step_dda", "majorant_index", "march_finish", "majorant_fetch", "majorant_value", "march_load", "march_idle", "majorant_cell_index", "majorant_level_offset", "round_mip_q"),
+    "collide": ("tricubic_tap", "tricubic_axis_fast", "tricubic_fast_test", "tricubic_axis_weights", "tap_addr", "tap_load", "tap_value", "collide_prep", "collide_finish", "collide_load",
+                "collide_idle", "nan_guard", "rng_skip9", "trilinear_prep", "trilinear_load", "trilinear_value", "axis_cells", "tf_lookup_at", "brick_voxel_line", "pair_voxel_line", "voxel_index"),
+    "new": ("do_new", "tea32", "make_unit"),
+    "nee": ("do_nee", "sample_environment", "env_warp_level", "shle_park"),
+    "postnee": ("do_postnee", "sample_phase_hg", "align", "shle_fetch", "item_fetch"),
+    "escape": ("do_escape", "lookup_environment"),
+}
+FUNC_TOP = {f: k for k, fs in TOP.items() for f in fs}
+SECTION_TOP = {"sched:resume": "resume", "sched:hot-pair glue": "glue", "sched:park": "park", "sched:decision": "decision", "sched:tail": "tail", "prologue": "prologue", "epilogue": "prologue",
+               "batch:escape": "escape", "batch:postnee": "postnee", "batch:new": "new", "batch:nee": "nee"}
+
+
+def classify(op, args):
+    srcs = args.split(";")[0].split(",")[1:]
+    sg = any(re.match(r"\s*-?\|?s(\[|\d)", a) for a in srcs)
+    if op.startswith(("v_cmp", "v_cmpx")):
+        return "cmp", False
+    if op.startswith("v_cndmask"):
+        return ("cnd_vcc" if op.endswith("_e32") or "vcc" in args.split(";")[0].split(",")[-1] else "cnd_sgpr"), False
+    if op.startswith(("v_rcp", "v_rsq", "v_sqrt", "v_log", "v_exp", "v_sin", "v_cos")):
+        return "trans", False
+    if op.startswith(("v_div_scale", "v_div_fmas", "v_div_fixup")):
+        return "div", False
+    if op.startswith(("v_readlane", "v_writelane", "v_readfirstlane", "v_mbcnt", "v_permlane")):
+        return "lane", False
+    if op.startswith(("v_min", "v_max", "v_med3")):
+        return "minmax", sg
+    if op.startswith(("v_lshlrev_b32", "v_lshl_add_u32", "v_add_lshl", "v_lshl_or")):
+        return "lshl", sg
+    if op.startswith(("v_mul_u32_u24", "v_mul_i32_i24", "v_mad_u32_u24", "v_mad_i32_i24", "v_mul_lo", "v_mul_hi")):
+        return "mul24", sg
+    if op.startswith(("v_lshl_add_u64", "v_mad_u64", "v_mad_i64", "v_lshlrev_b64", "v_lshrrev_b64")):
+        return "u64", False
+    if op.startswith(("v_cvt", "v_floor", "v_ceil", "v_trunc", "v_rndne", "v_fract", "v_frexp", "v_ldexp")):
+        return "cvt", False
+    if op.startswith("v_pk_"):
+        return "pk", False
+    if op.startswith(("v_fma_", "v_fmac", "v_fmaak", "v_fmamk")):
+        return "fma", sg
+    if op.startswith(("v_and_or", "v_or3", "v_add3", "v_xad", "v_bfe", "v_bfi", "v_alignbit", "v_perm", "v_xor3", "v_sad")):
+        return "vop3", False
+    if op.startswith("v_"):
+        return "simple", sg
+    return None, False
+
+
+def parse_blocks(path, want):
+    txt = open(path).read()
+    files = {int(m.group(1)): os.path.basename(m.group(2)) for m in re.finditer(r'\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', txt)}
+    m = next(mm for mm in re.finditer(r"\n(_ZN2vr[a-z_0-9]*16pathtrace_kernelINS[^\n:]*):[^\n]*\n", txt) if want in mm.group(1) and "Lb0EEEv" in mm.group(1))
+    body = txt[m.end():]
+    body = body[:body.index(".Lfunc_end")]
+    tr = T.function_ranges(os.path.join(ROOT, "volren_amd/csrc/vr_trace.h"))
+    pt = T.pathtrace_ranges()
+    blocks, cur = [], None
+
+    def new_block(label):
+        nonlocal cur
+        cur = dict(label=label, n=0, valu=0, cyc=0.0, classes=collections.Counter(), funcs=collections.Counter(), secs=collections.Counter(), branch=None, salu=0, vmem=0, lds=0, smem=0, nops=0, waits=0)
+        blocks.append(cur)
+    new_block("entry")
+    cfile, cline = None, 0
+    for ln in body.split("\n"):
+        ml = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if ml:
+            new_block(ml.group(1))
+            continue
+        mloc = re.match(r"\s+\.loc\s+(\d+)\s+(\d+)", ln)
+        if mloc:
+            cfile, cline = files.get(int(mloc.group(1)), "?"), int(mloc.group(2))
+            continue
+        mi = re.match(r"\s+([a-z][a-z0-9_]+)\s*(.*)", ln)
+        if not mi or mi.group(1).startswith("."):
+            continue
+        op, args = mi.group(1), mi.group(2)
+        if cur["branch"] is not None:
+            new_block(cur["label"] + "+")             # the instruction after a branch starts a block of its own
+        cur["n"] += 1
+        r = T.region_of(cfile, cline, tr, pt)
+        if r:
+            if r.startswith("trace:") or r.startswith("helper:"):
+                cur["funcs"][r.split(":", 1)[1]] += 1
+            else:
+                cur["secs"][r] += 1
+        cls, sg = classify(op, args)
+        if cls:
+            cur["valu"] += 1
+            cur["classes"][cls] += 1
+            cur["cyc"] += COST[cls] + (COST["sgpr_src"] if sg else 0.0)
+            if sg:
+                cur["classes"]["sgpr_src"] += 1
+        elif op.startswith("s_nop"):
+            cur["nops"] += 1
+        elif op.startswith("s_waitcnt"):
+            cur["waits"] += 1
+        elif op.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+            cur["branch"] = (op, args.split(";")[0].strip())
+            cur["salu"] += 1
+        elif op.startswith(("s_load", "s_buffer_load")):
+            cur["smem"] += 1
+        elif op.startswith("s_"):
+            cur["salu"] += 1
+        elif op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+            cur["vmem"] += 1
+        elif op.startswith("ds_"):
+            cur["lds"] += 1
+    return blocks
+
+
+def assign(blocks):
+    """top-level block of every basic block + its execution count relative to ONE execution of that top-level block (loops, rare paths)"""
+    prev = "prologue"
+    for b in blocks:
+        votes = collections.Counter()
+        for f, n in b["funcs"].items():
+            if f in FUNC_TOP:
+                votes[FUNC_TOP[f]] += n
+        for s, n in b["secs"].items():
+            t = SECTION_TOP.get(s)
+            if t:
+                votes[t] += n
+        top = votes.most_common(1)[0][0] if votes else prev
+        if top == "glue":                                # ballots and counts between the march and the collision code: with the march (runs every iteration)
+            top = "march"
+        b["top"] = top
+        prev = top
+        mult = 1.0
+        fs = b["funcs"]
+        self_loop = b["branch"] is not None and (b["branch"][1].split() or [""])[-1] == b["label"].rstrip("+")
+        if fs.get("tea32", 0) >= 20 and self_loop:
+            mult = 8.0                                   # 32 TEA rounds, unrolled by 4
+        elif fs.get("env_warp_level", 0) >= 40 and self_loop:
+            mult = 3.0                                   # levels (1,2) (3,4) (5,6) of the 512^2 importance map; (7,8) is the block after the loop
+        elif fs.get("tricubic_axis_weights", 0) >= 20:
+            mult = 0.02                                  # the reference's weights and divisions: only when a draw falls inside a guard band (9 x 4e-6 per lane and call)
+        elif fs.get("make_unit", 0) >= 20:
+            mult = 0.15                                  # a new work unit: once per 64 x spu items, i.e. every few NEW batches
+        b["mult"] = mult
+    return blocks
+
+
+def main():
+    path = sys.argv[1]
+    arg = lambda k, d=None: (sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d)
+    want = arg("--kernel", "TraceCfgILb0E")
+    blocks = assign(parse_blocks(path, want))
+    stats = json.load(open(arg("--stats"))) if arg("--stats") else None
+    # executions of each top-level block per scheduler iteration
+    if stats:
+        it = float(stats["iterations"])
+        per_iter = {"resume": stats.get("resumes", it) / it, "park": stats.get("parks", it) / it, "decision": 1.0, "tail": 1.0, "march": stats["march"][0] / it, "collide": stats["collide"][0] / it,
+                    "new": stats["new"][0] / it, "nee": stats["nee"][0] / it, "postnee": stats["postnee"][0] / it, "escape": stats["escape"][0] / it, "prologue": 0.0}
+        iters_per_sample = it / float(stats["samples"])
+    else:
+        per_iter = {"resume": stats.get("resumes", it) / it, "park": stats.get("parks", it) / it, "decision": 1.0, "tail": 1.0, "march": 0.97, "collide": 0.89, "new": 0.0675, "nee": 0.0675, "postnee": 0.068, "escape": 0.0675, "prologue": 0.0}
+        iters_per_sample = 15.7 / 64.0
+    tot = collections.defaultdict(lambda: collections.Counter())
+    for b in blocks:
+        w = b["mult"]
+        t = tot[b["top"]]
+        t["static_instr"] += b["n"]
+        t["valu"] += w * b["valu"]
+        t["cyc"] += w * b["cyc"]
+        t["salu"] += w * b["salu"]
+        t["vmem"] += w * b["vmem"]
+        t["lds"] += w * b["lds"]
+        t["nops"] += w * b["nops"]
+        for c, n in b["classes"].items():
+            t["c_" + c] += w * n
+    if "--blocks" in sys.argv:
+        for b in blocks:
+            print("%-14s %-9s x%-5.2f n %4d valu %4d cyc %6.0f  %s %s" % (b["label"], b["top"], b["mult"], b["n"], b["valu"], b["cyc"], dict(b["funcs"].most_common(3)), dict(b["secs"].most_common(2))))
+    order = ["resume", "march", "collide", "park", "decision", "escape", "postnee", "new", "nee", "tail"]
+    print("%-10s %9s | per execution: %6s %8s %5s %5s %5s %5s | per iteration: %7s %9s | share" % ("block", "exec/iter", "VALU", "VALU cyc", "SALU", "VMEM", "LDS", "s_nop", "VALU", "VALU cyc"))
+    sum_valu = sum_cyc = sum_salu = 0.0
+    rows = []
+    for k in order:
+        t = tot[k]
+        e = per_iter.get(k, 0.0)
+        rows.append((k, e, t["valu"], t["cyc"], t["salu"], t["vmem"], t["lds"], t["nops"], e * t["valu"], e * t["cyc"]))
+        sum_valu += e * t["valu"]
+        sum_cyc += e * t["cyc"]
+        sum_salu += e * t["salu"]
+    for r in rows:
+        print("%-10s %9.3f | %21.0f %8.0f %5.0f %5.0f %5.0f %5.0f | %22.1f %9.1f | %4.1f%%" % (r + (100.0 * r[-1] / sum_cyc,)))
+    print("sum per iteration: %.1f VALU wave-instructions, %.1f VALU issue cycles (%.2f cycles per instruction), %.1f SALU" % (sum_valu, sum_cyc, sum_cyc / sum_valu, sum_salu))
+    print("per sample (x %.4f iterations per sample): %.1f VALU wave-instructions, %.1f VALU issue cycles" % (iters_per_sample, sum_valu * iters_per_sample, sum_cyc * iters_per_sample))
+    if arg("--valu-per-sample"):
+        v = float(arg("--valu-per-sample"))
+        print("PMC SQ_INSTS_VALU per sample: %.1f -> the static model counts %.1f %% of it" % (v, 100.0 * sum_valu * iters_per_sample / v))
+    if arg("--msamples"):
+        avail = 1024 * 2.4e9 / (float(arg("--msamples")) * 1e6)
+        print("SIMD cycles available per sample at %.0f Msamples/s: %.1f -> VALU issue takes %.1f %% of the kernel's SIMD time" % (float(arg("--msamples")), avail, 100.0 * sum_cyc * iters_per_sample / avail))
+    # where the cycles are by instruction class, per iteration
+    cls = collections.Counter()
+    for k in order:
+        for c, n in tot[k].items():
+            if c.startswith("c_"):
+                cls[c[2:]] += per_iter.get(k, 0.0) * n * (COST[c[2:]])
+    print("VALU issue cycles per iteration by class:", ", ".join("%s %.0f" % (c, n) for c, n in cls.most_common()))
+
+
+if __name__ == "__main__":
+    main()

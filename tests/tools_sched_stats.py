@@ -12,6 +12,9 @@ r.sched_stats(True)
 r.render(spp); ms=r.last_kernel_ms()
 st = r.sched_stats(False, read=True)
 print(cfg,w,h,spp,"thr",thr,"ms %.2f  Msamples/s %.1f"%(ms, w*h*spp/ms/1e3))
+if os.environ.get("VR_STATS_JSON"):       # for tests/tools_issue_budget.py: executions per state and iterations of the instrumented launch
+    json.dump({"config": cfg, "width": w, "height": h, "spp": spp, "samples": w*h*spp, "iterations": st["iterations"], "resumes": st["resumes"], "parks": st["parks"], "waves": st["waves"], "ms": ms,
+               **{k: list(st[k]) for k in va.renderer.STATE_NAMES}}, open(os.environ["VR_STATS_JSON"], "w"))
 ns = w*h*spp
 tot_exec=0
 for k in va.renderer.STATE_NAMES:

@@ -286,6 +286,7 @@ int vr_set_int(vr_renderer* r, const char* name, int v) {
         else if (n == "integrator") R.integrator = v;
         else if (n == "fast_math") R.fast_math = v != 0;
         else if (n == "coalesce_trace") { R.flush_pending(); R.coalesce_trace = v != 0; }
+        else if (n == "majorant_layout") { if (v < -1 || v > 1) throw std::runtime_error("majorant_layout: -1 (per grid, chosen at commit), 0 (linear), 1 (4x4x4-cell blocks)"); R.majorant_layout = v; }
         else if (n == "tf_float_atlas") R.tf_float_atlas = v != 0;
         else if (n == "gpu_encoder") R.gpu_encoder = v != 0;
         else if (n == "sample_pool_mb") { if (v < 16 || v > 49152) throw std::runtime_error("sample_pool_mb must be in [16, 49152] (item indices of a sub-launch are 32-bit: < 2^32 RGBA32F items)"); R.sample_pool_bytes = (size_t)v << 20; }
@@ -313,6 +314,10 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "integrator") *v = R.integrator;
         else if (n == "fast_math") *v = R.fast_math ? 1 : 0;
         else if (n == "coalesce_trace") *v = R.coalesce_trace ? 1 : 0;
+        else if (n == "majorant_layout") *v = R.majorant_layout;
+        else if (n == "majorant_blocked") {          // what the current frame's next launch will use
+            vr::SceneParams P; R.fill_params(P); *v = P.density.maj_blocked;
+        }
         else if (n == "pending_samples") *v = R.pending_samples();
         else if (n == "tf_float_atlas") *v = R.tf_float_atlas ? 1 : 0;
         else if (n == "gpu_encoder") *v = R.gpu_encoder ? 1 : 0;

@@ -63,6 +63,7 @@ void RendererHIP::reset() { sample = 0; }
 
 // ---------------------------------------------------------------------------------------------------
 static void check_grid_bytes(size_t bytes, const char* what, const int32_t nb[3]);
+constexpr size_t kBlockedMajorantBricks = (size_t)1 << 18;       // active bricks above which commit() picks the blocked majorant layout (512 KiB of fp16 level-0 cells: 1/8 of an XCD's L2)
 static size_t brick_records(const BrickGridHIP& g);
 
 void RendererHIP::commit() {
@@ -73,6 +74,7 @@ void RendererHIP::commit() {
     majorant_emission = 0.f;
     maj_key_ = MajKey{};
     std::cout << "Preparing brick grids for HIP..." << std::endl;
+    std::vector<size_t> with_emission;                              // frames that have an emission grid (index into both vectors' tails)
     for (const auto& frame : volume->grids) {
         Volume::GridPtr density_grid = frame.at("density");       // throws std::out_of_range like the reference
         density_grids.push_back(grid_to_device(density_grid));
@@ -84,25 +86,33 @@ void RendererHIP::commit() {
         if (emission_grid) {
             emission_grids.push_back(grid_to_device(emission_grid));
             majorant_emission = std::max(majorant_emission, emission_grid->minorant_majorant().second);
-            // Both grids of the frame in brick form with the same brick layout: one paired atlas for the kernel compiled for that case (vr_scene.h).  The grids keep
-            // their own atlases too (float-atlas decoder, the run-time variant); when the paired one does not fit, the run-time variant serves the frame.
-            BrickGridHIP& gd = density_grids.back();
-            BrickGridHIP& ge = emission_grids.back();
-            if (VR_PAIRED_ATLAS && VR_BRICK_HEADERS && emission_grids.size() == density_grids.size() && gd.atlas && ge.atlas && !gd.dense && !ge.dense &&
-                gd.nb[0] == ge.nb[0] && gd.nb[1] == ge.nb[1] && gd.nb[2] == ge.nb[2]) {
-                try {
-                    const size_t n_rec = brick_records(gd);
-                    check_grid_bytes(n_rec * kPairBlockBytes, "the paired density + emission atlas", gd.nb);
-                    auto paired = make_device_buffer(n_rec * kPairBlockBytes);
-                    launch_pair_atlas(gd.atlas->as<uint8_t>(), ge.atlas->as<uint8_t>(), paired->as<uint8_t>(), n_rec, stream);
-                    VR_HIP(hipGetLastError());
-                    VR_HIP(hipStreamSynchronize(stream));
-                    gd.atlas_paired = ge.atlas_paired = paired;
-                } catch (const std::exception& e) {
-                    (void)hipGetLastError();
-                    std::cerr << "volren_amd: no room for the paired density + emission atlas (" << e.what() << "): the run-time kernel variant serves this frame" << std::endl;
-                }
-            }
+            if (emission_grids.size() == density_grids.size()) with_emission.push_back(density_grids.size() - 1);
+        }
+    }
+    // Second pass, after every grid the frames NEED is on the device (built inside the loop, the paired atlases of early frames could take the memory
+    // a later frame's mandatory upload needs, and an animation that loaded before would fail commit()): for a frame whose density and emission grids are both in
+    // brick form with the same brick layout, one paired atlas for the kernel compiled for that case (vr_scene.h).  The grids keep their own atlases too
+    // (float-atlas decoder, the run-time variant); when a paired one does not fit, the run-time variant serves that frame.
+    for (size_t f : with_emission) {
+        BrickGridHIP& gd = density_grids[f];
+        BrickGridHIP& ge = emission_grids[f];
+        if (!(VR_PAIRED_ATLAS && VR_BRICK_HEADERS && gd.atlas && ge.atlas && !gd.dense && !ge.dense && gd.nb[0] == ge.nb[0] && gd.nb[1] == ge.nb[1] && gd.nb[2] == ge.nb[2])) continue;
+        try {
+            const size_t n_rec = brick_records(gd);
+            check_grid_bytes(n_rec * kPairBlockBytes, "the paired density + emission atlas", gd.nb);
+            auto paired = make_device_buffer(n_rec * kPairBlockBytes);
+            launch_pair_atlas(gd.atlas->as<uint8_t>(), ge.atlas->as<uint8_t>(), paired->as<uint8_t>(), n_rec, stream);
+            VR_HIP(hipGetLastError());
+            VR_HIP(hipStreamSynchronize(stream));
+            gd.atlas_paired = ge.atlas_paired = paired;
+            // Layout of the density grid's majorant table for the kernel that serves this frame.  Levels 0-1 in 4x4x4-cell blocks of one cache line keep a DDA
+            // walk's neighbouring cells in the line it has just fetched; that pays on large grids whose bricks are filled in bulk (BASELINE configs[4] as specified,
+            // 350 000 active bricks of 2 M: +3 %) and costs 2 % where few bricks are active or the table is cache resident anyway (the 63 000-brick stand-in
+            // grid, smoke.brick): profiles/r4d_blocked_majorants_nt_stores_unit_size.txt, profiles/r5_majorant_layout_per_grid.txt
+            gd.maj_blocked = gd.n_active > kBlockedMajorantBricks;
+        } catch (const std::exception& e) {
+            (void)hipGetLastError();
+            std::cerr << "volren_amd: no room for the paired density + emission atlas of frame " << f << " (" << e.what() << "): the run-time kernel variant serves it" << std::endl;
         }
     }
 }
@@ -193,6 +203,11 @@ BrickGridHIP RendererHIP::dense_to_bricks_on_device(const std::shared_ptr<DenseG
     for (int m = 1; m <= 3; ++m) launch_range_mip(words + out.mip_off[m - 1], mdim[m - 1], words + out.mip_off[m], mdim[m], stream);
     VR_HIP(hipGetLastError());
     VR_HIP(hipStreamSynchronize(stream));
+    {   // bricks whose voxels matter (majorant layout choice, commit())
+        std::vector<uint32_t> flags(n);
+        flag.download(flags.data(), n * sizeof(uint32_t), stream);
+        for (uint32_t f : flags) out.n_active += f != 0u;
+    }
     return out;
 }
 
@@ -267,6 +282,7 @@ BrickGridHIP RendererHIP::brick_grid_to_device(const std::shared_ptr<BrickGrid>&
         if (VR_BRICK_HEADERS)
             for (uint32_t l = 0; l < 5; ++l) { memcpy(dst + l * 128u, &r.rmin, 4); memcpy(dst + l * 128u + 4u, &r.rdiff, 4); }
         if (r.rdiff != 0.f && px < sx && py < sy && pz < sz) {
+            ++out.n_active;
             for (uint32_t z = 0; z < 8; ++z)
                 for (uint32_t y = 0; y < 8; ++y) {
                     const uint8_t* src = &g->atlas.data[g->atlas.index(px * 8, py * 8 + y, pz * 8 + z)];
@@ -305,7 +321,7 @@ void RendererHIP::scale_and_move_to_unit_cube() {
 // ---------------------------------------------------------------------------------------------------
 static void copy3(float* dst, vec3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
 
-static GridView make_view(const BrickGridHIP& g, bool paired = false) {
+static GridView make_view(const BrickGridHIP& g, bool paired = false, bool maj_blocked = false) {
     GridView v;
     memset(&v, 0, sizeof v);                     // padding bytes too: launch inputs are compared byte by byte (LaunchInputs::same_launch_as)
     v.bricks = g.bricks ? g.bricks->as<BrickRec>() : nullptr;
@@ -320,7 +336,7 @@ static GridView make_view(const BrickGridHIP& g, bool paired = false) {
     for (int i = 0; i < 3; ++i) v.nb[i] = g.nb[i];
     for (int i = 0; i < 3; ++i) { v.mshift[i] = g.mshift[i]; v.mlim[i] = (float)(8u << g.mshift[i]); }
     v.n_mips = g.n_mips;
-    v.maj_blocked = VR_MAJORANT_BLOCKED;        // build-time experiment (vr_scene.h), off
+    v.maj_blocked = maj_blocked ? 1 : 0;         // the layout the majorant table is (re)built in and the kernel variant reads (vr_kernels.hip pathtrace_variant)
     return v;
 }
 
@@ -371,7 +387,8 @@ void RendererHIP::fill_params(SceneParams& P) {
         memcpy(P.emission_from_density, efd.m, sizeof efd.m);
         // the kernel compiled for two brick grids (DDA trackers) reads them from their paired atlas; every other kernel reads each grid's own
         P.paired = (integrator == 0 && density.atlas_paired && density.atlas_paired == emission.atlas_paired) ? 1 : 0;
-        if (P.paired) P.density = make_view(density, true);
+        // ... and is the one kernel compiled for both layouts of the majorant table's fine levels: blocked for the grids commit() marked (or as majorant_layout says)
+        if (P.paired) P.density = make_view(density, true, majorant_layout < 0 ? density.maj_blocked : majorant_layout == 1);
         P.emission = make_view(emission, P.paired != 0);
         u.has_emission = 1;
     }
@@ -402,7 +419,7 @@ void RendererHIP::fill_params(SceneParams& P) {
 void RendererHIP::update_majorants(const LaunchInputs& in, BrickGridHIP& g) {
     const MajKey& k = in.maj;
     if (k.density_scale == maj_key_.density_scale && k.tf_version == maj_key_.tf_version &&
-        k.wl == maj_key_.wl && k.ww == maj_key_.ww && k.frame == maj_key_.frame)
+        k.wl == maj_key_.wl && k.ww == maj_key_.ww && k.frame == maj_key_.frame && k.blocked == maj_key_.blocked)
         return;
     launch_majorants(in.P, g.range_words->as<uint32_t>(), g.nb, g.mip_off, g.n_mips, g.mshift, g.majorant->as<float>(), g.majorant16->as<uint16_t>(), in.stream);
     VR_HIP(hipGetLastError());
@@ -475,7 +492,7 @@ const int32_t* RendererHIP::tile_order(const SceneParams& P, int n_tiles) {
 
 bool RendererHIP::LaunchInputs::same_launch_as(const LaunchInputs& o) const {
     return memcmp(&P, &o.P, sizeof P) == 0 && frame == o.frame && maj.density_scale == o.maj.density_scale && maj.tf_version == o.maj.tf_version &&
-           maj.wl == o.maj.wl && maj.ww == o.maj.ww && memcmp(tuning.thr, o.tuning.thr, sizeof tuning.thr) == 0 && tuning.stats == o.tuning.stats &&
+           maj.wl == o.maj.wl && maj.ww == o.maj.ww && maj.blocked == o.maj.blocked && memcmp(tuning.thr, o.tuning.thr, sizeof tuning.thr) == 0 && tuning.stats == o.tuning.stats &&
            tuning.samples_per_unit == o.tuning.samples_per_unit && tuning.blocks_per_cu == o.tuning.blocks_per_cu && order_tiles == o.order_tiles &&
            launch_target_ms == o.launch_target_ms && fast_math == o.fast_math && sample_pool_bytes == o.sample_pool_bytes && stream == o.stream;
 }
@@ -528,6 +545,7 @@ void RendererHIP::capture(LaunchInputs& in) {
     in.maj.wl = transferfunc ? transferfunc->window_left : 0.f;
     in.maj.ww = transferfunc ? transferfunc->window_width : 0.f;
     in.maj.frame = in.frame;
+    in.maj.blocked = in.P.density.maj_blocked;
     in.tuning = tuning;
     in.order_tiles = order_tiles; in.launch_target_ms = launch_target_ms; in.fast_math = fast_math ? 1 : 0;
     in.sample_pool_bytes = sample_pool_bytes;

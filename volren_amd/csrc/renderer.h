@@ -55,6 +55,8 @@ struct BrickGridHIP {
     int32_t n_mips = 0;
     int32_t n_cells = 0;                   // words in range_words
     int32_t mshift[3] = { 3, 3, 3 };       // padded power-of-two extent of `majorant` (vr_scene.h)
+    size_t n_active = 0;                   // bricks whose voxels matter (range not a single value): what the choice of the majorant layout looks at
+    bool maj_blocked = false;              // commit()'s choice for this grid: majorant levels 0-1 in 4x4x4-cell blocks (vr_scene.h majorant_cell_index)
     mat4 transform;
 };
 
@@ -125,6 +127,10 @@ struct RendererHIP {
                                                       // is left when the work queue runs empty are short paths (profiles/r4f_*): 0 never, 1 when the renderer has a tile
                                                       // subset (a rank's share: +0.5 ... +7 %), 2 always (full frames measure +-0.5 %: raster order stays their default).
                                                       // Which tile runs when never changes a result
+    int majorant_layout = -1;                         // layout of the majorant table's levels 0-1 for the frames the two-brick-grid kernel serves: -1 = per grid, chosen at
+                                                      // commit() (blocked when more than kBlockedMajorantBricks bricks carry voxels: the large, well filled sparse grids of
+                                                      // BASELINE configs[4], +3 % there, -2 % on small or thinly filled ones: profiles/r4d_*, r5_*), 0 = linear, 1 = blocked.
+                                                      // Results never depend on it
     bool fast_math = false;                           // opt-in tolerance mode: hardware log/sin/cos/rcp instead of the specified arithmetic
                                                       // (not bit-reproducible; without a transfer function within 1e-3 relative L2 of the default --
                                                       // with one bound the renderer refuses it: DESIGN.md 3)
@@ -159,7 +165,7 @@ struct RendererHIP {
 
 private:
     // majorant cache key
-    struct MajKey { float density_scale = -1.f; uint64_t tf_version = ~0ull; float wl = 0, ww = 0; size_t frame = ~(size_t)0; };   // tf_version: TransferFunction::version (unique per upload), 0 = no LUT
+    struct MajKey { float density_scale = -1.f; uint64_t tf_version = ~0ull; float wl = 0, ww = 0; size_t frame = ~(size_t)0; int blocked = -1; };   // tf_version: TransferFunction::version (unique per upload), 0 = no LUT
     // Everything a launch reads from the renderer's mutable state, as one trace()/render() call found it.  `P` is zero-filled before it is written
     // (fill_params), so two snapshots are compared byte by byte; the handles keep alive what P points into (a caller may replace the environment or
     // re-upload the LUT between two trace() calls: the recorded samples still see the old arrays, as the reference's already issued dispatches do).

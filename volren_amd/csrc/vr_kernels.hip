@@ -84,7 +84,8 @@ accumulate_kernel(const float* __restrict__ sbuf, float* __restrict__ fb, const 
 // the pools better from units of 4: c4 +1.3 %, c2 +-0, c3 -1 % (profiles/r2x_occupancy_recheck.txt) -- and, round 4, on the emission kernel:
 // c5cloud +1 %, c5full +0.5 % (profiles/r4d_*)
 constexpr int32_t kMaxSamplesPerUnit = 8;
-static int32_t samples_per_unit(const PathtraceTuning& T, int variant) { return T.samples_per_unit > 0 ? T.samples_per_unit : ((variant == 1 || variant == 2) ? 4 : kMaxSamplesPerUnit); }
+static int32_t samples_per_unit(const PathtraceTuning& T, int variant) { return T.samples_per_unit > 0 ? T.samples_per_unit : ((variant == 1 || variant == 2 || variant == 4) ? 4 : kMaxSamplesPerUnit); }
+constexpr int kPtVariants = 5;
 
 PathtraceTuning default_tuning() {
     static std::once_flag once;
@@ -102,7 +103,7 @@ PathtraceTuning default_tuning() {
 size_t pathtrace_pool_floats(const PathtraceTuning& T, int32_t n_tiles, int32_t n_samples) {
     // the samples are rounded up to whole units: sized for whichever unit size a variant may use (samples_per_unit)
     size_t padded = 0;
-    for (int variant = 0; variant < 4; ++variant) {
+    for (int variant = 0; variant < kPtVariants; ++variant) {
         const int32_t spu = std::min(n_samples, samples_per_unit(T, variant));
         padded = std::max(padded, (size_t)((n_samples + spu - 1) / spu) * (size_t)spu);
     }
@@ -114,21 +115,23 @@ extern "C" {
 #define VR_PT_DECL(N) \
     int vr_pt_occupancy_##N(int tf, int stats); \
     void vr_pt_launch_##N(int tf, int stats, unsigned grid, hipStream_t stream, const void* P, float* sbuf, float* cold_ws, const void* D, const void* S, uint32_t* status, unsigned long long* stats_buf);
-VR_PT_DECL(0) VR_PT_DECL(1) VR_PT_DECL(2) VR_PT_DECL(3) VR_PT_DECL(0_fast) VR_PT_DECL(1_fast) VR_PT_DECL(2_fast) VR_PT_DECL(3_fast)
+VR_PT_DECL(0) VR_PT_DECL(1) VR_PT_DECL(2) VR_PT_DECL(3) VR_PT_DECL(4) VR_PT_DECL(0_fast) VR_PT_DECL(1_fast) VR_PT_DECL(2_fast) VR_PT_DECL(3_fast) VR_PT_DECL(4_fast)
 #undef VR_PT_DECL
 }
 typedef int (*PtOccupancy)(int, int);
 typedef void (*PtLaunch)(int, int, unsigned, hipStream_t, const void*, float*, float*, const void*, const void*, uint32_t*, unsigned long long*);
-static const PtOccupancy kPtOccupancy[2][4] = { { vr_pt_occupancy_0, vr_pt_occupancy_1, vr_pt_occupancy_2, vr_pt_occupancy_3 },
-                                                { vr_pt_occupancy_0_fast, vr_pt_occupancy_1_fast, vr_pt_occupancy_2_fast, vr_pt_occupancy_3_fast } };
-static const PtLaunch kPtLaunch[2][4] = { { vr_pt_launch_0, vr_pt_launch_1, vr_pt_launch_2, vr_pt_launch_3 },
-                                          { vr_pt_launch_0_fast, vr_pt_launch_1_fast, vr_pt_launch_2_fast, vr_pt_launch_3_fast } };
+static const PtOccupancy kPtOccupancy[2][kPtVariants] = { { vr_pt_occupancy_0, vr_pt_occupancy_1, vr_pt_occupancy_2, vr_pt_occupancy_3, vr_pt_occupancy_4 },
+                                                          { vr_pt_occupancy_0_fast, vr_pt_occupancy_1_fast, vr_pt_occupancy_2_fast, vr_pt_occupancy_3_fast, vr_pt_occupancy_4_fast } };
+static const PtLaunch kPtLaunch[2][kPtVariants] = { { vr_pt_launch_0, vr_pt_launch_1, vr_pt_launch_2, vr_pt_launch_3, vr_pt_launch_4 },
+                                                    { vr_pt_launch_0_fast, vr_pt_launch_1_fast, vr_pt_launch_2_fast, vr_pt_launch_3_fast, vr_pt_launch_4_fast } };
 
 // which compiled variant serves a scene (see vr_pathtrace.hip)
 static int pathtrace_variant(const SceneParams& P) {
     if (P.u.integrator != 0) return 3;
     // variant 2: both grids in brick form -- and, when the kernels are built for the paired atlas, sharing one (same brick layout: RendererHIP::commit)
-    if (P.u.has_emission) return (P.density.dense || P.emission.dense || (VR_PAIRED_ATLAS && !P.paired)) ? 3 : 2;
+    // (4 = 2 compiled for majorant levels 0-1 in 4x4x4-cell blocks; every other kernel of a fixed layout reads linear tables: RendererHIP::fill_params only
+    // sets maj_blocked on the views of frames this variant -- or the run-time variant -- serves)
+    if (P.u.has_emission) return (P.density.dense || P.emission.dense || (VR_PAIRED_ATLAS && !P.paired)) ? 3 : (P.density.maj_blocked ? 4 : 2);
     return P.density.dense ? 1 : 0;
 }
 

@@ -516,6 +516,7 @@ pathtrace_kernel(const KernelArgs A) {
 #endif
     unsigned long long occ[6] = { 0, 0, 0, 0, 0, 0 };      // summed per iteration: marching lanes, READY, NEE, POSTNEE, ESCAPE, FREE
     unsigned long long t_exhausted = 0ull;                 // STATS: constant-rate clock (100 MHz) when this wavefront found the work queue empty
+    uint32_t n_resume = 0u, n_park = 0u;                   // STATS: iterations in which a lane resumed / parked a path (the two bookkeeping blocks are skipped otherwise)
 #define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
 #define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
 // push the slots of all lanes where COND holds onto stack QI (wave-synchronous)
@@ -587,6 +588,7 @@ pathtrace_kernel(const KernelArgs A) {
             const uint64_t idle = wave_ballot(slot < 0);
             const int32_t take = min(popc(idle), cnt_ready);
             if (take > 0) {
+                if (STATS) ++n_resume;
                 if (slot < 0) {
                     const int32_t r = (int32_t)lane_rank(idle);
                     if (r < take) {
@@ -623,7 +625,7 @@ pathtrace_kernel(const KernelArgs A) {
 #if VR_MARCH_SPECULATIVE
             MarchIO mio;
             march_idle(mio);
-            if (is_m) march_prep<K::dense>(l, P, mio);
+            if (is_m) march_prep<K::dense, K::majb>(l, P, mio);
             if constexpr (kMajCells > 0) march_load_lds<K::tf, MajT>(P, mio, lds_maj, maj_first);
             else march_load<K::tf>(P, mio);
 #if VR_MARCH_LOADS_PINNED
@@ -635,7 +637,7 @@ pathtrace_kernel(const KernelArgs A) {
             if (is_m) march_finish<K::tf>(l, P, mio);
 #else
             for (int32_t k = 0; k < 2; ++k)            // diagnostic: two plain steps, one majorant load each, only where a step runs
-                if (slot >= 0 && l.state == ST_MARCH) do_march<K::tf, K::dense>(l, P);
+                if (slot >= 0 && l.state == ST_MARCH) do_march<K::tf, K::dense, K::majb>(l, P);
 #endif
             if (STATS) { const int32_t nm = popc(wave_ballot(is_m)); if (nm) { st_exec[ST_MARCH] += 1u; st_lanes[ST_MARCH] += (uint32_t)nm; } const unsigned long long t_now = __builtin_readcyclecounter(); st_cyc[ST_MARCH] += t_now - t_blk; t_blk = t_now; }
 #if VR_DIAG_PAD_VALU > 0
@@ -683,6 +685,7 @@ pathtrace_kernel(const KernelArgs A) {
             // one integer, so that every ballot below is a single v_cmp
             const int32_t ps = (slot >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE) ? l.state : -1;
             if (wave_ballot(ps >= 0)) {
+                if (STATS) ++n_park;
                 if (ps >= 0) {
                     hs.save_marched(l, slot);
                     if (emission_on && !l.shadow) {                                                    // EmissionCache: L back to the cold line, or -- a path without one -- to its slot
@@ -865,6 +868,8 @@ pathtrace_kernel(const KernelArgs A) {
     if (STATS && stats && lane == 0) {
 #pragma unroll
         for (int k = 0; k < ST_DONE; ++k) { atomicAdd(&stats[2 * k], (unsigned long long)st_exec[k]); atomicAdd(&stats[2 * k + 1], (unsigned long long)st_lanes[k]); }
+        atomicAdd(&stats[14], (unsigned long long)n_resume);
+        atomicAdd(&stats[15], (unsigned long long)n_park);
         atomicAdd(&stats[16], (unsigned long long)iters);
         atomicAdd(&stats[17], 1ull);
 #pragma unroll

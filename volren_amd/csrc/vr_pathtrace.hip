@@ -3,6 +3,8 @@
 //   0  DDA trackers, brick density grid, no emission grid      (BASELINE configs c1, c2, c3)
 //   1  DDA trackers, dense fp16 density grid, no emission grid (c4)
 //   2  DDA trackers, brick density grid, emission grid bound   (c5)
+//   4  variant 2 for grids whose majorant table keeps levels 0-1 in 4x4x4-cell blocks (GridView::maj_blocked, chosen per grid at commit(): the large, well
+//      filled sparse grids of BASELINE configs[4], whose DDA walks then touch a quarter fewer cache lines)
 //   3  everything decided at run time: the global-majorant trackers (common.glsl:333-394, the code the reference compiles out with
 //      USE_DDA) and the one remaining combination, a dense fp16 density grid with an emission grid
 // Each is built twice: bit-exact arithmetic (the default and the parity target) and, with -DVR_FAST_MATH=1, the opt-in
@@ -12,7 +14,7 @@
 #include <stdint.h>
 
 #ifndef VR_PT_VARIANT
-#error "compile with -DVR_PT_VARIANT=0..3"
+#error "compile with -DVR_PT_VARIANT=0..4"
 #endif
 #ifdef VR_FAST_MATH
 #define vr vr_fastmath            // the inline lane code differs from the exact build's: keep the two apart for the linker
@@ -36,8 +38,10 @@ template <bool TF> using Cfg = TraceCfg<TF, 0, 0, 0>;
 template <bool TF> using Cfg = TraceCfg<TF, 0, 0, 1>;
 #elif VR_PT_VARIANT == 2
 template <bool TF> using Cfg = TraceCfg<TF, 0, 1, 0>;
+#elif VR_PT_VARIANT == 4
+template <bool TF> using Cfg = TraceCfg<TF, 0, 1, 0, 1>;
 #else
-template <bool TF> using Cfg = TraceCfg<TF, 2, 2, 2>;
+template <bool TF> using Cfg = TraceCfg<TF, 2, 2, 2, 2>;
 #endif
 
 typedef void (*PtKernel)(const KernelArgs);

@@ -42,10 +42,12 @@ enum LaneState : int32_t {
 //   GLOBAL    0: DDA trackers (USE_DDA, both reference kernels)  1: global-majorant trackers (common.glsl:333-394)  2: run time
 //   EMISSION  0: no emission grid bound (the 9 draws of lookup_emission are still consumed)  1: bound  2: run time
 //   DENSE     0: density grid = bricks  1: dense fp16 voxels  2: run time
-template <bool TF, int GLOBAL, int EMISSION, int DENSE>
+//   MAJB      layout of the majorant table's levels 0-1 (vr_scene.h majorant_cell_index): 0 linear, 1 in 4x4x4-cell blocks of one cache line, 2 run time
+//             (GridView::maj_blocked, chosen per grid at commit(): round 5)
+template <bool TF, int GLOBAL, int EMISSION, int DENSE, int MAJB = 0>
 struct TraceCfg {
     static constexpr bool tf = TF;
-    static constexpr int global = GLOBAL, emission = EMISSION, dense = DENSE;
+    static constexpr int global = GLOBAL, emission = EMISSION, dense = DENSE, majb = MAJB;
     static constexpr int edense = EMISSION == 1 ? DENSE : 2;      // a kernel with a compiled-in emission grid takes it in the same form as the density grid
     // that kernel, on brick grids, reads both grids from one paired atlas (vr_scene.h): component 1 = density, 2 = emission, 0 = a grid's own atlas
     static constexpr int pair_d = (VR_PAIRED_ATLAS && EMISSION == 1 && DENSE == 0) ? 1 : 0, pair_e = pair_d ? 2 : 0;
@@ -228,14 +230,16 @@ VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
 // The padded layout (vr_scene.h) holds 0 in every cell beyond the real extent of a level, so only the padded extent -- the
 // same for all levels -- is tested, on the floats (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails), after
 // which truncation equals floor.
-template <int DENSE = 2>
+template <int DENSE = 2, int MAJB = 2>
 VR_HD int32_t majorant_index(const GridView& g, v3 ipos, int32_t mip) {
     const bool inside = (mip <= g.n_mips) & (ipos.x >= 0.0f) & (ipos.x < g.mlim[0]) & (ipos.y >= 0.0f) & (ipos.y < g.mlim[1]) & (ipos.z >= 0.0f) & (ipos.z < g.mlim[2]);
     const uint32_t sh = 3u + (uint32_t)mip;
     const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
     const uint32_t sx = (uint32_t)g.mshift[0] - (uint32_t)mip, sy = (uint32_t)g.mshift[1] - (uint32_t)mip;
     const uint32_t off = majorant_level_offset((uint32_t)(g.mshift[0] + g.mshift[1] + g.mshift[2]), (uint32_t)mip);
-    const bool blocked = VR_MAJORANT_BLOCKED != 0;    // compile-time (vr_scene.h): majorant_kernel lays the table out from GridView::maj_blocked = the same constant
+    // the layout majorant_kernel wrote the table in (GridView::maj_blocked, a property of the grid since round 5): known at compile time in the kernels built
+    // for one layout -- a kernel is only launched on grids of its layout (vr_kernels.hip pathtrace_variant) -- read from the view otherwise (wave-uniform)
+    const bool blocked = MAJB == 2 ? g.maj_blocked != 0 : MAJB == 1;
     return inside ? (int32_t)(off + majorant_cell_index(bx, by, bz, sx, sy, (uint32_t)mip, blocked)) : -1;
 }
 // Unconditional load (cell 0 when outside; the caller discards it then).  TF kernels read the float table (TF-remapped
@@ -247,9 +251,9 @@ VR_HD uint32_t majorant_fetch(const GridView& g, int32_t idx) {
 }
 template <bool TF>
 VR_HD float majorant_value(const SceneParams& P, uint32_t raw) { return TF ? u2f(raw) : P.u.vol_density_scale * half2float(raw); }
-template <bool TF, int DENSE = 2>
+template <bool TF, int DENSE = 2, int MAJB = 2>
 VR_HD float majorant_at(const SceneParams& P, v3 ipos, int32_t mip) {
-    const int32_t idx = majorant_index<DENSE>(P.density, ipos, mip);
+    const int32_t idx = majorant_index<DENSE, MAJB>(P.density, ipos, mip);
     const float m = majorant_value<TF>(P, majorant_fetch<TF>(P.density, idx));
     return idx < 0 ? 0.0f : m;
 }
@@ -777,19 +781,19 @@ constexpr int32_t kMarchSteps = VR_MARCH_STEPS;
 // the two-step form written out (the default; the generic loop below compiles ~1 % slower for the same arithmetic)
 struct MarchIO { float dt1, dt2, t1; uint32_t maj1, maj2; int32_t i1, i2; bool go1, go2; };     // i*: majorant cell or -1 (outside: majorant 0); maj*: as loaded (majorant_fetch)
 VR_HD void march_idle(MarchIO& io) { io.i1 = io.i2 = -1; io.dt1 = io.dt2 = io.t1 = 0.0f; io.go1 = io.go2 = false; }      // a lane that is not marching
-template <int DENSE = 2>
+template <int DENSE = 2, int MAJB = 2>
 VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
     io.go1 = h.t < h.far;
     const v3 c1 = axpy(h.ipos, h.t, h.idir);
     const int32_t m1 = round_mip_q(h.mipq);
-    io.i1 = majorant_index<DENSE>(P.density, c1, m1);
+    io.i1 = majorant_index<DENSE, MAJB>(P.density, c1, m1);
     io.dt1 = step_dda(c1, h.ri, m1);
     io.t1 = h.t + io.dt1;
     const int32_t q2 = h.mipq < 12 ? h.mipq + 1 : 12;              // mip = min(mip + 0.25, 3)
     const int32_t m2 = round_mip_q(q2);
     io.go2 = io.t1 < h.far;
     const v3 c2 = axpy(h.ipos, io.t1, h.idir);
-    io.i2 = majorant_index<DENSE>(P.density, c2, m2);
+    io.i2 = majorant_index<DENSE, MAJB>(P.density, c2, m2);
     io.dt2 = step_dda(c2, h.ri, m2);
 }
 // the loads: unconditional and for every lane of the wavefront (an idle lane reads cell 0), so that they sit in straight-line
@@ -849,7 +853,7 @@ VR_HD void march_idle(MarchIO& io) {             // a lane that is not marching
 #pragma unroll
     for (int k = 0; k < kMarchSteps; ++k) { io.idx[k] = -1; io.dt[k] = io.t[k] = 0.0f; io.go[k] = false; }
 }
-template <int DENSE = 2>
+template <int DENSE = 2, int MAJB = 2>
 VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
     float t = h.t;
     int32_t q = h.mipq;
@@ -858,7 +862,7 @@ VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
         io.go[k] = t < h.far;
         const v3 c = axpy(h.ipos, t, h.idir);
         const int32_t m = round_mip_q(q);
-        io.idx[k] = majorant_index<DENSE>(P.density, c, m);
+        io.idx[k] = majorant_index<DENSE, MAJB>(P.density, c, m);
         io.dt[k] = step_dda(c, h.ri, m);
         t = t + io.dt[k];
         io.t[k] = t;
@@ -898,12 +902,12 @@ tentative_collision:
 }
 #endif
 // one iteration (sequential form; the scheduler uses the two-phase form above)
-template <bool TF, int DENSE = 2>
+template <bool TF, int DENSE = 2, int MAJB = 2>
 VR_HD void do_march(Hot& h, const SceneParams& P) {
     if (!(h.t < h.far)) { h.state = segment_end_state(h.shadow); return; }
     const v3 curr = axpy(h.ipos, h.t, h.idir);
     const int32_t m = round_mip_q(h.mipq);
-    const float majorant = majorant_at<TF, DENSE>(P, curr, m);
+    const float majorant = majorant_at<TF, DENSE, MAJB>(P, curr, m);
     const float dt = step_dda(curr, h.ri, m);
     h.t += dt;
     h.tau -= majorant * dt;
@@ -1308,7 +1312,7 @@ VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, 
         do_new<K>(h, c, P, wu, next_item++);
         if (h.first) { stash.dir = h.ipos; stash.item = f2u(h.Tr); first_resume(h, P); }      // = HotStore::save_new + load_resume
         break;
-    case ST_MARCH: { MarchIO io; march_prep<K::dense>(h, P, io); march_load<K::tf>(P, io); march_finish<K::tf>(h, P, io); break; }     // two DDA steps, as on the device
+    case ST_MARCH: { MarchIO io; march_prep<K::dense, K::majb>(h, P, io); march_load<K::tf>(P, io); march_finish<K::tf>(h, P, io); break; }     // two DDA steps, as on the device
     case ST_COLLIDE: do_collide<K>(h, c, P); break;
     case ST_NEE: do_nee<K>(h, c, c, P); break;
     case ST_POSTNEE: do_postnee<K>(h, c, P, wu); break;

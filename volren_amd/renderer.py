@@ -7,7 +7,7 @@ import numpy as np
 from . import _lib
 
 _INT_FIELDS = ("sample", "sppx", "seed", "bounces", "show_environment", "tonemapping", "integrator", "grid_frame_counter",
-               "sample_pool_mb", "gpu_encoder", "fast_math", "tf_float_atlas", "launch_target_ms", "order_tiles", "coalesce_trace")
+               "sample_pool_mb", "gpu_encoder", "fast_math", "tf_float_atlas", "launch_target_ms", "order_tiles", "coalesce_trace", "majorant_layout")
 _FLOAT_FIELDS = {"tonemap_exposure": 1, "tonemap_gamma": 1, "albedo": 3, "phase": 1, "density_scale": 1,
                  "emission_scale": 1, "vol_clip_min": 3, "vol_clip_max": 3, "env_strength": 1, "env_transform": 9,
                  "tf_window_left": 1, "tf_window_width": 1, "cam_pos": 3, "cam_dir": 3, "cam_up": 3, "cam_fov": 1,
@@ -49,7 +49,7 @@ class Renderer:
 
     # ---- fields ----
     def __getattr__(self, name):
-        if name in _INT_FIELDS or name in ("n_grid_frames", "last_launches", "pending_samples"):
+        if name in _INT_FIELDS or name in ("n_grid_frames", "last_launches", "pending_samples", "majorant_blocked"):
             v = C.c_int()
             _lib.check(self._L.vr_get_int(self._h, name.encode(), C.byref(v)))
             return bool(v.value) if name in ("show_environment", "tonemapping") else v.value
@@ -266,6 +266,7 @@ class Renderer:
         if not read:
             return None
         d = {n: (int(out[2 * i]), int(out[2 * i + 1])) for i, n in enumerate(STATE_NAMES)}
+        d["resumes"], d["parks"] = int(out[14]), int(out[15])      # iterations in which the resume / the park block ran
         d["iterations"] = int(out[16])
         d["waves"] = int(out[17])
         d["cycles"] = {n: int(out[18 + i]) for i, n in enumerate(STATE_NAMES)}     # shader-clock ticks inside each state's block
