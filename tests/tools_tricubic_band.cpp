@@ -1,6 +1,8 @@
 // Verifier for the fast decision of the stochastic-tricubic filter tests (vr_trace.h: tricubic_axis_fast / tricubic_fast_test).
 // TEST TOOL -- compiles the product's lane code for the host, like tests/hostkernel.
 //
+// (Round 5: the product's test is x = RN(k s' - W') against -G / +G with W' = 2^24 w' and an absolute band G, VR_TAP_ABS_BAND in vr_trace.h; this tool
+// searches the product's own tricubic_fast_test, so it checks whichever form the header compiles.  The comparisons named below are round 2's.)
 // Claim checked: for every fractional coordinate t a float can take in [0, 1] and EVERY one of the 2^24 values a draw can take,
 // a test that the fast path decides ("yes" / "no") is decided the same way by the reference's code
 //     r < w / s,   r = k * 2^-24,   w, s from tricubic_axis_weights (common.glsl:221-244 restated operation by operation),
@@ -20,6 +22,11 @@
 #include "../volren_amd/csrc/vr_trace.h"
 
 using namespace vr;
+#if VR_TAP_ABS_BAND
+#define VR_BAND_TEXT "absolute, 160 units of k s, round 5's form"
+#else
+#define VR_BAND_TEXT "2^-18 relative, round 2's form"
+#endif
 
 static const double TWO24 = 16777216.0;
 
@@ -31,13 +38,13 @@ static inline int64_t count_ref(float w, float s) {          // number of k in [
     const double c = std::ceil(td);
     return (int64_t)c;                                       // k < td  <=>  k < ceil(td) (k integer), also when td is an integer
 }
-// first k in [0, 2^24] with pred(RN(k * s)) true, for a predicate that is monotone (false ... false true ... true); guess from k0
-template <class Pred> static inline int64_t first_k(float s, double k0, Pred pred) {
+// first k in [0, 2^24] with pred(k) true, for a predicate that is monotone in k (false ... false true ... true); guess from k0
+template <class Pred> static inline int64_t first_k(double k0, Pred pred) {
     int64_t k = (int64_t)std::floor(k0) - 4;
-    if (k < 0) k = 0;
+    if (!(k0 == k0) || k < 0) k = 0;
     if (k > (int64_t)TWO24) k = (int64_t)TWO24;
-    while (k > 0 && pred((float)k * s)) --k;                 // guess too high: walk down to a false
-    while (k < (int64_t)TWO24 && !pred((float)k * s)) ++k;   // then up to the first true
+    while (k > 0 && pred((float)k)) --k;                     // guess too high: walk down to a false
+    while (k < (int64_t)TWO24 && !pred((float)k)) ++k;       // then up to the first true
     return k;
 }
 
@@ -67,9 +74,16 @@ int main(int argc, char** argv) {
         const float fw[3] = { F.w2, F.w3, F.w4 }, fs[3] = { F.s2, F.s3, 6.0f };
         for (int j = 0; j < 3; ++j) {
             const int64_t K_ref = count_ref(rw[j], rs[j]);
-            const float lo = fma_(fw[j], kTapLo, -1e-20f), hi = fma_(fw[j], kTapHi, 1e-20f), s = fs[j];
-            const int64_t K_yes = first_k(s, (double)lo / (double)s, [lo](float x) { return !(x < lo); });       // first k that is NOT a yes
-            const int64_t K_no = first_k(s, (double)hi / (double)s, [hi](float x) { return x > hi; });           // first k that is a no
+            const float s = fs[j], w = fw[j];
+            // both decision sets are intervals of k: the fast test's x(k) (RN(k s) against two thresholds in round 2's form, RN(k s - W) against -G / +G in
+            // round 5's) is monotone in k.  The product's own test function is what is searched: first k that is NOT a yes, first k that IS a no
+#if VR_TAP_ABS_BAND
+            const double g_yes = ((double)w - (double)kTapBand) / (double)s, g_no = ((double)w + (double)kTapBand) / (double)s;
+#else
+            const double g_yes = (double)fma_(w, kTapLo, -1e-20f) / (double)s, g_no = (double)fma_(w, kTapHi, 1e-20f) / (double)s;
+#endif
+            const int64_t K_yes = first_k(g_yes, [w, s](float k) { bool y, n; tricubic_fast_test(k, w, s, y, n); return !y; });
+            const int64_t K_no = first_k(g_no, [w, s](float k) { bool y, n; tricubic_fast_test(k, w, s, y, n); return n; });
             // cross-check the interval picture with the product's own test function at the boundaries
             if (K_yes > 0 && decide((float)(K_yes - 1), fw[j], s) != 1) ++violations;
             if (K_yes < (int64_t)TWO24 && decide((float)K_yes, fw[j], s) == 1) ++violations;
@@ -78,7 +92,11 @@ int main(int argc, char** argv) {
             if (K_yes > K_ref) { ++violations; ++decided_wrong_yes; if (std::getenv("TB_VERBOSE")) std::printf("yes>ref: q %.9g test %d K_yes %lld K_ref %lld K_no %lld  rw %.9g rs %.9g fw %.9g fs %.9g\n", q, j, (long long)K_yes, (long long)K_ref, (long long)K_no, rw[j], rs[j], fw[j], s); }
             if (K_no < K_ref) { ++violations; ++decided_wrong_no; }
             ++checked;
+#if VR_TAP_ABS_BAND
+            const double T = (double)rw[j] / (double)rs[j], Tf = (double)fw[j] / TWO24 / (double)s;
+#else
             const double T = (double)rw[j] / (double)rs[j], Tf = (double)fw[j] / (double)s;
+#endif
             if (T > 1e-30) { const double d = std::fabs(Tf / T - 1.0); if (d > max_disc) max_disc = d; }
             const double band = (double)(K_no - K_yes) / TWO24;
             if (band > max_band) max_band = band;
@@ -93,7 +111,7 @@ int main(int argc, char** argv) {
     (void)worst_t;
     std::printf("stride %u: %lld (t, test) pairs checked, violations %lld (fast yes where the reference says no: %lld, fast no where it says yes: %lld)\n",
                 stride, checked, violations, decided_wrong_yes, decided_wrong_no);
-    std::printf("largest relative difference between the two thresholds: %.3e = 2^%.2f (guard band: 2^-18); widest band: %.3e of the draws\n",
+    std::printf("largest relative difference between the two thresholds: %.3e = 2^%.2f (guard band: " VR_BAND_TEXT "); widest band: %.3e of the draws\n",
                 max_disc, std::log2(max_disc > 0 ? max_disc : 1e-300), max_band);
     return violations == 0 ? 0 : 1;
 }

@@ -619,7 +619,21 @@ pathtrace_kernel(const KernelArgs A) {
         // trips per pass instead of four: both majorants are loaded together (the second step is prepared speculatively,
         // march_prep), and a tap's brick record and voxel are loaded together (brick-linear atlas, tap_load).  The loads
         // themselves are unconditional straight-line code between the exec-masked blocks (march_load / collide_load).
-        {
+        // VR_HOT_PAIRS (round 5): the pair runs up to that many times per scheduler iteration -- straight-line copies, no loop -- so that the bookkeeping around
+        // it (resume, park, batch decision: ~17 % of the kernel's VALU issue cycles, profiles/r5_issue_budget.txt) is paid once per VR_HOT_PAIRS passes; a
+        // further copy only runs while at least VR_HOT_PAIR_MIN lanes still hold a marching or colliding path (lanes whose path reached an event idle through
+        // it).  Measured (profiles/r5c_*, r5d_*): 2 / 3 / 4 / 6 copies c2 +3.5 / +3.6 / +3.4 / +3.2 %, c3 +3.6 %, c4 +0.5 ... +1 %, c5cloud +1.2 ... +4 %,
+        // c5full +6.3 / +8.1 / +8.8 / +9.2 % (sparse grids: several march passes per collision); MIN 32 / 44 / 54 within the noise.  Round 2 had tried the
+        // same as a LOOP around the march block (profiles/r2ac_*): the loop form cost more than the repetitions brought.
+#ifndef VR_HOT_PAIRS
+#define VR_HOT_PAIRS 4
+#endif
+#ifndef VR_HOT_PAIR_MIN
+#define VR_HOT_PAIR_MIN 44
+#endif
+#pragma unroll
+        for (int hot_rep_ = 0; hot_rep_ < VR_HOT_PAIRS; ++hot_rep_) {
+            if (hot_rep_ > 0 && popc(wave_ballot(slot >= 0 && (uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) break;
             if (STATS) t_blk = __builtin_readcyclecounter();
             const bool is_m = slot >= 0 && l.state == ST_MARCH;
 #if VR_MARCH_SPECULATIVE

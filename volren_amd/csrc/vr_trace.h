@@ -387,6 +387,36 @@ constexpr LcgJump lcg_jump(int j) {
     for (int i = 0; i < j; ++i) { A = A * 1664525u; C = C * 1664525u + 1013904223u; }
     return LcgJump{ A, C };
 }
+// Round 5 (VR_TAP_ABS_BAND, default on): the same decision with fewer operations.  The weights come out of the Horner forms already scaled by 2^24 (the
+// constants carry the factor: scaling by a power of two commutes with every rounding of the evaluation, so W = 2^24 x w bit for bit), the partial sums are
+// s2 = RN(2^-24 W2 + u^3), s3 = RN(2^-24 W3 + s2) (one fma each, the same single rounding as the additions they replace), and a test is ONE fma and two
+// compares: x = RN(k s - W);  yes: x < -G,  no: x > G,  with an ABSOLUTE band G = 160 (in units of k s; W <= 4 x 2^24, so G / W >= 2^-18.7 where the two
+// evaluations' thresholds differ most, 2^-21.3 relative = 26 units).  Round 2's form -- x = k s against RN(W lo - eps) and RN(W hi + eps), a relative band --
+// took a multiply and two fmas per test.  tests/tools_tricubic_band.cpp checks either form for every float t in [0, 1] and all 2^24 draws.
+#ifndef VR_TAP_ABS_BAND
+#define VR_TAP_ABS_BAND 1
+#endif
+#if VR_TAP_ABS_BAND
+struct AxisFast { float w2, s2, w3, s3, w4, fl; };      // w*: 2^24 x 6 x the weights; s*: 6 x the partial sums (s4 = 6)
+constexpr float kTapScale = 16777216.0f, kTapInvScale = 1.0f / 16777216.0f, kTapBand = 160.0f;
+VR_HD AxisFast tricubic_axis_fast(float q) {
+    AxisFast a;
+    a.fl = floor_(q);
+    const float t = q - a.fl, t2 = t * t, u = 1.0f - t;
+    a.w4 = (t2 * t) * kTapScale;                                                                               // 2^24 t^3
+    a.w2 = fma_(fma_(3.0f * kTapScale, t, -6.0f * kTapScale), t2, 4.0f * kTapScale);                           // 2^24 (3t^3 - 6t^2 + 4)
+    a.w3 = fma_(fma_(fma_(-3.0f * kTapScale, t, 3.0f * kTapScale), t, 3.0f * kTapScale), t, kTapScale);        // 2^24 (-3t^3 + 3t^2 + 3t + 1)
+    a.s2 = fma_(a.w2, kTapInvScale, (u * u) * u);                                                              // (1 - t)^3 + 6 w2
+    a.s3 = fma_(a.w3, kTapInvScale, a.s2);
+    return a;
+}
+// one test: yes / no as the reference decides, or neither (inside the band).  k: the draw's 24 bits as a float; w: 2^24 x the weight
+VR_HD void tricubic_fast_test(float k, float w, float s, bool& yes, bool& no) {
+    const float x = fma_(k, s, -w);
+    yes = x < -kTapBand;
+    no = x > kTapBand;
+}
+#else
 struct AxisFast { float w2, s2, w3, s3, w4, fl; };      // 6 x the weights; s4 = 6
 VR_HD AxisFast tricubic_axis_fast(float q) {
     AxisFast a;
@@ -408,6 +438,7 @@ VR_HD void tricubic_fast_test(float k, float w, float s, bool& yes, bool& no) {
     yes = x < fma_(w, kTapLo, -1e-20f);
     no = x > fma_(w, kTapHi, 1e-20f);
 }
+#endif
 #ifndef VR_TAP_FAST
 #if defined(__HIP_DEVICE_COMPILE__)
 #define VR_TAP_FAST 1
