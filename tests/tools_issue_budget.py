@@ -231,6 +231,17 @@ def main():
             if c.startswith("c_"):
                 cls[c[2:]] += per_iter.get(k, 0.0) * n * (COST[c[2:]])
     print("VALU issue cycles per iteration by class:", ", ".join("%s %.0f" % (c, n) for c, n in cls.most_common()))
+    if arg("--json"):
+        out = {"kernel": want, "asm": os.path.basename(path), "cycles_per_valu_op": sum_cyc / sum_valu, "valu_per_iteration_model": sum_valu, "valu_issue_cycles_per_iteration": sum_cyc,
+               "iterations_per_sample": iters_per_sample, "valu_per_sample_model": sum_valu * iters_per_sample,
+               "sections": {r[0]: {"executions_per_iteration": r[1], "valu_per_execution": r[2], "valu_cycles_per_execution": r[3], "share_of_valu_cycles": r[9] / sum_cyc} for r in rows},
+               "classes_cycles_per_iteration": dict(cls)}
+        if arg("--valu-per-sample"):
+            out["valu_per_sample_pmc"] = float(arg("--valu-per-sample"))
+            out["model_over_pmc"] = sum_valu * iters_per_sample / float(arg("--valu-per-sample"))
+        if stats:
+            out["stats"] = {k: stats[k] for k in ("config", "width", "height", "spp", "iterations", "resumes", "parks") if k in stats}
+        json.dump(out, open(arg("--json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -641,6 +641,7 @@ pathtrace_kernel(const KernelArgs A) {
             march_idle(mio);
             if (is_m) march_prep<K::dense, K::majb>(l, P, mio);
             if constexpr (kMajCells > 0) march_load_lds<K::tf, MajT>(P, mio, lds_maj, maj_first);
+            else if constexpr (K::maj_reuse) march_load_reuse<K::tf>(P, mio, l);
             else march_load<K::tf>(P, mio);
 #if VR_MARCH_LOADS_PINNED
             // Both majorants must have been REQUESTED before the first is used.  Left alone, the compiler sinks each load into the
@@ -648,7 +649,7 @@ pathtrace_kernel(const KernelArgs A) {
             // empty asm that takes both values as operands keeps the two loads above it, back to back.
             asm volatile("" : "+v"(mio.maj1), "+v"(mio.maj2));
 #endif
-            if (is_m) march_finish<K::tf>(l, P, mio);
+            if (is_m) march_finish<K::tf, K::maj_reuse>(l, P, mio);
 #else
             for (int32_t k = 0; k < 2; ++k)            // diagnostic: two plain steps, one majorant load each, only where a step runs
                 if (slot >= 0 && l.state == ST_MARCH) do_march<K::tf, K::dense, K::majb>(l, P);

@@ -28,6 +28,11 @@
 // marching path waits in its LDS slot meanwhile) instead of a second set -- no scratch, at the price of an LDS round trip per batch
 #define VR_BATCH_REGS 0
 #endif
+#if VR_PT_VARIANT == 3 && !defined(VR_HOT_PAIRS)
+// ... and one copy of the hot pair per scheduler iteration (the other variants run up to four, vr_pathtrace.h): a second copy costs its transfer-function
+// instance 8 VGPR spills to scratch memory (profiles/r5_kernel_resources.txt)
+#define VR_HOT_PAIRS 1
+#endif
 #include "vr_pathtrace.h"
 
 namespace vr {

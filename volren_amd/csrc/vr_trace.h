@@ -44,6 +44,9 @@ enum LaneState : int32_t {
 //   DENSE     0: density grid = bricks  1: dense fp16 voxels  2: run time
 //   MAJB      layout of the majorant table's levels 0-1 (vr_scene.h majorant_cell_index): 0 linear, 1 in 4x4x4-cell blocks of one cache line, 2 run time
 //             (GridView::maj_blocked, chosen per grid at commit(): round 5)
+#ifndef VR_MAJ_REUSE
+#define VR_MAJ_REUSE 0       /* build-time experiment (round 5, profiles/r5f_*): 0 never (default: c5cloud +-0, c2 -0.6 %), 1 in the kernel for blocked majorant tables (variant 4), 2 in every kernel */
+#endif
 template <bool TF, int GLOBAL, int EMISSION, int DENSE, int MAJB = 0>
 struct TraceCfg {
     static constexpr bool tf = TF;
@@ -51,6 +54,8 @@ struct TraceCfg {
     static constexpr int edense = EMISSION == 1 ? DENSE : 2;      // a kernel with a compiled-in emission grid takes it in the same form as the density grid
     // that kernel, on brick grids, reads both grids from one paired atlas (vr_scene.h): component 1 = density, 2 = emission, 0 = a grid's own atlas
     static constexpr int pair_d = (VR_PAIRED_ATLAS && EMISSION == 1 && DENSE == 0) ? 1 : 0, pair_e = pair_d ? 2 : 0;
+    // the kernel compiled for the large sparse grids (blocked majorant table: the grid whose gathers leave the caches) remembers the last majorant it used
+    static constexpr bool maj_reuse = VR_MAJ_REUSE == 2 || (VR_MAJ_REUSE == 1 && MAJB == 1);
 };
 
 // the pool of work items of one wavefront: pixel p = item & 63 of the 8x8 tile at (px0, py0), sample
@@ -86,6 +91,11 @@ struct Hot {
     // (SHLE_IN_HOT, vr_pathtrace.h ShleBanks); otherwise it goes through the side array (C_SHLE)
     v3 shle;
     uint32_t item;           // same schedulers: the path's slot in the sample buffer (otherwise C_ITEM of the side array)
+    // kernels with majorant reuse (round 5, TraceCfg::maj_reuse): the table index and the raw table word of the majorant this LANE used last.  The table does not
+    // change during a launch, so the pair stays valid whatever path the lane holds: a step that asks for the same cell again -- the walk restarting in place
+    // after a null collision on the finest level -- takes the word from here and sends its load to cell 0, a line all such lanes share
+    int32_t maj_idx;
+    uint32_t maj_raw;
 };
 // A new path needs nothing of its cold line until its first event: position = the camera's, throughput 1, radiance 0, no
 // scatter yet.  What it does need there -- its world direction and its slot in the sample buffer -- waits in the path's hot
@@ -593,6 +603,11 @@ VR_HD int32_t env_warp_level(const float* rec, float& px, float& py, int32_t& po
     posy = 2 * posy + (up ? 1 : 0);
     return (up ? 2 : 0) + (right ? 1 : 0);
 }
+#ifndef VR_ENV_BLOCK_LOADS
+#define VR_ENV_BLOCK_LOADS 1
+#endif
+// BLOCK: load a pair of levels' 64-byte block at once (below); off in the everything-at-run-time kernel, which has no registers for it
+template <bool BLOCK = true>
 VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i, v3& Le, float& pdf_out) {
     int32_t posx = 0, posy = 0;
     float px = r0, py = r1;
@@ -607,8 +622,24 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
     }
     for (; k + 1 < top; k += 2) {                               // levels k and k + 1: parent record, then the chosen child's in the same block
         const float* b = blk + kEnvCdfBlockFloats * (size_t)((posy << k) + posx);
+#if VR_ENV_BLOCK_LOADS && defined(__HIP_DEVICE_COMPILE__)
+        if (BLOCK) {
+        // the whole 64-byte block at once -- parent record and all four children's -- and the child picked in registers: one memory round trip per pair of
+        // levels instead of two dependent ones (the second was a hit in the line the first had fetched, but a round trip all the same)
+        const float4 q0 = reinterpret_cast<const float4*>(b)[0], q1 = reinterpret_cast<const float4*>(b)[1], q2 = reinterpret_cast<const float4*>(b)[2], q3 = reinterpret_cast<const float4*>(b)[3];
+        const float parent[3] = { q0.x, q0.y, q0.z };
+        const int32_t c = env_warp_level(parent, px, py, posx, posy);
+        const bool c_right = (c & 1) != 0, c_up = (c & 2) != 0;          // children: c0 = (q0.w q1.x q1.y)  c1 = (q1.z q1.w q2.x)  c2 = (q2.y q2.z q2.w)  c3 = (q3.x q3.y q3.z)
+        const float lo_d = c_right ? q1.z : q0.w, lo_e0 = c_right ? q1.w : q1.x, lo_e1 = c_right ? q2.x : q1.y;
+        const float hi_d = c_right ? q3.x : q2.y, hi_e0 = c_right ? q3.y : q2.z, hi_e1 = c_right ? q3.z : q2.w;
+        const float child[3] = { c_up ? hi_d : lo_d, c_up ? hi_e0 : lo_e0, c_up ? hi_e1 : lo_e1 };
+        env_warp_level(child, px, py, posx, posy);
+        } else
+#endif
+        {
         const int32_t c = env_warp_level(b, px, py, posx, posy);
         env_warp_level(b + 3 + 3 * c, px, py, posx, posy);
+        }
         blk += (size_t)kEnvCdfBlockFloats << (2 * k);
     }
     if (k < top) {                                              // the last pair: one 128-byte line, the finest records carry their four texels
@@ -707,6 +738,7 @@ VR_HD void hot_init(Hot& h) {
     h.shadow = 0;
     h.state = ST_NEW;
     h.first = 0;
+    h.maj_idx = -2; h.maj_raw = 0u;
 }
 
 // result of trace_path: vec4(L, clamp(n_paths, 0, 1)) -> the item's slot of the sample buffer
@@ -834,6 +866,14 @@ VR_HD void march_load(const SceneParams& P, MarchIO& io) {
     io.maj1 = majorant_fetch<TF>(P.density, io.i1);
     io.maj2 = majorant_fetch<TF>(P.density, io.i2);
 }
+// the same with the lane's remembered (index, word) pair (Hot::maj_idx): a first step into the remembered cell loads nothing new
+template <bool TF>
+VR_HD void march_load_reuse(const SceneParams& P, MarchIO& io, const Hot& h) {
+    const bool same = io.i1 == h.maj_idx;                        // (-1 = outside never equals a remembered index: those are >= 0 or -2)
+    const uint32_t m1 = majorant_fetch<TF>(P.density, same ? 0 : io.i1);
+    io.maj1 = same ? h.maj_raw : m1;
+    io.maj2 = majorant_fetch<TF>(P.density, io.i2);
+}
 // The same loads when the tail of the majorant table -- cells [first, end): the coarse levels, or the whole table of a small grid -- has been copied
 // to LDS (vr_pathtrace.h): a lane whose cell lies there reads the copy and sends its global load to cell 0, which all such lanes share (one
 // line); when the whole table is resident (first == 0, wave-uniform) no global load is issued at all.  T: uint16_t (raw fp16) or float (TF).
@@ -853,15 +893,18 @@ VR_HD void march_load_lds(const SceneParams& P, MarchIO& io, const T* lds, int32
     io.maj1 = majorant_fetch_lds<TF, T>(P.density, io.i1, lds, first, all_resident);
     io.maj2 = majorant_fetch_lds<TF, T>(P.density, io.i2, lds, first, all_resident);
 }
-template <bool TF>
+template <bool TF, bool REUSE = false>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     if (!io.go1) { h.state = segment_end_state(h.shadow); return; }
     float t = io.t1, maj = io.i1 >= 0 ? majorant_value<TF>(P, io.maj1) : 0.0f;
     float tau = h.tau - maj * io.dt1;
     int32_t q = h.mipq < 12 ? h.mipq + 1 : 12;
+    // REUSE: the cell whose majorant the lane leaves the pass with (Hot::maj_idx; selects, not conditional stores)
+    if (REUSE) { const bool keep = io.i1 >= 0; h.maj_idx = keep ? io.i1 : h.maj_idx; h.maj_raw = keep ? io.maj1 : h.maj_raw; }
     if (tau > 0.0f) {                                              // no tentative collision in the first cell: second step
         if (!io.go2) { h.t = t; h.tau = tau; h.mipq = q; h.state = segment_end_state(h.shadow); return; }
         maj = io.i2 >= 0 ? majorant_value<TF>(P, io.maj2) : 0.0f;
+        if (REUSE) { const bool keep = io.i2 >= 0; h.maj_idx = keep ? io.i2 : h.maj_idx; h.maj_raw = keep ? io.maj2 : h.maj_raw; }
         t = io.t1 + io.dt2;
         tau = tau - maj * io.dt2;
         q = q < 12 ? q + 1 : 12;
@@ -909,8 +952,9 @@ VR_HD void march_load(const SceneParams& P, MarchIO& io) {
 }
 template <bool TF, class T>
 VR_HD void march_load_lds(const SceneParams&, MarchIO&, const T*, int32_t) { static_assert(sizeof(T) == 0, "VR_MAJ_LDS is written for VR_MARCH_STEPS == 2"); }
-template <bool TF>
+template <bool TF, bool REUSE = false>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
+    static_assert(!REUSE, "majorant reuse is written for VR_MARCH_STEPS == 2");
     float tau = h.tau, maj = 0.0f, t = h.t;
     int32_t q = h.mipq;
 #pragma unroll
@@ -1107,7 +1151,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     const float r0 = rng(h.seed), r1 = rng(h.seed);
     float pdf;
     v3 w_i, Le;
-    sample_environment(P, r0, r1, w_i, Le, pdf);
+    sample_environment<K::global != 2>(P, r0, r1, w_i, Le, pdf);
     c.st(C_SHPDF, pdf);
     if (pdf > 0.0f) {
         const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
