@@ -54,7 +54,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 SIMDS = 1024                 # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4              # peak engine clock, MI355X_MICROARCH.md
-CYCLES_PER_VALU_OP = 1.8     # a wave64 fp32 VALU instruction occupies a SIMD for 1.8 cycles with >= 4 resident wavefronts (profiles/r2_valu_issue_rate.txt)
+CYCLES_PER_VALU_OP = 1.8     # the CHEAPEST opcodes (fp32 add / mul / fma, and / or, right shifts with VGPR operands) occupy a SIMD for 1.73-1.9 cycles with 4 resident wavefronts; the
+                             # kernels' own mix costs 2.3-2.4 (profiles/r5_issue_budget.json: static ISA per scheduler section x STATS execution counts x the per-opcode costs of
+                             # profiles/r5_instruction_costs.txt) -- roofline_issue uses the mix's figure when the profile has one for the configuration
 COUNTER_SPP = 8              # oracle samples per pixel behind events_per_sample (COUNTER_SPP batches of 1 spp: their spread is the standard error)
 CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}
 
@@ -200,11 +202,26 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def issue_profile(cfg):
+    """Opcode-weighted issue cost of the configuration's kernel (profiles/r5_issue_budget.json, tests/tools_issue_budget_all.sh): cycles per VALU wave-instruction of
+    ITS instruction mix, the share of its issue cycles per scheduler section, and the counter SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the same run.  c5full runs the
+    sibling of c5cloud's kernel (same code, linear majorant table): its entry is c5cloud's, marked approximate."""
+    j = profile_json("r5_issue_budget.json")
+    if not j:
+        return None, False
+    key = {"c4:512": "c4"}.get(cfg, cfg)
+    if key in j:
+        return j[key], False
+    if cfg.startswith("c5") and "c5cloud" in j:
+        return j["c5cloud"], True
+    return None, False
+
+
 def traffic_profile(cfg, w, h):
     """(entry, file, stale) of the newest committed PMC profile taken on this configuration AT THIS FRAME SIZE (the instruction and traffic mix per sample
     depends on the view: c4 at 1920x1080 is not c4 at 1024x1024), or (None, None, None).  Round 4's file is keyed by the bench line's config names and
     records the frame; older files only have the square frames of their rounds."""
-    for name in ("r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
+    for name in ("r5_hbm_traffic.json", "r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
         tj = profile_json(name)
         if not tj:
             continue
@@ -395,13 +412,26 @@ def roofline_of(config, w, h, spp, m, counted):
     issue = None
     if tp and "per_sample" in tp and "valu" in tp["per_sample"]:
         valu = tp["per_sample"]["valu"]
-        peak_issue = SIMDS * CLOCK_GHZ / CYCLES_PER_VALU_OP                 # G wave-instructions/s
+        ip, approx = issue_profile(cfg)
+        cyc = ip["cycles_per_valu_op"] if ip else CYCLES_PER_VALU_OP       # opcode-weighted: this kernel's instruction mix (verdict r4 #2a); 1.8 = the cheapest opcodes
+        peak_issue = SIMDS * CLOCK_GHZ / cyc                                # G wave-instructions/s the SIMDs sustain at this mix
         ach_issue = valu * kernel_rate / 1e9
         issue = {"bound": "valu_issue", "achieved": ach_issue, "peak": peak_issue, "unit": "G wave-instructions/s", "frac": ach_issue / peak_issue,
                  "valu_wave_instructions_per_sample": valu, "lane_utilisation": tp.get("lane_utilisation"), "hbm_frac": achieved / HBM_PEAK_GBS,
-                 "cycles_per_valu_op": CYCLES_PER_VALU_OP, "cycles_source": "profiles/r2_valu_issue_rate.txt", "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
-                 "counts_source": tp_file, "stale": bool(stale),
-                 "summary": "hbm %.2f / issue %.2f / lanes %s" % (achieved / HBM_PEAK_GBS, ach_issue / peak_issue, ("%.2f" % tp["lane_utilisation"]) if tp.get("lane_utilisation") else "?")}
+                 "cycles_per_valu_op": cyc, "cycles_per_valu_op_cheapest": CYCLES_PER_VALU_OP, "frac_at_cheapest_opcode_cost": ach_issue / (SIMDS * CLOCK_GHZ / CYCLES_PER_VALU_OP),
+                 "cycles_source": ("profiles/r5_issue_budget.json (static ISA per scheduler section x STATS execution counts x profiles/r5_instruction_costs.txt)" + (", entry of the sibling kernel c5cloud" if approx else "")) if ip else "profiles/r2_valu_issue_rate.txt",
+                 "simds": SIMDS, "clock_ghz": CLOCK_GHZ, "counts_source": tp_file, "stale": bool(stale)}
+        if ip:
+            # the counter beside the model: quad-cycles a wavefront spends in VALU instructions / its resident quad-cycles, x resident wavefronts per SIMD = VALU pipelines'
+            # worth per SIMD; a SIMD sustains 4 / cycles_per_valu_op of them
+            share = ip.get("valu_active_share_of_wave_cycles")
+            issue["sections_share_of_valu_issue_cycles"] = {k: round(v["share_of_valu_cycles"], 3) for k, v in ip["sections"].items() if v["share_of_valu_cycles"] > 0}
+            issue["model_over_pmc_valu_count"] = ip.get("model_over_pmc")
+            if share:
+                issue["counter_valu_active_share_of_wave_cycles"] = share
+                issue["counter_frac"] = share * cyc            # = (4 x share) / (4 / cyc)
+        issue["summary"] = "hbm %.2f / issue %.2f (counter %s) / lanes %s" % (achieved / HBM_PEAK_GBS, ach_issue / peak_issue, ("%.2f" % issue["counter_frac"]) if issue.get("counter_frac") else "?",
+                                                                            ("%.2f" % tp["lane_utilisation"]) if tp.get("lane_utilisation") else "?")
     # the same with SURVEY 8d's FUSED framebuffer figure (B_fb = 16 B per pixel per frame = 16 / spp per sample) instead of the 32 B per sample this
     # build's sample pool moves (16 B written by the path-tracing kernel, 16 B read back by the ordered accumulation pass): the pool is the build's own
     # staging, so this is the fraction to hold against a renderer that accumulates in registers
@@ -410,7 +440,7 @@ def roofline_of(config, w, h, spp, m, counted):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "frac_fused_fb": achieved_fused / HBM_PEAK_GBS, "bytes_per_sample_fused_fb": b_fused,
             "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "pathtrace_kernel<TraceCfg<tf=%s, %s>, false>" % ("true" if use_tf else "false", variant),
+            "kernel": "pathtrace_kernel<TraceCfg<tf=%s, %s>, false>" % ("true" if use_tf else "false", variant + (", majorant levels 0-1 blocked" if cfg.startswith("c5cloud") else "")),
             "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "samples_per_launch": m["samples_per_launch"],
             "bytes_per_sample": b_sample, "bytes_per_sample_stderr": stderr, "events_per_sample": events, "roofline_issue": issue,
             "note": "bytes = algorithmic (SURVEY 8d), event counts from %d oracle samples per pixel (stderr over the batches); the kernel is limited by its work per sample (vector instructions and fully divergent vector-memory accesses at ~74 %% lane utilisation: roofline_issue), not by HBM bandwidth nor by where its gathers hit (DESIGN.md 5, profiles/r3c_whatif_voxel_taps_in_cache.txt): 2-9 useful bytes per 128-byte line" % len(batches)}

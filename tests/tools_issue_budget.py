@@ -140,7 +140,7 @@ def parse_blocks(path, want):
     return blocks
 
 
-def assign(blocks):
+def assign(blocks, tf_kernel=False):
     """top-level block of every basic block + its execution count relative to ONE execution of that top-level block (loops, rare paths)"""
     prev = "prologue"
     for b in blocks:
@@ -168,6 +168,10 @@ def assign(blocks):
             mult = 0.02                                  # the reference's weights and divisions: only when a draw falls inside a guard band (9 x 4e-6 per lane and call)
         elif fs.get("make_unit", 0) >= 20:
             mult = 0.15                                  # a new work unit: once per 64 x spu items, i.e. every few NEW batches
+        elif tf_kernel and b["top"] == "collide" and (fs.get("tap_load", 0) + fs.get("tap_value", 0)) >= 0.5 * max(1, sum(fs.values())):
+            mult = 0.0                                   # the byte-atlas corners of the trilinear lookup: not run while the decoded float atlas is bound (brick grids behind a LUT)
+        elif tf_kernel and (fs.get("collide_finish", 0) + fs.get("tf_lookup_at", 0) + fs.get("trilinear_value", 0)) >= 0.5 * max(1, sum(fs.values())) and b["top"] == "collide":
+            mult = 0.5                                   # transfer-function kernels carry collide_finish twice (LUT in LDS / in global memory: address spaces are compile-time); one runs
         b["mult"] = mult
     return blocks
 
@@ -176,7 +180,7 @@ def main():
     path = sys.argv[1]
     arg = lambda k, d=None: (sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d)
     want = arg("--kernel", "TraceCfgILb0E")
-    blocks = assign(parse_blocks(path, want))
+    blocks = assign(parse_blocks(path, want), tf_kernel="TraceCfgILb1E" in want)
     stats = json.load(open(arg("--stats"))) if arg("--stats") else None
     # executions of each top-level block per scheduler iteration
     if stats:
@@ -187,9 +191,12 @@ def main():
     else:
         per_iter = {"resume": stats.get("resumes", it) / it, "park": stats.get("parks", it) / it, "decision": 1.0, "tail": 1.0, "march": 0.97, "collide": 0.89, "new": 0.0675, "nee": 0.0675, "postnee": 0.068, "escape": 0.0675, "prologue": 0.0}
         iters_per_sample = 15.7 / 64.0
+    # the hot pair is compiled VR_HOT_PAIRS times (straight-line copies, vr_pathtrace.h); the STATS counters count every copy's executions, so a copy's cost
+    # is the static total / copies
+    copies = float(arg("--hot-pairs", "1"))
     tot = collections.defaultdict(lambda: collections.Counter())
     for b in blocks:
-        w = b["mult"]
+        w = b["mult"] / (copies if b["top"] in ("march", "collide") else 1.0)
         t = tot[b["top"]]
         t["static_instr"] += b["n"]
         t["valu"] += w * b["valu"]
