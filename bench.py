@@ -427,7 +427,7 @@ def roofline_of(config, w, h, spp, m, counted):
             share = ip.get("valu_active_share_of_wave_cycles")
             issue["sections_share_of_valu_issue_cycles"] = {k: round(v["share_of_valu_cycles"], 3) for k, v in ip["sections"].items() if v["share_of_valu_cycles"] > 0}
             issue["model_over_pmc_valu_count"] = ip.get("model_over_pmc")
-            if share:
+            if share and not approx:                       # (the sibling kernel's counter says nothing about this scene's stalls)
                 issue["counter_valu_active_share_of_wave_cycles"] = share
                 issue["counter_frac"] = share * cyc            # = (4 x share) / (4 / cyc)
         issue["summary"] = "hbm %.2f / issue %.2f (counter %s) / lanes %s" % (achieved / HBM_PEAK_GBS, ach_issue / peak_issue, ("%.2f" % issue["counter_frac"]) if issue.get("counter_frac") else "?",

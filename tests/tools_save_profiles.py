@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_source_sha  # noqa: E402
-R = sys.argv[1] if len(sys.argv) > 1 else "r4"
+R = sys.argv[1] if len(sys.argv) > 1 else "r5"
 P = os.path.join(ROOT, "gpurun_out", "prof")
 prof = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (R, name))
 d = None
