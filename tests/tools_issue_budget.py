@@ -166,12 +166,18 @@ def assign(blocks, tf_kernel=False):
             mult = 3.0                                   # levels (1,2) (3,4) (5,6) of the 512^2 importance map; (7,8) is the block after the loop
         elif fs.get("tricubic_axis_weights", 0) >= 20:
             mult = 0.02                                  # the reference's weights and divisions: only when a draw falls inside a guard band (9 x 4e-6 per lane and call)
+        elif fs.get("rcp3_exact", 0) >= 0.5 * max(1, sum(fs.values())) and b["classes"].get("div", 0) >= 6:
+            mult = 0.0                                   # rcp3_exact's fall-back to three IEEE divisions: only for operands outside the exact reciprocal's range
+        elif fs.get("wrap_repeat", 0) >= 0.8 * max(1, sum(fs.values())) and b["n"] >= 24:
+            mult = 0.0                                   # GL_REPEAT for coordinates far outside [0, 1]: an integer division, never taken by directions on the sphere
         elif fs.get("make_unit", 0) >= 20:
             mult = 0.15                                  # a new work unit: once per 64 x spu items, i.e. every few NEW batches
         elif tf_kernel and b["top"] == "collide" and (fs.get("tap_load", 0) + fs.get("tap_value", 0)) >= 0.5 * max(1, sum(fs.values())):
             mult = 0.0                                   # the byte-atlas corners of the trilinear lookup: not run while the decoded float atlas is bound (brick grids behind a LUT)
         elif tf_kernel and (fs.get("collide_finish", 0) + fs.get("tf_lookup_at", 0) + fs.get("trilinear_value", 0)) >= 0.5 * max(1, sum(fs.values())) and b["top"] == "collide":
-            mult = 0.5                                   # transfer-function kernels carry collide_finish twice (LUT in LDS / in global memory: address spaces are compile-time); one runs
+            # transfer-function kernels carry collide_finish twice (LUT in LDS / in global memory: address spaces are compile-time); the LDS one runs for LUTs of up
+            # to 256 entries (the bench's): a copy that reads LDS counts, one that reads global memory does not, the rest (no load in the block) half
+            mult = 1.0 if b["lds"] > 0 else (0.0 if b["vmem"] > 0 else 0.5)
         b["mult"] = mult
     return blocks
 
