@@ -527,7 +527,7 @@ def sharded_leg(args, world):
                                                                  "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "NCCL_ASYNC")))}
         cmd = [sys.executable, os.path.abspath(__file__), "--host", "sharded", "--gpus", str(world), "--devices", ",".join(str(d) for d in devices), "--steps", str(args.steps),
                "--warmup", str(args.warmup), "--config", args.config, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--cpu-budget", "0"]
-        proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("VOLREN_SHARDED_LEG_TIMEOUT", "240")))
+        proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("VOLREN_SHARDED_LEG_TIMEOUT", "150")))
         lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
         if proc.returncode != 0 or not lines:
             return {"error": "exit %d: %s" % (proc.returncode, (proc.stderr or proc.stdout)[-600:])}

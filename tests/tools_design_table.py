@@ -35,8 +35,8 @@ def kst(sub):
 
 
 text = "\n".join(doc)
-text = re.sub(r"\(c2\) \d+ launches, average [\d.]+ ms \(min [\d.]+, max [\d.]+\)", "(c2) " + kst("TraceCfg<false, 0, 0, 0>, false"), text)
-text = re.sub(r"\(c3\) \d+ launches, average [\d.]+ ms \(min [\d.]+, max [\d.]+\)", "(c3) " + kst("TraceCfg<true, 0, 0, 0>, false"), text)
+text = re.sub(r"\(c2\) \d+ launches, average [\d.]+ ms \(min [\d.]+, max [\d.]+\)", "(c2) " + kst("TraceCfg<false, 0, 0, 0, 0>, false"), text)
+text = re.sub(r"\(c3\) \d+ launches, average [\d.]+ ms \(min [\d.]+, max [\d.]+\)", "(c3) " + kst("TraceCfg<true, 0, 0, 0, 0>, false"), text)
 fm, cb, cr, c1 = B["fast_math"], B["cpu_baseline"], B["cpu_baseline_raymarch"], B["cpu_baseline_c1"]
 text = re.sub(r"never the parity target\): c2 \d+ Msamples/s \(×[\d.]+\), relative L2 against the bit-exact frame [\d.e-]+\.",
               "never the parity target): c2 %.0f Msamples/s (×%.3f), relative L2 against the bit-exact frame %.1e." % (fm["value"], fm["speedup"], fm["rel_l2_vs_bit_exact"]), text)
