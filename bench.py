@@ -639,7 +639,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else
                                       "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if use_tf else "")),
             "config": {"workload": workload_name(args.config, w, h, spp),
-                       "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, "; value_pipelined: consecutive frames over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, %d fused launch(es)/frame (16 GiB sample pool)%s%s" % (m["launches"], "; value_pipelined: consecutive frames over 2 streams" if b.pipelined else "", ", one-rank process group: pack_tiles -> all_gather -> unpack_tiles per frame" if dist is not None else "")},
+                       "parallelism": ("tiles16x16 diagonal-interleaved over %d GPU(s), 1 all_gather/frame%s" % (world, "; value_pipelined: consecutive frames over 2 streams" if b.pipelined else "")) if world > 1 else "1 GPU, %d fused launch(es)/frame (sample pool budget %d GiB)%s%s" % (m["launches"], b.r.sample_pool_mb >> 10, "; value_pipelined: consecutive frames over 2 streams" if b.pipelined else "", ", one-rank process group: pack_tiles -> all_gather -> unpack_tiles per frame" if dist is not None else "")},
             "roofline": b.roofline(m, counted),
             "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
             "dist_backend": (dist.get_backend() if dist is not None else None),

@@ -91,7 +91,7 @@ int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
  *     relative L2 of the default -- refused with VR_ERR while a transfer function is bound, where it misses that bound)
  *     "tf_float_atlas" (default 1: transfer-function renders of brick grids decode the atlas to floats once, 4x its size; 0 = read the bytes)
  *     "grid_frame_counter"
- *     "sample_pool_mb" (HBM budget of the per-sample radiance pool, default 16384)
+ *     "sample_pool_mb" (HBM budget of the per-sample radiance pool, 16 .. 65536, default 65536: allocated only as large as a launch needs)
  *     "launch_target_ms" (default 2000: a vr_render is split into sub-launches planned to take at most this long each, from the rate this
  *     renderer measured last -- a short probe launch, one synchronisation, when it has none for the current settings and the request is
  *     large; 0 = split by the sample pool alone.  Results never depend on the split)

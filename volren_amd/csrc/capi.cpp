@@ -289,7 +289,7 @@ int vr_set_int(vr_renderer* r, const char* name, int v) {
         else if (n == "majorant_layout") { if (v < -1 || v > 1) throw std::runtime_error("majorant_layout: -1 (per grid, chosen at commit), 0 (linear), 1 (4x4x4-cell blocks)"); R.majorant_layout = v; }
         else if (n == "tf_float_atlas") R.tf_float_atlas = v != 0;
         else if (n == "gpu_encoder") R.gpu_encoder = v != 0;
-        else if (n == "sample_pool_mb") { if (v < 16 || v > 49152) throw std::runtime_error("sample_pool_mb must be in [16, 49152] (item indices of a sub-launch are 32-bit: < 2^32 RGBA32F items)"); R.sample_pool_bytes = (size_t)v << 20; }
+        else if (n == "sample_pool_mb") { if (v < 16 || v > 65536) throw std::runtime_error("sample_pool_mb must be in [16, 65536] (item indices of a sub-launch are 32-bit: < 2^32 RGBA32F items)"); R.sample_pool_bytes = (size_t)v << 20; }
         else if (n == "launch_target_ms") { if (v < 0) throw std::runtime_error("launch_target_ms must be >= 0 (0 = no sizing by time)"); R.launch_target_ms = v; }
         else if (n == "order_tiles") { if (v < 0 || v > 2) throw std::runtime_error("order_tiles: 0 (never), 1 (tile subsets), 2 (always)"); R.order_tiles = v; }
         else if (n == "grid_frame_counter") {

@@ -139,7 +139,10 @@ struct RendererHIP {
     int launch_target_ms = 2000;                      // a sub-launch is planned to take at most this long, from the rate the renderer measured on its last launch (a short
                                                       // probe launch when it has none for the current settings and the request is large); 0 = plan by the sample pool alone.
                                                       // Correctness does not depend on it (the kernel's watchdog is progress-based): it bounds how long one launch holds the GPU
-    size_t sample_pool_bytes = (size_t)16 << 30;      // HBM budget of the per-sample radiance pool (16 B per pixel-sample; sized for 288 GB HBM3E, allocated on demand)
+    size_t sample_pool_bytes = (size_t)64 << 30;      // HBM budget of the per-sample radiance pool (16 B per pixel-sample; sized for 288 GB HBM3E: 64 GiB = the 2^32 items a sub-launch
+                                                      // can index; allocated on demand, only as large as a launch needs, halved when it does not fit the free memory).  Round 5: 16 -> 64 GiB,
+                                                      // a 2048^2 x 4096-spp frame is 5 sub-launches instead of 16 and each one's drain (4-8 ms) is paid that much less often: c5full +2.2 %,
+                                                      // c4 at 1920x1080x4096 +0.9 % (tests/tools_pool_ab.py)
 
     void set_tiles(const std::vector<int32_t>& tile_ids);     // empty = whole frame
     void fill_params(SceneParams& P);                          // renderer.cpp:88-138

@@ -44,6 +44,9 @@ enum LaneState : int32_t {
 //   DENSE     0: density grid = bricks  1: dense fp16 voxels  2: run time
 //   MAJB      layout of the majorant table's levels 0-1 (vr_scene.h majorant_cell_index): 0 linear, 1 in 4x4x4-cell blocks of one cache line, 2 run time
 //             (GridView::maj_blocked, chosen per grid at commit(): round 5)
+#ifndef VR_MARCH_STEPS
+#define VR_MARCH_STEPS 2     /* DDA steps a march pass prepares and loads together (march_prep below) */
+#endif
 #ifndef VR_MAJ_REUSE
 #define VR_MAJ_REUSE 0       /* build-time experiment (round 5, profiles/r5f_*): 0 never (default: c5cloud +-0, c2 -0.6 %), 1 in the kernel for blocked majorant tables (variant 4), 2 in every kernel */
 #endif
@@ -55,7 +58,7 @@ struct TraceCfg {
     // that kernel, on brick grids, reads both grids from one paired atlas (vr_scene.h): component 1 = density, 2 = emission, 0 = a grid's own atlas
     static constexpr int pair_d = (VR_PAIRED_ATLAS && EMISSION == 1 && DENSE == 0) ? 1 : 0, pair_e = pair_d ? 2 : 0;
     // the kernel compiled for the large sparse grids (blocked majorant table: the grid whose gathers leave the caches) remembers the last majorant it used
-    static constexpr bool maj_reuse = VR_MAJ_REUSE == 2 || (VR_MAJ_REUSE == 1 && MAJB == 1);
+    static constexpr bool maj_reuse = VR_MARCH_STEPS == 2 && (VR_MAJ_REUSE == 2 || (VR_MAJ_REUSE == 1 && MAJB == 1));
 };
 
 // the pool of work items of one wavefront: pixel p = item & 63 of the 8x8 tile at (px0, py0), sample
@@ -952,6 +955,8 @@ VR_HD void march_load(const SceneParams& P, MarchIO& io) {
 }
 template <bool TF, class T>
 VR_HD void march_load_lds(const SceneParams&, MarchIO&, const T*, int32_t) { static_assert(sizeof(T) == 0, "VR_MAJ_LDS is written for VR_MARCH_STEPS == 2"); }
+template <bool TF>
+VR_HD void march_load_reuse(const SceneParams& P, MarchIO& io, const Hot&) { march_load<TF>(P, io); }      // (majorant reuse is written for VR_MARCH_STEPS == 2)
 template <bool TF, bool REUSE = false>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     static_assert(!REUSE, "majorant reuse is written for VR_MARCH_STEPS == 2");
