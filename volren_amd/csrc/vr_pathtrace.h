@@ -77,6 +77,16 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #ifndef VR_BATCH_REGS
 #define VR_BATCH_REGS 1
 #endif
+// Instruction-arbiter priority (s_setprio) of a wavefront while it runs the hot pair / its event batches (round 5).  A SIMD's four wavefronts compete for the
+// issue slots; the hot pair is short dependent chains that the issue-bound kernels live on, an event batch is long latency chains (cold line, nine table
+// levels, texels) that lose little by waiting a cycle.  Hot pair above events (1 / 0): c2 +0.6 ... +1 %, c3 +1.9 %, c5full +1 %, c4 and c5cloud +-0
+// (2 / 1, 3 / 0, 3 / 1 the same within the noise; events ABOVE the hot pair: c2 -0.4 %, c4 +0.5 %): profiles/r5i_*, r5j_*.
+#ifndef VR_PRIO_HOT
+#define VR_PRIO_HOT 1
+#endif
+#ifndef VR_PRIO_EVENTS
+#define VR_PRIO_EVENTS 0
+#endif
 #ifndef VR_EMISSION_BY_POINTER
 #define VR_EMISSION_BY_POINTER 1
 #endif
@@ -505,6 +515,7 @@ pathtrace_kernel(const KernelArgs A) {
 
     const unsigned long long t_begin_rt = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t iters = 0u, idle_iters = 0u;     // scheduler iterations: in all (statistics), since the last finished path or pulled unit (watchdog)
+    if (VR_PRIO_EVENTS != VR_PRIO_HOT) __builtin_amdgcn_s_setprio(VR_PRIO_HOT);      // (the priority the loop starts with)
     uint32_t t_last = (uint32_t)__builtin_readcyclecounter(), t_elapsed = 0u;
     uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
@@ -628,6 +639,7 @@ pathtrace_kernel(const KernelArgs A) {
 #ifndef VR_HOT_PAIRS
 #define VR_HOT_PAIRS 4
 #endif
+
 #ifndef VR_HOT_PAIR_MIN
 #define VR_HOT_PAIR_MIN 44
 #endif
@@ -745,6 +757,7 @@ pathtrace_kernel(const KernelArgs A) {
             __builtin_amdgcn_wave_barrier();
             Hot& b = l;
 #endif
+            if (VR_PRIO_EVENTS != VR_PRIO_HOT) __builtin_amdgcn_s_setprio(VR_PRIO_EVENTS);
             if (want_esc) {
                 n = min(64, cnt_esc);
                 VR_STAT(ST_ESCAPE, n);
@@ -873,6 +886,7 @@ pathtrace_kernel(const KernelArgs A) {
             if (my_slot >= 0) { hs.load_resume(l, my_slot); l.majorant = my_majorant; if (emission_on && !l.shadow) { const ColdT c = VR_COLD(my_slot); l.ethr = ld3(c, C_THR); l.eL = ld3(c, C_L); } }
 #endif
         }
+        if (VR_PRIO_EVENTS != VR_PRIO_HOT) __builtin_amdgcn_s_setprio(VR_PRIO_HOT);
         VR_SECTION(3);                                                   // batch decision + event batches (the events' own cycles are in st_cyc)
 #if VR_STAT_SCHED
         t_tail = t_sec;
