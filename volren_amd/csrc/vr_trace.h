@@ -198,8 +198,15 @@ VR_HD TapData tap_load(const GridView& g, TapAddr a) {
         const uint32_t line = pair_voxel_line(a.off);
         const uint8_t* ln = g.atlas + ((size_t)a.cell * kPairBlockBytes + (size_t)(line * 128u));
         const float* rec = reinterpret_cast<const float*>(ln) + (PAIR == 2 ? 2 : 0);
+#if defined(VR_TAP_NT) && defined(__HIP_DEVICE_COMPILE__)
+        // build-time experiment (round 5): the paired atlas of a large grid streams through the L2 (450 MB touched on c5cloud); non-temporal taps would leave the L2
+        // to the majorant and environment tables
+        d.rmin = __builtin_nontemporal_load(rec); d.rdiff = __builtin_nontemporal_load(rec + 1);
+        d.raw = __builtin_nontemporal_load(ln + (kPairLineHeader + 2u * (a.off - line * kPairLineVoxels) + (PAIR == 2 ? 1u : 0u)));
+#else
         d.rmin = rec[0]; d.rdiff = rec[1];
         d.raw = ln[kPairLineHeader + 2u * (a.off - line * kPairLineVoxels) + (PAIR == 2 ? 1u : 0u)];
+#endif
         return d;
     }
     if (grid_is_dense<DENSE>(g)) {
