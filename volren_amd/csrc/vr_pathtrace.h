@@ -114,7 +114,9 @@ __device__ __forceinline__ WorkUnit make_unit(const LaunchDesc& D, int32_t W, ui
 #define VR_HOT_RI 0
 #endif
 #ifndef VR_HOT_STRIDE
-#define VR_HOT_STRIDE (VR_HOT_RI ? 15 : 13)      /* odd: lanes with different slots spread over the LDS banks (12 fields + 1 pad) */
+#define VR_HOT_STRIDE (VR_HOT_RI ? 15 : 12)      /* round 5: 12-dword slots without the pad dword = 188 slots instead of 175 (13-dword, odd stride: rounds 3-4).  With the bookkeeping
+                                                    amortised over up to four passes the larger pool is worth more than the odd stride: c2 +0.6 %, c4 +0.3 %, c5cloud +-0 (profiles/r5l_*);
+                                                    150 slots: c2 -1.7 %, c4 -1.1 %; 1/dir stored again (15 dwords, 152 slots): c2 -1.2 %, c5cloud -3 % */
 #endif
 // Workgroup shape.  Default: four 4-wavefront workgroups per CU.  Build-time experiment (round 3, profiles/r3h_lds_resident_majorants.txt):
 // -DVR_WG_WAVES=16 = ONE workgroup per CU whose 16 wavefronts share nothing but read-only tables in LDS -- the transfer-function LUT once per CU
