@@ -41,8 +41,23 @@ for name, tag, asm, kernel in cfgs:
     if wave.get("SQ_WAVE_CYCLES"):
         j["valu_active_share_of_wave_cycles"] = wave["SQ_ACTIVE_INST_VALU"] / wave["SQ_WAVE_CYCLES"]       # counter: quad-cycles a wavefront spends in VALU instructions / its resident quad-cycles
         j["any_inst_active_share_of_wave_cycles"] = wave["SQ_ACTIVE_INST_ANY"] / wave["SQ_WAVE_CYCLES"]
+    # the budget against the kernel's TIME: SIMD cycles per sample = SIMDs x clock / the kernel's own rate in the committed bench line (HIP events around the kernel)
+    try:
+        bl = json.load(open(os.path.join(root, "profiles/%s_bench.json" % R)))
+        rf = bl["roofline"] if name == "c2" else next(c["roofline"] for c in bl["configs"] if c["name"].split("@")[0] == name)
+        rate = rf["samples_per_launch"] / (rf["kernel_ms"] * 1e-3)
+        simd_cycles = 1024 * 2.4e9 / rate
+        valu_cyc = j["valu_issue_cycles_per_iteration"] * j["iterations_per_sample"] / j["model_over_pmc"]        # scaled to the hardware's instruction count
+        j["simd_cycles_per_sample"] = simd_cycles
+        j["valu_issue_cycles_per_sample"] = valu_cyc
+        j["valu_issue_share_of_kernel_time"] = valu_cyc / simd_cycles
+    except Exception as e:
+        print("no bench line for", name, e)
     out_json[name] = j
     out_txt.append("== %s (%s, %s x %s x %s spp; kernel %s of %s)\n%s" % (name, st["config"], st["width"], st["height"], st["spp"], kernel, asm, "\n".join(l for l in txt.split("\n") if not l.startswith("SIMD cycles available"))))
+    if "simd_cycles_per_sample" in j:
+        out_txt.append("kernel time: %.0f SIMD cycles per sample (1024 SIMDs x 2.4 GHz / the kernel's %.0f Msamples/s, profiles/%s_bench.json) = %.0f cycles of VALU issue (model scaled to the PMC instruction count: %.0f %%) + %.0f cycles in which the SIMD issues no VALU instruction (all four wavefronts waiting on memory, LDS, the scalar unit or a dependency)" % (
+            j["simd_cycles_per_sample"], 1024 * 2.4e3 / j["simd_cycles_per_sample"], R, j["valu_issue_cycles_per_sample"], 100 * j["valu_issue_share_of_kernel_time"], j["simd_cycles_per_sample"] - j["valu_issue_cycles_per_sample"]))
     if "valu_active_share_of_wave_cycles" in j:
         out_txt.append("counter: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = %.3f of a wavefront's resident time in VALU instructions; x 4 resident wavefronts = %.2f VALU pipelines' worth per SIMD, of the %.2f a SIMD sustains at this mix's %.2f cycles per instruction (4 / cycles per instruction) -> VALU issue at %.0f %% of its ceiling\n" % (
             j["valu_active_share_of_wave_cycles"], 4 * j["valu_active_share_of_wave_cycles"], 4.0 / j["cycles_per_valu_op"], j["cycles_per_valu_op"], 100 * j["valu_active_share_of_wave_cycles"] * j["cycles_per_valu_op"]))
