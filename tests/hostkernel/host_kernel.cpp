@@ -55,10 +55,16 @@ void build_grid(HostGrid& g, const Uniforms& u, const float* lut, const uint32_t
         words.insert(words.end(), mips[m - 1], mips[m - 1] + cnt);
     }
     const uint32_t k = (uint32_t)(g.view.mshift[0] + g.view.mshift[1] + g.view.mshift[2]);
-    g.majorant.assign(majorant_padded_cells(k), 0.0f);
-    g.majorant16.assign(majorant_padded_cells(k), 0);
+    g.majorant.assign(majorant_table_cells(k), 0.0f);
+    g.majorant16.assign(majorant_table_cells(k), 0);
+    g.view.maj_outside = (int32_t)majorant_padded_cells(k);
     if (density) {
         SceneParams P{}; P.u = u; P.tf_lut = lut;
+        {   // == majorant_kernel: every cell without a range word (beyond the real extent, missing level, the "outside" cell) holds density_scale * 0, TF-remapped
+            float m0 = u.vol_density_scale * half2float(0u);
+            if (u.use_tf) { float rgba[4]; tf_lookup(P, m0 * u.vol_inv_majorant, rgba); m0 = u.vol_majorant * rgba[3]; }
+            g.majorant.assign(majorant_table_cells(k), m0);
+        }
         for (int mip = 0; mip <= n_mips; ++mip) {            // == majorant_kernel of vr_kernels.hip
             const uint32_t rnd = (1u << mip) - 1u;
             const uint32_t dx = (nb[0] + rnd) >> mip, dy = (nb[1] + rnd) >> mip, dz = (nb[2] + rnd) >> mip;

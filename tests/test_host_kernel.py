@@ -222,3 +222,19 @@ def test_harness_under_ubsan():
     ) % (scenes.ROOT, scenes.ROOT + "/tests", so)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_transfer_function_that_is_opaque_at_zero_density():
+    """A LUT whose alpha at density 0 is not 0: the reference's majorant of a cell without data -- beyond a level's real extent, outside the grid -- is then
+    vol_majorant * tf_lookup(0).a, not 0 (common.glsl:278-281, 425: the out-of-range texelFetch returns 0 and goes through the transfer function).  The
+    majorant table holds that value in those cells and in its last one, which a DDA step outside the padded box reads (vr_scene.h majorant_table_cells)."""
+    rs = np.random.RandomState(5)
+    lut = rs.uniform(0, 1, (16, 4)).astype(np.float32)
+    lut[:, 3] = np.sort(lut[:, 3])[::-1]                  # most opaque where the density is lowest
+    r = scenes.oracle_scene("c2", 40, 40)
+    r.set_transferfunc(lut)
+    r.tf_window_left, r.tf_window_width = -0.2, 0.9
+    want = r.render(6).copy()
+    got, steps = hk.render(r, 6)
+    assert steps > 0
+    assert _same(got, want), "relative L2 %.3e" % scenes.rel_l2(got[..., :3], want[..., :3])

@@ -23,7 +23,7 @@
 
 using namespace vr;
 #if VR_TAP_ABS_BAND
-#define VR_BAND_TEXT "absolute, 160 units of k s, round 5's form"
+#define VR_BAND_TEXT "absolute, 160 units of k s, round 5's form; draws and weights scaled by kTapDrawScale"
 #else
 #define VR_BAND_TEXT "2^-18 relative, round 2's form"
 #endif
@@ -48,9 +48,14 @@ template <class Pred> static inline int64_t first_k(double k0, Pred pred) {
     return k;
 }
 
+#if VR_TAP_ABS_BAND
+static const float KS = kTapDrawScale;                       // a draw enters the product's test as KS x k (vr_trace.h VR_TAP_PRESHIFT): exact, k < 2^24
+#else
+static const float KS = 1.0f;
+#endif
 static inline int decide(float k, float w, float s) {         // the product's test: 1 yes, 0 no, 2 inside the band
     bool yes, no;
-    tricubic_fast_test(k, w, s, yes, no);
+    tricubic_fast_test(k * KS, w, s, yes, no);
     if (yes && no) return -1;
     return yes ? 1 : (no ? 0 : 2);
 }
@@ -78,12 +83,12 @@ int main(int argc, char** argv) {
             // both decision sets are intervals of k: the fast test's x(k) (RN(k s) against two thresholds in round 2's form, RN(k s - W) against -G / +G in
             // round 5's) is monotone in k.  The product's own test function is what is searched: first k that is NOT a yes, first k that IS a no
 #if VR_TAP_ABS_BAND
-            const double g_yes = ((double)w - (double)kTapBand) / (double)s, g_no = ((double)w + (double)kTapBand) / (double)s;
+            const double g_yes = ((double)w - (double)kTapBand) / (double)s / (double)KS, g_no = ((double)w + (double)kTapBand) / (double)s / (double)KS;
 #else
             const double g_yes = (double)fma_(w, kTapLo, -1e-20f) / (double)s, g_no = (double)fma_(w, kTapHi, 1e-20f) / (double)s;
 #endif
-            const int64_t K_yes = first_k(g_yes, [w, s](float k) { bool y, n; tricubic_fast_test(k, w, s, y, n); return !y; });
-            const int64_t K_no = first_k(g_no, [w, s](float k) { bool y, n; tricubic_fast_test(k, w, s, y, n); return n; });
+            const int64_t K_yes = first_k(g_yes, [w, s](float k) { bool y, n; tricubic_fast_test(k * KS, w, s, y, n); return !y; });
+            const int64_t K_no = first_k(g_no, [w, s](float k) { bool y, n; tricubic_fast_test(k * KS, w, s, y, n); return n; });
             // cross-check the interval picture with the product's own test function at the boundaries
             if (K_yes > 0 && decide((float)(K_yes - 1), fw[j], s) != 1) ++violations;
             if (K_yes < (int64_t)TWO24 && decide((float)K_yes, fw[j], s) == 1) ++violations;
@@ -93,7 +98,7 @@ int main(int argc, char** argv) {
             if (K_no < K_ref) { ++violations; ++decided_wrong_no; }
             ++checked;
 #if VR_TAP_ABS_BAND
-            const double T = (double)rw[j] / (double)rs[j], Tf = (double)fw[j] / TWO24 / (double)s;
+            const double T = (double)rw[j] / (double)rs[j], Tf = (double)fw[j] / (TWO24 * (double)KS) / (double)s;
 #else
             const double T = (double)rw[j] / (double)rs[j], Tf = (double)fw[j] / (double)s;
 #endif
@@ -108,6 +113,33 @@ int main(int argc, char** argv) {
         const AxisFast F = tricubic_axis_fast(q);
         if (decide(12345.0f, F.w2, F.s2) != 2 || decide(12345.0f, F.w3, F.s3) != 2 || decide(12345.0f, F.w4, 6.0f) != 2) ++violations;
     }
+    // the whole call, fast form against the reference's code (vr_trace.h tricubic_tap_t<true> / <false>): taps and RNG end state must agree for finite coordinates
+    // (random points and seeds) and for coordinates that are not finite on one, two or all three axes -- a test whose x is NaN drops out of the call's min |x| and
+    // decides "no", which is what the reference's comparison against a NaN quotient decides (VR_TAP_PRESHIFT)
+    long long calls = 0, call_mismatches = 0;
+    {
+        uint32_t st = 0x2545F491u;
+        auto nextu = [&st]() { st ^= st << 13; st ^= st >> 17; st ^= st << 5; return st; };
+        const float special[5] = { INFINITY, -INFINITY, NAN, -NAN, 3.0e38f };
+        for (int it = 0; it < 4000000; ++it) {
+            v3 p = v3{ (float)(nextu() & 0xFFFFFFu) * (1.0f / 65536.0f) - 8.0f, (float)(nextu() & 0xFFFFFFu) * (1.0f / 65536.0f) - 8.0f, (float)(nextu() & 0xFFFFFFu) * (1.0f / 65536.0f) - 8.0f };
+            if (it % 4 == 0) {                                  // every fourth call: 1-3 axes not finite
+                const uint32_t m = 1u + nextu() % 7u;
+                if (m & 1u) p.x = special[nextu() % 5u];
+                if (m & 2u) p.y = special[nextu() % 5u];
+                if (m & 4u) p.z = special[nextu() % 5u];
+            }
+            const uint32_t seed = nextu();
+            uint32_t s_fast = seed, s_ref = seed;
+            int32_t fx, fy, fz, rx, ry, rz;
+            tricubic_tap_t<true>(p, s_fast, fx, fy, fz);
+            tricubic_tap_t<false>(p, s_ref, rx, ry, rz);
+            ++calls;
+            if (fx != rx || fy != ry || fz != rz || s_fast != s_ref) ++call_mismatches;
+        }
+    }
+    violations += call_mismatches;
+    std::printf("whole calls, fast form against the reference's code: %lld calls (a quarter with non-finite coordinates), mismatches %lld\n", calls, call_mismatches);
     (void)worst_t;
     std::printf("stride %u: %lld (t, test) pairs checked, violations %lld (fast yes where the reference says no: %lld, fast no where it says yes: %lld)\n",
                 stride, checked, violations, decided_wrong_yes, decided_wrong_no);

@@ -142,7 +142,7 @@ static void set_layout(BrickGridHIP& out) {
         throw std::runtime_error("grid upload: more than 2^30 bricks");
     if ((uint64_t)out.nb[1] * out.nb[2] >= (1ull << 24) || out.nb[0] >= (1 << 24))
         throw std::runtime_error("grid upload: brick counts beyond the 24-bit index arithmetic of the kernels (n_bricks.y * n_bricks.z < 2^24)");
-    const size_t cells = majorant_padded_cells((uint32_t)(out.mshift[0] + out.mshift[1] + out.mshift[2]));
+    const size_t cells = majorant_table_cells((uint32_t)(out.mshift[0] + out.mshift[1] + out.mshift[2]));
     out.majorant = make_device_buffer(cells * sizeof(float));
     out.majorant16 = make_device_buffer(cells * sizeof(uint16_t));
 }
@@ -337,6 +337,7 @@ static GridView make_view(const BrickGridHIP& g, bool paired = false, bool maj_b
     for (int i = 0; i < 3; ++i) { v.mshift[i] = g.mshift[i]; v.mlim[i] = (float)(8u << g.mshift[i]); }
     v.n_mips = g.n_mips;
     v.maj_blocked = maj_blocked ? 1 : 0;         // the layout the majorant table is (re)built in and the kernel variant reads (vr_kernels.hip pathtrace_variant)
+    v.maj_outside = (int32_t)majorant_padded_cells((uint32_t)(g.mshift[0] + g.mshift[1] + g.mshift[2]));
     return v;
 }
 

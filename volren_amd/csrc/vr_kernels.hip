@@ -403,7 +403,7 @@ struct MajorantLayout { int32_t nb[3], mip_off[4], n_mips, mshift[3], blocked; }
 __global__ void __launch_bounds__(256)
 majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, const MajorantLayout L, uint32_t n_padded, float* __restrict__ out, uint16_t* __restrict__ out16) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_padded) return;
+    if (i > n_padded) return;                                 // cell n_padded: "outside the grid" (vr_scene.h majorant_table_cells)
     const uint32_t k = (uint32_t)(L.mshift[0] + L.mshift[1] + L.mshift[2]);
     uint32_t mip = 0u;
     while (mip < 3u && i >= majorant_level_offset(k, mip + 1u)) ++mip;
@@ -418,16 +418,16 @@ majorant_kernel(const SceneParams P, const uint32_t* __restrict__ range_words, c
     } else { cx = j & ((1u << sx) - 1u); cy = (j >> sx) & ((1u << sy) - 1u); cz = j >> (sx + sy); }
     const uint32_t rnd = (1u << mip) - 1u;
     const uint32_t dx = ((uint32_t)L.nb[0] + rnd) >> mip, dy = ((uint32_t)L.nb[1] + rnd) >> mip, dz = ((uint32_t)L.nb[2] + rnd) >> mip;
-    float m = 0.0f;
+    // a cell beyond the level's real extent, a level the grid does not have and the table's last cell read what the reference's out-of-range texelFetch
+    // returns, 0, and go through the same arithmetic: density_scale * 0, TF-remapped when a LUT is bound (common.glsl:278-281, 425)
     uint32_t h = 0u;
-    if ((int32_t)mip <= L.n_mips && cx < dx && cy < dy && cz < dz) {
+    if (i < n_padded && (int32_t)mip <= L.n_mips && cx < dx && cy < dy && cz < dz)
         h = range_words[(uint32_t)L.mip_off[mip] + (cz * dy + cy) * dx + cx] >> 16;
-        m = P.u.vol_density_scale * half2float(h);
-        if (P.u.use_tf) {
-            float rgba[4];
-            tf_lookup(P, m * P.u.vol_inv_majorant, rgba);
-            m = P.u.vol_majorant * rgba[3];
-        }
+    float m = P.u.vol_density_scale * half2float(h);
+    if (P.u.use_tf) {
+        float rgba[4];
+        tf_lookup(P, m * P.u.vol_inv_majorant, rgba);
+        m = P.u.vol_majorant * rgba[3];
     }
     out[i] = m;
     out16[i] = (uint16_t)h;
@@ -440,7 +440,7 @@ void launch_majorants(const SceneParams& P, const uint32_t* range_words_all_mips
     for (int i = 0; i < 4; ++i) L.mip_off[i] = mip_off[i];
     L.n_mips = n_mips;
     const uint32_t n = (uint32_t)majorant_padded_cells((uint32_t)(mshift[0] + mshift[1] + mshift[2]));
-    hipLaunchKernelGGL(majorant_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, P, range_words_all_mips, L, n, out_padded, out16_padded);
+    hipLaunchKernelGGL(majorant_kernel, dim3((n + 256u) / 256u), dim3(256), 0, stream, P, range_words_all_mips, L, n, out_padded, out16_padded);      // n + 1 cells
 }
 
 // ---------------------------------------------------------------------------------------------------

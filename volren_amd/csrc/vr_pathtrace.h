@@ -272,6 +272,8 @@ constexpr size_t kColdMainFloats = (size_t)kMaxWorkgroups * 4u * (size_t)kColdWa
 // the lanes for which `cond` holds; the builtin takes the i1 as it is (HIP's __ballot goes through an int: v_cndmask + v_cmp per call)
 __device__ __forceinline__ uint64_t wave_ballot(bool cond) { return __builtin_amdgcn_ballot_w64(cond); }
 __device__ __forceinline__ int32_t popc(uint64_t mask) { return (int32_t)__popcll(mask); }     // int: min(long long, int) would go through double
+// the same as one scalar instruction the optimiser cannot widen: `popc(m) < constant` otherwise becomes a 64-bit compare, which only the VECTOR unit has (v_cmp_lt_u64)
+__device__ __forceinline__ int32_t popc_s(uint64_t mask) { int32_t r; asm("s_bcnt1_i32_b64 %0, %1" : "=s"(r) : "s"(mask) : "scc"); return r; }
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -471,7 +473,7 @@ pathtrace_kernel(const KernelArgs A) {
     int32_t maj_first = 0x7FFFFFFF;
     if (kMajCells > 0) {
         const uint32_t k = (uint32_t)(P.density.mshift[0] + P.density.mshift[1] + P.density.mshift[2]);
-        const int32_t maj_end = (int32_t)majorant_padded_cells(k);
+        const int32_t maj_end = (int32_t)majorant_table_cells(k);         // the "outside" cell included
         maj_first = maj_end;
 #pragma unroll
         for (int mip = 3; mip >= 0; --mip) {
@@ -645,9 +647,19 @@ pathtrace_kernel(const KernelArgs A) {
 #ifndef VR_HOT_PAIR_MIN
 #define VR_HOT_PAIR_MIN 44
 #endif
+        // VR_BALLOT_VALID (round 5): `slot` does not change inside the hot pair, so "the lane holds a path" is ONE ballot per scheduler iteration and the pair's
+        // counts are ballots of a single compare ANDed with it on the scalar unit; a ballot of `slot >= 0 && state == X` costs a v_cndmask + v_cmp more each
+#ifndef VR_BALLOT_VALID
+#define VR_BALLOT_VALID 1
+#endif
+        const uint64_t holds_path = wave_ballot(slot >= 0);
 #pragma unroll
         for (int hot_rep_ = 0; hot_rep_ < VR_HOT_PAIRS; ++hot_rep_) {
+#if VR_BALLOT_VALID
+            if (hot_rep_ > 0 && popc_s(holds_path & wave_ballot((uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) break;
+#else
             if (hot_rep_ > 0 && popc(wave_ballot(slot >= 0 && (uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) break;
+#endif
             if (STATS) t_blk = __builtin_readcyclecounter();
             const bool is_m = slot >= 0 && l.state == ST_MARCH;
 #if VR_MARCH_SPECULATIVE
@@ -687,8 +699,13 @@ pathtrace_kernel(const KernelArgs A) {
             // A wavefront that is running dry (end of the launch: a handful of deep paths) must not make them wait for each other:
             // the threshold is at most half the lanes that hold a marching or colliding path.
             const bool is_c = slot >= 0 && l.state == ST_COLLIDE;
+#if VR_BALLOT_VALID
+            const int32_t n_c = popc(holds_path & wave_ballot(l.state == ST_COLLIDE));
+            const int32_t n_m = popc(holds_path & wave_ballot(l.state == ST_MARCH));
+#else
             const int32_t n_c = popc(wave_ballot(is_c));
             const int32_t n_m = popc(wave_ballot(slot >= 0 && l.state == ST_MARCH));
+#endif
             if (n_c > 0 && n_c >= min(VR_THR_COLLIDE, (n_c + n_m + 1) >> 1)) {
                 CollideIO<K> cio;
                 collide_idle<K>(cio);

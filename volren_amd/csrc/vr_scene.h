@@ -32,6 +32,10 @@ VR_SCENE_HD int32_t ceil_log2(uint32_t v) { int32_t s = 0; while (s < 31 && (1u 
 // offset of level m = S0 * (0, 1, 9/8, 73/64)[m], S0 = 2^k cells on level 0 (k >= 9)
 VR_SCENE_HD uint32_t majorant_level_offset(uint32_t k, uint32_t mip) { const uint32_t s = 9u - 3u * mip; return ((0x49u >> s) << s) << (k - 6u); }
 VR_SCENE_HD size_t majorant_padded_cells(uint32_t k) { return (size_t)majorant_level_offset(k, 3u) + ((size_t)1 << (k - 9u)); }
+// The table has one cell more than its levels, at index majorant_padded_cells(k) (GridView::maj_outside): the answer to "outside the grid" -- what the reference's
+// lookup_majorant makes of an out-of-range texelFetch, density_scale * 0, TF-remapped when a LUT is bound (common.glsl:278-281, 425).  A DDA step outside the
+// padded box reads that cell instead of selecting 0 after the load (round 5: one clamp, one compare and one select less per step).
+VR_SCENE_HD size_t majorant_table_cells(uint32_t k) { return majorant_padded_cells(k) + 1u; }
 // Cell (cx, cy, cz) of level `mip` inside its level.  Linear: x fastest with power-of-two pitches.  Blocked (GridView::maj_blocked,
 // used for the large tables of dense grids): levels 0 and 1 -- at least 4 cells per axis -- are stored as 4x4x4-cell blocks of 64
 // consecutive cells (128 bytes of fp16 = one cache line), so that a DDA step to ANY neighbouring cell usually stays in the line;
@@ -136,6 +140,7 @@ struct GridView {
     float mlim[3];               // the same extent in voxels, (float)(8 << mshift[i]): the inside test of the DDA compares against it
     int32_t n_mips;              // range mips available above level 0 (reference: 3)
     int32_t maj_blocked;         // majorant levels 0 and 1 in 4x4x4-cell blocks (majorant_cell_index): set for dense grids
+    int32_t maj_outside;         // index of the table's last cell, which holds the majorant of "outside the grid" (majorant_table_cells)
     const uint16_t* dense;       // dense fp16 voxels in 4x4x4 blocks of 128 contiguous bytes (one cache line): block (x>>2, y>>2, z>>2),
                                  // x fastest over dblk[0] x dblk[1] x ceil(dim.z/4) blocks, voxel (x&3) + 4*(y&3) + 16*(z&3) inside; or nullptr
     int32_t dim[3];              // voxel extent of the dense grid

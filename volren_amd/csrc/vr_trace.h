@@ -134,9 +134,14 @@ template <class Cold> VR_HD void stu(Cold& c, int32_t f, uint32_t v) { c.st(f, u
 
 // ---------------------------------------------------------------------------------------------------
 // RNG  (common.glsl:40-67)
+// Fully unrolled on the device (round 5): the round's key schedule s0 = n * delta folds into the literal of ONE add per half-round (v1 + s0 + k would otherwise be an
+// add with the loop's scalar register -- 0.9 cycles dearer than a literal operand on gfx950 -- and a second one): 6 instead of 7 instructions per half-round, 384 in all
+#ifndef VR_TEA_UNROLL
+#define VR_TEA_UNROLL 32
+#endif
 VR_HD uint32_t tea32(uint32_t v0, uint32_t v1) {
     uint32_t s0 = 0u;
-#pragma unroll 4
+#pragma unroll VR_TEA_UNROLL
     for (int n = 0; n < 32; ++n) {
         s0 += 0x9e3779b9u;
         v0 += ((v1 << 4) + 0xA341316Cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xC8013EA4u);
@@ -250,6 +255,12 @@ VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
 // The padded layout (vr_scene.h) holds 0 in every cell beyond the real extent of a level, so only the padded extent -- the
 // same for all levels -- is tested, on the floats (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails), after
 // which truncation equals floor.
+// VR_MAJ_OUTSIDE_CELL (round 5, default): "outside" is the index of the table's last cell, which holds what the reference computes there (vr_scene.h
+// majorant_table_cells), instead of -1 with the loaded value replaced by 0 afterwards: the load needs no clamp and the value no compare + select.  Either way the
+// arithmetic on the value is the reference's: density_scale * 0 outside.  0: the -1 convention (kept for the A/B, profiles/r5o_*)
+#ifndef VR_MAJ_OUTSIDE_CELL
+#define VR_MAJ_OUTSIDE_CELL 1
+#endif
 template <int DENSE = 2, int MAJB = 2>
 VR_HD int32_t majorant_index(const GridView& g, v3 ipos, int32_t mip) {
     const bool inside = (mip <= g.n_mips) & (ipos.x >= 0.0f) & (ipos.x < g.mlim[0]) & (ipos.y >= 0.0f) & (ipos.y < g.mlim[1]) & (ipos.z >= 0.0f) & (ipos.z < g.mlim[2]);
@@ -260,22 +271,30 @@ VR_HD int32_t majorant_index(const GridView& g, v3 ipos, int32_t mip) {
     // the layout majorant_kernel wrote the table in (GridView::maj_blocked, a property of the grid since round 5): known at compile time in the kernels built
     // for one layout -- a kernel is only launched on grids of its layout (vr_kernels.hip pathtrace_variant) -- read from the view otherwise (wave-uniform)
     const bool blocked = MAJB == 2 ? g.maj_blocked != 0 : MAJB == 1;
-    return inside ? (int32_t)(off + majorant_cell_index(bx, by, bz, sx, sy, (uint32_t)mip, blocked)) : -1;
+    return inside ? (int32_t)(off + majorant_cell_index(bx, by, bz, sx, sy, (uint32_t)mip, blocked)) : (VR_MAJ_OUTSIDE_CELL ? g.maj_outside : -1);
 }
 // Unconditional load (cell 0 when outside; the caller discards it then).  TF kernels read the float table (TF-remapped
 // majorants); the others read the raw fp16 range maximum -- half the cache lines -- and scale it themselves (majorant_value).
 template <bool TF>
 VR_HD uint32_t majorant_fetch(const GridView& g, int32_t idx) {
-    const int32_t i = idx < 0 ? 0 : idx;
+    const int32_t i = VR_MAJ_OUTSIDE_CELL ? idx : (idx < 0 ? 0 : idx);
+#if VR_MAJ_OUTSIDE_CELL && defined(__clang__)
+    __builtin_assume(i >= 0 && i <= (1 << 30));      // a table index (set_layout: at most 2^30 cells): the address is base + a 32-bit byte offset, no 64-bit arithmetic
+#endif
     return TF ? f2u(g.majorant[i]) : (uint32_t)g.majorant16[i];
 }
 template <bool TF>
 VR_HD float majorant_value(const SceneParams& P, uint32_t raw) { return TF ? u2f(raw) : P.u.vol_density_scale * half2float(raw); }
+// the majorant of a step from the word march_load fetched for cell `idx`
+template <bool TF>
+VR_HD float majorant_of(const SceneParams& P, int32_t idx, uint32_t raw) {
+    const float m = majorant_value<TF>(P, raw);
+    return VR_MAJ_OUTSIDE_CELL ? m : (idx >= 0 ? m : 0.0f);
+}
 template <bool TF, int DENSE = 2, int MAJB = 2>
 VR_HD float majorant_at(const SceneParams& P, v3 ipos, int32_t mip) {
     const int32_t idx = majorant_index<DENSE, MAJB>(P.density, ipos, mip);
-    const float m = majorant_value<TF>(P, majorant_fetch<TF>(P.density, idx));
-    return idx < 0 ? 0.0f : m;
+    return majorant_of<TF>(P, idx, majorant_fetch<TF>(P.density, idx));
 }
 // a NaN coordinate must read "outside": on the device voxel_index turns NaN into index o, so one index is forced negative
 VR_HD int32_t nan_guard(int32_t ix, float fx, float fy, float fz) {
@@ -416,9 +435,22 @@ constexpr LcgJump lcg_jump(int j) {
 #ifndef VR_TAP_ABS_BAND
 #define VR_TAP_ABS_BAND 1
 #endif
+// VR_TAP_PRESHIFT (round 5, default): the nine draws are taken from the LCG state SHIFTED LEFT BY 8 -- multiplying the recurrence by 2^8 commutes with it mod 2^32, and
+// the top 24 bits of the shifted state are the draw's 24 bits, so its conversion to float is 2^8 k exactly (24 significant bits) and the mask per draw is gone.  The
+// weights and the band carry the same factor (all of it powers of two: every rounding of the evaluation commutes with it, x' = 2^8 x bit for bit).  And a call
+// needs the exact code when the SMALLEST |x| of its nine tests lies inside the band: min(|x|) chained through the tests (min3 for two of them) and ONE compare,
+// instead of a second compare per test.  A test whose x is NaN (a non-finite coordinate on that axis) drops out of the minimum and decides "no" -- what the exact
+// code's comparisons against NaN quotients decide for that axis as well.
+#ifndef VR_TAP_PRESHIFT
+#define VR_TAP_PRESHIFT 1
+#endif
+#ifndef VR_TAP_CHAIN
+#define VR_TAP_CHAIN 0
+#endif
 #if VR_TAP_ABS_BAND
-struct AxisFast { float w2, s2, w3, s3, w4, fl; };      // w*: 2^24 x 6 x the weights; s*: 6 x the partial sums (s4 = 6)
-constexpr float kTapScale = 16777216.0f, kTapInvScale = 1.0f / 16777216.0f, kTapBand = 160.0f;
+struct AxisFast { float w2, s2, w3, s3, w4, fl; };      // w*: 2^24 x 6 x the weights (2^32 x with VR_TAP_PRESHIFT); s*: 6 x the partial sums (s4 = 6)
+constexpr float kTapDrawScale = VR_TAP_PRESHIFT ? 256.0f : 1.0f;        // a draw enters its test as kTapDrawScale x k, k its 24 bits
+constexpr float kTapScale = 16777216.0f * kTapDrawScale, kTapInvScale = 1.0f / kTapScale, kTapBand = 160.0f * kTapDrawScale;
 VR_HD AxisFast tricubic_axis_fast(float q) {
     AxisFast a;
     a.fl = floor_(q);
@@ -467,15 +499,19 @@ VR_HD void tricubic_fast_test(float k, float w, float s, bool& yes, bool& no) {
 #endif
 #endif
 
-VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) {
+// FAST: the guarded fast decision first, the reference's code only for a call with a draw inside a band (the device; the host harness can switch it on);
+// otherwise the reference's code always.  Both are compiled everywhere: tests/tools_tricubic_band.cpp runs one against the other.
+template <bool FAST>
+VR_HD void tricubic_tap_t(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) {
     int32_t jx = 0, jy = 0, jz = 0;
+    float flx, fly, flz;
 #if VR_FAST_DEVICE
     // tolerance mode: draw j is k_j * 2^-24 and "r_j < w / s" is taken as k_j * s < w * 2^24, unguarded (one rounding apart
     // from the reference's quotient; a decision flips only when the draw lands within that rounding of the threshold)
     const AxisWeights ax = tricubic_axis_weights(ipos.x - 0.5f);
     const AxisWeights ay = tricubic_axis_weights(ipos.y - 0.5f);
     const AxisWeights az = tricubic_axis_weights(ipos.z - 0.5f);
-    const float flx = ax.fl, fly = ay.fl, flz = az.fl;
+    flx = ax.fl; fly = ay.fl; flz = az.fl;
     {
         const uint32_t lo24 = seed & 0x00FFFFFFu;
 #define VR_TAPF(J, V, W, S, N) do { \
@@ -490,31 +526,66 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
         rng_skip9(seed);
     }
 #else
-#if VR_TAP_FAST
-    // a draw only uses the low 24 bits of the state, and those of state_j = A_j * seed + C_j only need the low 24 bits of seed and
-    // A_j: one 24-bit multiply-add per draw instead of a chained 32-bit multiply
-    const AxisFast fx = tricubic_axis_fast(ipos.x - 0.5f), fy = tricubic_axis_fast(ipos.y - 0.5f), fz = tricubic_axis_fast(ipos.z - 0.5f);
-    const float flx = fx.fl, fly = fy.fl, flz = fz.fl;
-    const uint32_t seed0 = seed, lo24 = seed & 0x00FFFFFFu;
-    bool unsure = false;
-#define VR_TAP(J, V, W, S, N) do { \
-        constexpr LcgJump g_ = lcg_jump(N); \
-        bool yes_, no_; \
-        tricubic_fast_test((float)((mul24(lo24, g_.A & 0x00FFFFFFu) + g_.C) & 0x00FFFFFFu), W, S, yes_, no_); \
-        J = yes_ ? V : J; \
-        unsure = unsure | !(yes_ | no_); \
-    } while (0)
-    VR_TAP(jx, 1, fx.w2, fx.s2, 1); VR_TAP(jy, 1, fy.w2, fy.s2, 2); VR_TAP(jz, 1, fz.w2, fz.s2, 3);
-    VR_TAP(jx, 2, fx.w3, fx.s3, 4); VR_TAP(jy, 2, fy.w3, fy.s3, 5); VR_TAP(jz, 2, fz.w3, fz.s3, 6);
-    VR_TAP(jx, 3, fx.w4, 6.0f, 7); VR_TAP(jy, 3, fy.w4, 6.0f, 8); VR_TAP(jz, 3, fz.w4, 6.0f, 9);
-#undef VR_TAP
-    rng_skip9(seed);
-    if (unsure) {
-        seed = seed0; jx = jy = jz = 0;
+    bool exact = true;
+    if constexpr (FAST) {
+        // a draw only uses the low 24 bits of the state, and those of state_j = A_j * seed + C_j only need the low 24 bits of seed and
+        // A_j: one 24-bit multiply-add per draw instead of a chained 32-bit multiply
+        const AxisFast fx = tricubic_axis_fast(ipos.x - 0.5f), fy = tricubic_axis_fast(ipos.y - 0.5f), fz = tricubic_axis_fast(ipos.z - 0.5f);
+        flx = fx.fl; fly = fy.fl; flz = fz.fl;
+        const uint32_t seed0 = seed;
+#if VR_TAP_ABS_BAND && VR_TAP_PRESHIFT
+        const uint32_t sh8 = seed << 8;
+        float amin = __builtin_inff();                               // the smallest |x| of the nine tests
+#if VR_TAP_CHAIN
+        // the nine shifted states one from the other, st_j = a st_(j-1) + 2^8 c: ONE multiplier in a scalar register instead of nine jump-ahead constants (the
+        // kernels are short of scalar registers: the brick kernel re-loaded the atlas pointer from the kernel arguments in every collision pass).  The empty asm
+        // keeps the optimiser from folding the chain back into nine constants.
+        uint32_t st_ = sh8;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VR_TAP_KEEP(X) asm("" : "+v"(X))
 #else
-    const float flx = floor_(ipos.x - 0.5f), fly = floor_(ipos.y - 0.5f), flz = floor_(ipos.z - 0.5f);
-    {
+#define VR_TAP_KEEP(X) do { } while (0)
 #endif
+#define VR_TAP(J, V, W, S, N) do { \
+            st_ = st_ * 1664525u + (1013904223u << 8); \
+            VR_TAP_KEEP(st_); \
+            const float x_ = fma_((float)st_, S, -(W));     /* tricubic_fast_test's x for the draw 2^8 k */ \
+            J = x_ < -kTapBand ? V : J; \
+            amin = __builtin_fminf(amin, __builtin_fabsf(x_)); \
+        } while (0)
+#else
+#define VR_TAP(J, V, W, S, N) do { \
+            constexpr LcgJump g_ = lcg_jump(N); \
+            const float x_ = fma_((float)(sh8 * g_.A + (g_.C << 8)), S, -(W));     /* tricubic_fast_test's x for the draw 2^8 k */ \
+            J = x_ < -kTapBand ? V : J; \
+            amin = __builtin_fminf(amin, __builtin_fabsf(x_)); \
+        } while (0)
+#endif
+#else
+        const uint32_t lo24 = seed & 0x00FFFFFFu;
+        bool unsure = false;
+#define VR_TAP(J, V, W, S, N) do { \
+            constexpr LcgJump g_ = lcg_jump(N); \
+            bool yes_, no_; \
+            tricubic_fast_test((float)((mul24(lo24, g_.A & 0x00FFFFFFu) + g_.C) & 0x00FFFFFFu), W, S, yes_, no_); \
+            J = yes_ ? V : J; \
+            unsure = unsure | !(yes_ | no_); \
+        } while (0)
+#endif
+        VR_TAP(jx, 1, fx.w2, fx.s2, 1); VR_TAP(jy, 1, fy.w2, fy.s2, 2); VR_TAP(jz, 1, fz.w2, fz.s2, 3);
+        VR_TAP(jx, 2, fx.w3, fx.s3, 4); VR_TAP(jy, 2, fy.w3, fy.s3, 5); VR_TAP(jz, 2, fz.w3, fz.s3, 6);
+        VR_TAP(jx, 3, fx.w4, 6.0f, 7); VR_TAP(jy, 3, fy.w4, 6.0f, 8); VR_TAP(jz, 3, fz.w4, 6.0f, 9);
+#undef VR_TAP
+#if VR_TAP_ABS_BAND && VR_TAP_PRESHIFT
+        const bool unsure = !(amin > kTapBand);                      // a test inside the band, or nine NaNs
+#endif
+        rng_skip9(seed);
+        exact = unsure;
+        if (unsure) { seed = seed0; jx = jy = jz = 0; }
+    } else {
+        flx = floor_(ipos.x - 0.5f); fly = floor_(ipos.y - 0.5f); flz = floor_(ipos.z - 0.5f);
+    }
+    if (exact) {
         // the reference's code (common.glsl:221-244)
         const AxisWeights ax = tricubic_axis_weights(ipos.x - 0.5f);
         const AxisWeights ay = tricubic_axis_weights(ipos.y - 0.5f);
@@ -533,6 +604,7 @@ VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32
 #endif
     tx = nan_guard(voxel_index(flx, jx - 1), flx, fly, flz); ty = voxel_index(fly, jy - 1); tz = voxel_index(flz, jz - 1);
 }
+VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) { tricubic_tap_t<VR_TAP_FAST != 0>(ipos, seed, tx, ty, tz); }
 
 // transfer function (common.glsl:203-212)
 // `lut`: tf_size x vec4 -- the SSBO in global memory, or the copy the path-tracing kernel stages in LDS (vr_pathtrace.h)
@@ -853,7 +925,7 @@ constexpr int32_t kMarchSteps = VR_MARCH_STEPS;
 #if VR_MARCH_STEPS == 2
 // the two-step form written out (the default; the generic loop below compiles ~1 % slower for the same arithmetic)
 struct MarchIO { float dt1, dt2, t1; uint32_t maj1, maj2; int32_t i1, i2; bool go1, go2; };     // i*: majorant cell or -1 (outside: majorant 0); maj*: as loaded (majorant_fetch)
-VR_HD void march_idle(MarchIO& io) { io.i1 = io.i2 = -1; io.dt1 = io.dt2 = io.t1 = 0.0f; io.go1 = io.go2 = false; }      // a lane that is not marching
+VR_HD void march_idle(MarchIO& io) { io.i1 = io.i2 = VR_MAJ_OUTSIDE_CELL ? 0 : -1; io.dt1 = io.dt2 = io.t1 = 0.0f; io.go1 = io.go2 = false; }      // a lane that is not marching (its loads: cell 0)
 template <int DENSE = 2, int MAJB = 2>
 VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
     io.go1 = h.t < h.far;
@@ -906,15 +978,15 @@ VR_HD void march_load_lds(const SceneParams& P, MarchIO& io, const T* lds, int32
 template <bool TF, bool REUSE = false>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     if (!io.go1) { h.state = segment_end_state(h.shadow); return; }
-    float t = io.t1, maj = io.i1 >= 0 ? majorant_value<TF>(P, io.maj1) : 0.0f;
+    float t = io.t1, maj = majorant_of<TF>(P, io.i1, io.maj1);
     float tau = h.tau - maj * io.dt1;
     int32_t q = h.mipq < 12 ? h.mipq + 1 : 12;
     // REUSE: the cell whose majorant the lane leaves the pass with (Hot::maj_idx; selects, not conditional stores)
-    if (REUSE) { const bool keep = io.i1 >= 0; h.maj_idx = keep ? io.i1 : h.maj_idx; h.maj_raw = keep ? io.maj1 : h.maj_raw; }
+    if (REUSE) { const bool keep = VR_MAJ_OUTSIDE_CELL || io.i1 >= 0; h.maj_idx = keep ? io.i1 : h.maj_idx; h.maj_raw = keep ? io.maj1 : h.maj_raw; }
     if (tau > 0.0f) {                                              // no tentative collision in the first cell: second step
         if (!io.go2) { h.t = t; h.tau = tau; h.mipq = q; h.state = segment_end_state(h.shadow); return; }
-        maj = io.i2 >= 0 ? majorant_value<TF>(P, io.maj2) : 0.0f;
-        if (REUSE) { const bool keep = io.i2 >= 0; h.maj_idx = keep ? io.i2 : h.maj_idx; h.maj_raw = keep ? io.maj2 : h.maj_raw; }
+        maj = majorant_of<TF>(P, io.i2, io.maj2);
+        if (REUSE) { const bool keep = VR_MAJ_OUTSIDE_CELL || io.i2 >= 0; h.maj_idx = keep ? io.i2 : h.maj_idx; h.maj_raw = keep ? io.maj2 : h.maj_raw; }
         t = io.t1 + io.dt2;
         tau = tau - maj * io.dt2;
         q = q < 12 ? q + 1 : 12;
@@ -935,7 +1007,7 @@ struct MarchIO {
 };
 VR_HD void march_idle(MarchIO& io) {             // a lane that is not marching
 #pragma unroll
-    for (int k = 0; k < kMarchSteps; ++k) { io.idx[k] = -1; io.dt[k] = io.t[k] = 0.0f; io.go[k] = false; }
+    for (int k = 0; k < kMarchSteps; ++k) { io.idx[k] = VR_MAJ_OUTSIDE_CELL ? 0 : -1; io.dt[k] = io.t[k] = 0.0f; io.go[k] = false; }
 }
 template <int DENSE = 2, int MAJB = 2>
 VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
@@ -972,7 +1044,7 @@ VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
 #pragma unroll
     for (int k = 0; k < kMarchSteps; ++k) {
         if (!io.go[k]) { h.t = t; h.tau = tau; h.mipq = q; h.state = segment_end_state(h.shadow); return; }
-        maj = io.idx[k] >= 0 ? majorant_value<TF>(P, io.maj[k]) : 0.0f;
+        maj = majorant_of<TF>(P, io.idx[k], io.maj[k]);
         t = io.t[k];
         tau = tau - maj * io.dt[k];
         q = q < 12 ? q + 1 : 12;
