@@ -164,6 +164,9 @@ FLAG_VARIANTS = {
     "crop": ("c1", dict(vol_clip_min=(0.2, 0.1, 0.0), vol_clip_max=(0.9, 0.6, 1.0))),
     "camera_inside_wide_fov": ("c1", dict(cam_pos=(0.0, -0.2, 0.05), cam_dir=(0.3, 1.0, 0.1), cam_fov=95.0)),
     "camera_top_down": ("c1", dict(cam_pos=(0.0, 2.0, 0.0), cam_dir=(0.0, -1.0, 0.001), cam_up=(0.0, 0.0, 1.0))),
+    # 36 000 volume widths away: the camera segments start at |ipos| > 2^20 voxels -- not "clean" (vr_trace.h seg_clean): wavefronts that hold one run the hot
+    # pair in its general form, the others in the clean form
+    "camera_very_far": ("c2", dict(cam_pos=(3.0e4, 0.5e4, 2.0e4), cam_dir=(-0.8241634368896484, -0.1373605728149414, -0.5494422912597656), cam_fov=0.003)),
     "env_strong_rotated": ("c1", dict(env_strength=7.5, env_rot=123.0)),
     "seed": ("c1", dict(seed=-7)),
     "tf_window": ("c3", dict(tf_window_left=0.05, tf_window_width=0.4)),

@@ -238,3 +238,26 @@ def test_transfer_function_that_is_opaque_at_zero_density():
     got, steps = hk.render(r, 6)
     assert steps > 0
     assert _same(got, want), "relative L2 %.3e" % scenes.rel_l2(got[..., :3], want[..., :3])
+
+
+def _far_camera(r):
+    pos = np.array([3.0e4, 0.5e4, 2.0e4], np.float32)
+    r.cam_pos = tuple(pos.tolist())
+    r.cam_dir = tuple((-pos / np.float32(np.linalg.norm(pos))).astype(np.float32).tolist())
+    r.cam_fov = 0.003
+    return r
+
+
+def test_segments_that_are_not_clean():
+    """vr_trace.h seg_clean: a camera 36 000 volume widths away starts its segments at |ipos| > 2^20 voxels -- not "clean", so they take the general forms of the
+    DDA step / inside test / tap (float compares, NaN guard), while the scatter and shadow segments that begin inside the volume take the clean ones.  Both against
+    the oracle, bit for bit; the volume is hit (alpha > 0) so the segments do march."""
+    r = _far_camera(scenes.oracle_scene("c2", 40, 40))
+    ipos = np.array(r.params().vol_density_inv_transform, np.float32).reshape(4, 4).T @ np.array([*r.cam_pos, 1.0], np.float32)
+    assert np.abs(ipos[:3]).max() > 2.0 ** 20
+    want = r.render(6).copy()
+    assert want[..., 3].max() == 1.0 and want[..., 3].mean() > 0.01
+    for fast_tap in (False, True):
+        got, steps = hk.render(r, 6, fast_tap=fast_tap)
+        assert steps > 0
+        assert _same(got, want), "relative L2 %.3e" % scenes.rel_l2(got[..., :3], want[..., :3])

@@ -653,19 +653,27 @@ pathtrace_kernel(const KernelArgs A) {
 #define VR_BALLOT_VALID 1
 #endif
         const uint64_t holds_path = wave_ballot(slot >= 0);
-#pragma unroll
-        for (int hot_rep_ = 0; hot_rep_ < VR_HOT_PAIRS; ++hot_rep_) {
+        // Clean segments (vr_trace.h seg_clean, round 5): while every path the wavefront holds is on one -- always, outside degenerate scenes -- the pair runs in
+        // its CLEAN form (integer inside test, v_min3 in the DDA step, no NaN guard on the density tap); otherwise ONE pass in the general form.  A lane's path, and
+        // with it the flag in the sign of its `far`, only changes in the resume block above: one ballot per scheduler iteration.
+        // (VR_CLEAN_FORMS=0, the everything-at-run-time variant: the general form only -- a second form costs that kernel registers it does not have)
+#ifndef VR_CLEAN_FORMS
+#define VR_CLEAN_FORMS VR_CLEAN_FLAG
+#endif
+        const bool all_clean = VR_CLEAN_FORMS && (holds_path & wave_ballot((int32_t)f2u(l.far) < 0)) == 0ull;
+        auto hot_pair = [&](auto clean_tag, const int hot_rep_) __attribute__((always_inline)) -> bool {
+            constexpr bool CLEAN = decltype(clean_tag)::value;
 #if VR_BALLOT_VALID
-            if (hot_rep_ > 0 && popc_s(holds_path & wave_ballot((uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) break;
+            if (hot_rep_ > 0 && popc_s(holds_path & wave_ballot((uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) return false;
 #else
-            if (hot_rep_ > 0 && popc(wave_ballot(slot >= 0 && (uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) break;
+            if (hot_rep_ > 0 && popc(wave_ballot(slot >= 0 && (uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) return false;
 #endif
             if (STATS) t_blk = __builtin_readcyclecounter();
             const bool is_m = slot >= 0 && l.state == ST_MARCH;
 #if VR_MARCH_SPECULATIVE
             MarchIO mio;
             march_idle(mio);
-            if (is_m) march_prep<K::dense, K::majb>(l, P, mio);
+            if (is_m) march_prep<K::dense, K::majb, CLEAN>(l, P, mio);
             if constexpr (kMajCells > 0) march_load_lds<K::tf, MajT>(P, mio, lds_maj, maj_first);
             else if constexpr (K::maj_reuse) march_load_reuse<K::tf>(P, mio, l);
             else march_load<K::tf>(P, mio);
@@ -710,7 +718,7 @@ pathtrace_kernel(const KernelArgs A) {
                 CollideIO<K> cio;
                 collide_idle<K>(cio);
                 const SceneParams& PE = VR_EMISSION_BY_POINTER && K::emission != 0 ? event_args().P : P;      // see collide_prep
-                if (is_c) collide_prep<K>(l, P, PE, cio);
+                if (is_c) collide_prep<K, CLEAN>(l, P, PE, cio);
                 collide_load<K>(P, PE, cio);
                 if (is_c) {
                     ColdT c = VR_COLD(slot);
@@ -723,6 +731,18 @@ pathtrace_kernel(const KernelArgs A) {
             // "possibly outstanding" around the loop and waits where nothing is pending
             __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0)
             if (STATS) st_cyc[ST_COLLIDE] += __builtin_readcyclecounter() - t_blk;
+            return true;
+        };
+        if (all_clean) {
+#pragma unroll
+            for (int hot_rep_ = 0; hot_rep_ < VR_HOT_PAIRS; ++hot_rep_) if (!hot_pair(std::true_type{}, hot_rep_)) break;
+        } else {
+#if VR_CLEAN_FORMS
+            hot_pair(std::false_type{}, 0);
+#else
+#pragma unroll
+            for (int hot_rep_ = 0; hot_rep_ < VR_HOT_PAIRS; ++hot_rep_) if (!hot_pair(std::false_type{}, hot_rep_)) break;
+#endif
         }
         VR_SECTION(1);                                                   // hot pair (also in st_cyc[MARCH] + st_cyc[COLLIDE])
         // (3) park paths that reached an event

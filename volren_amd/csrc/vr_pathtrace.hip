@@ -33,6 +33,10 @@
 // instance 8 VGPR spills to scratch memory (profiles/r5_kernel_resources.txt)
 #define VR_HOT_PAIRS 1
 #endif
+#if VR_PT_VARIANT == 3 && !defined(VR_CLEAN_FORMS)
+// ... and the hot pair in its general form only (vr_trace.h seg_clean: the other variants also carry the form for wavefronts whose paths are all on clean segments)
+#define VR_CLEAN_FORMS 0
+#endif
 #include "vr_pathtrace.h"
 
 namespace vr {

@@ -261,16 +261,52 @@ VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
 #ifndef VR_MAJ_OUTSIDE_CELL
 #define VR_MAJ_OUTSIDE_CELL 1
 #endif
-template <int DENSE = 2, int MAJB = 2>
+#ifndef VR_MAJ_LEVEL_TEST
+#define VR_MAJ_LEVEL_TEST 0
+#endif
+// ---- "clean" segments (round 5, VR_CLEAN_FLAG) ------------------------------------------------------------------------------------------------------------
+// begin_segment marks a segment whose ray is finite and of moderate size -- |ipos| < 2^20 and |idir| * far < 2^20 per axis, all comparisons that fail for NaN --
+// in the sign of Hot::far (clean: far as computed, >= 0; not clean: -far; every reader takes |far|, seg_far).  On such a segment every point the trackers
+// evaluate, p = ipos + t * idir with t < far, is finite with |p| < 2^21, and then:
+//   * floor(p) converts to int exactly, so "inside the padded table" is an INTEGER test on the cell coordinates the index needs anyway (three right shifts, an
+//     or3, one compare) instead of six float compares -- same set: 0 <= floor(x) < lim <=> 0 <= x < lim for the integer lim, and -0 is inside either way;
+//   * the three candidates of a DDA step are never NaN (the bracket floor(p / dim) * dim + o - p is exact and its modulus >= 0.5, and 1 / idir is finite or
+//     +-inf, never NaN): min(tx, min(ty, tz)) is ONE v_min3_f32 -- which differs from the reference's comparisons only in what it does with NaN;
+//   * a tap's coordinates are not NaN: no NaN guard on the voxel index.
+// The scheduler (vr_pathtrace.h) runs the hot pair in the CLEAN form while every marching path of the wavefront is clean and in the general form otherwise; the
+// host harness picks the form per path (lane_step), so both are checked against the oracle on the CPU.
+#ifndef VR_CLEAN_FLAG
+#define VR_CLEAN_FLAG 1
+#endif
+constexpr float kCleanBound = 1048576.0f;      // 2^20
+VR_HD float seg_far(const Hot& h) { return VR_CLEAN_FLAG ? abs_(h.far) : h.far; }
+VR_HD bool seg_clean(const Hot& h) { return VR_CLEAN_FLAG ? (int32_t)f2u(h.far) >= 0 : false; }
+// floor(x) as an int for |x| < 2^31 (clean segments: < 2^21)
+VR_HD int32_t cvt_flr(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r;
+#else
+    return (int32_t)floor_(x);
+#endif
+}
+template <int DENSE = 2, int MAJB = 2, bool CLEAN = false>
 VR_HD int32_t majorant_index(const GridView& g, v3 ipos, int32_t mip) {
-    const bool inside = (mip <= g.n_mips) & (ipos.x >= 0.0f) & (ipos.x < g.mlim[0]) & (ipos.y >= 0.0f) & (ipos.y < g.mlim[1]) & (ipos.z >= 0.0f) & (ipos.z < g.mlim[2]);
     const uint32_t sh = 3u + (uint32_t)mip;
-    const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
     const uint32_t sx = (uint32_t)g.mshift[0] - (uint32_t)mip, sy = (uint32_t)g.mshift[1] - (uint32_t)mip;
     const uint32_t off = majorant_level_offset((uint32_t)(g.mshift[0] + g.mshift[1] + g.mshift[2]), (uint32_t)mip);
     // the layout majorant_kernel wrote the table in (GridView::maj_blocked, a property of the grid since round 5): known at compile time in the kernels built
     // for one layout -- a kernel is only launched on grids of its layout (vr_kernels.hip pathtrace_variant) -- read from the view otherwise (wave-uniform)
     const bool blocked = MAJB == 2 ? g.maj_blocked != 0 : MAJB == 1;
+    if (CLEAN && VR_MAJ_OUTSIDE_CELL) {
+        const uint32_t bx = (uint32_t)cvt_flr(ipos.x) >> sh, by = (uint32_t)cvt_flr(ipos.y) >> sh, bz = (uint32_t)cvt_flr(ipos.z) >> sh;
+        const uint32_t sz = (uint32_t)g.mshift[2] - (uint32_t)mip;
+        const bool inside = ((bx >> sx) | (by >> sy) | (bz >> sz)) == 0u;          // a negative coordinate leaves ones above the shifted-out bits
+        return inside ? (int32_t)(off + majorant_cell_index(bx, by, bz, sx, sy, (uint32_t)mip, blocked)) : g.maj_outside;
+    }
+    // (a level the grid does not have -- mip > n_mips -- needs no test: the table has all four levels and the cells of a missing one hold the "outside" value,
+    // vr_kernels.hip majorant_kernel; VR_MAJ_LEVEL_TEST=1 brings the compare back)
+    const bool inside = (VR_MAJ_LEVEL_TEST ? (mip <= g.n_mips) : true) & (ipos.x >= 0.0f) & (ipos.x < g.mlim[0]) & (ipos.y >= 0.0f) & (ipos.y < g.mlim[1]) & (ipos.z >= 0.0f) & (ipos.z < g.mlim[2]);
+    const uint32_t bx = (uint32_t)(int32_t)ipos.x >> sh, by = (uint32_t)(int32_t)ipos.y >> sh, bz = (uint32_t)(int32_t)ipos.z >> sh;
     return inside ? (int32_t)(off + majorant_cell_index(bx, by, bz, sx, sy, (uint32_t)mip, blocked)) : (VR_MAJ_OUTSIDE_CELL ? g.maj_outside : -1);
 }
 // Unconditional load (cell 0 when outside; the caller discards it then).  TF kernels read the float table (TF-remapped
@@ -322,13 +358,14 @@ VR_HD AxisCells axis_cells(int32_t i0, int32_t i1, uint32_t extent_voxels, uint3
     return a;
 }
 struct TriIO { TapAddr a[8]; TapData d[8]; float fx, fy, fz; uint32_t in_mask; };      // corners in [z][y][x] order
-template <int DENSE = 2>
+template <int DENSE = 2, bool GUARD = true>
 VR_HD void trilinear_prep(const GridView& g, v3 ipos, TriIO& io) {
     const float qx = ipos.x - 0.5f, qy = ipos.y - 0.5f, qz = ipos.z - 0.5f;
     const float flx = floor_(qx), fly = floor_(qy), flz = floor_(qz);
     io.fx = qx - flx; io.fy = qy - fly; io.fz = qz - flz;
-    const int32_t ix = nan_guard(voxel_index(flx, 0), flx, fly, flz), iy = voxel_index(fly, 0), iz = voxel_index(flz, 0);
-    const int32_t x1 = nan_guard(voxel_index(flx, 1), flx, fly, flz), y1 = voxel_index(fly, 1), z1 = voxel_index(flz, 1);
+    const int32_t ix0 = voxel_index(flx, 0), ix1 = voxel_index(flx, 1);
+    const int32_t ix = GUARD ? nan_guard(ix0, flx, fly, flz) : ix0, iy = voxel_index(fly, 0), iz = voxel_index(flz, 0);     // GUARD = false: a point of a clean segment, not NaN
+    const int32_t x1 = GUARD ? nan_guard(ix1, flx, fly, flz) : ix1, y1 = voxel_index(fly, 1), z1 = voxel_index(flz, 1);
     const bool dense = grid_is_dense<DENSE>(g);
     const uint32_t lg = dense ? 2u : 3u;
     const AxisCells X = axis_cells(ix, x1, dense ? (uint32_t)g.dim[0] : (uint32_t)g.nb[0] << 3, lg);
@@ -501,7 +538,8 @@ VR_HD void tricubic_fast_test(float k, float w, float s, bool& yes, bool& no) {
 
 // FAST: the guarded fast decision first, the reference's code only for a call with a draw inside a band (the device; the host harness can switch it on);
 // otherwise the reference's code always.  Both are compiled everywhere: tests/tools_tricubic_band.cpp runs one against the other.
-template <bool FAST>
+// GUARD = false: the coordinates are known not to be NaN (a tap on a clean segment): no NaN guard on the index
+template <bool FAST, bool GUARD = true>
 VR_HD void tricubic_tap_t(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) {
     int32_t jx = 0, jy = 0, jz = 0;
     float flx, fly, flz;
@@ -602,9 +640,11 @@ VR_HD void tricubic_tap_t(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int
         r = rng(seed); if (r < az.w4 / az.s4) jz = 3;
     }
 #endif
-    tx = nan_guard(voxel_index(flx, jx - 1), flx, fly, flz); ty = voxel_index(fly, jy - 1); tz = voxel_index(flz, jz - 1);
+    tx = voxel_index(flx, jx - 1); ty = voxel_index(fly, jy - 1); tz = voxel_index(flz, jz - 1);
+    if (GUARD) tx = nan_guard(tx, flx, fly, flz);
 }
-VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) { tricubic_tap_t<VR_TAP_FAST != 0>(ipos, seed, tx, ty, tz); }
+template <bool GUARD = true>
+VR_HD void tricubic_tap(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) { tricubic_tap_t<VR_TAP_FAST != 0, GUARD>(ipos, seed, tx, ty, tz); }
 
 // transfer function (common.glsl:203-212)
 // `lut`: tf_size x vec4 -- the SSBO in global memory, or the copy the path-tracing kernel stages in LDS (vr_pathtrace.h)
@@ -797,8 +837,16 @@ VR_HD bool intersect_box(v3 pos, v3 dir, const float* bmin, const float* bmax, f
 }
 
 // one DDA step on mip (common.glsl:404-409)
+#ifndef VR_DDA_INT_DIM
+#define VR_DDA_INT_DIM 1
+#endif
+template <bool CLEAN = false>
 VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
+#if VR_DDA_INT_DIM
+    const float dim = u2f((uint32_t)(130 + mip) << 23);        // 2^(3+mip) = (float)(8 << mip), from the exponent: shares the shift with idim (round 5: an add instead of shift + convert)
+#else
     const float dim = (float)(8 << mip);
+#endif
     const float idim = u2f((uint32_t)(124 - mip) << 23);       // 1 / dim exactly (dim = 2^(3+mip)): no division
     const float ox = ri.x >= 0.0f ? dim + 0.5f : -0.5f;
     const float oy = ri.y >= 0.0f ? dim + 0.5f : -0.5f;
@@ -806,6 +854,7 @@ VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
     const float tx = (floor_(p.x * idim) * dim + ox - p.x) * ri.x;
     const float ty = (floor_(p.y * idim) * dim + oy - p.y) * ri.y;
     const float tz = (floor_(p.z * idim) * dim + oz - p.z) * ri.z;
+    if (CLEAN) return __builtin_fminf(tx, __builtin_fminf(ty, tz));       // no NaN among them (clean segment): one v_min3_f32
     return min_(tx, min_(ty, tz));
 }
 
@@ -860,14 +909,15 @@ VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
     }
     h.ipos = mat4_point(P.u.vol_density_inv_transform, pos);
     h.idir = mat4_dir(P.u.vol_density_inv_transform, d);
-    h.far = tfar;
+    h.far = tfar;                                   // >= tnear >= 0: the sign is free (seg_clean)
     if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) {
         // global-majorant delta / ratio tracking (common.glsl:333-394; compiled out in the reference by USE_DDA):
         // t = near - log(1 - xi) * vol_inv_majorant, then straight to the first tentative collision
         h.ri = v3{ 0, 0, 0 };
         h.tau = 0.0f;
+        if (VR_CLEAN_FLAG) h.far = -tfar;            // these trackers' segments are never examined: not clean
         h.t = tnear + neg_log_1m(rng(h.seed)) * P.u.vol_inv_majorant;
-        if (h.t < h.far) { h.majorant = P.u.vol_majorant; h.state = ST_COLLIDE; }
+        if (h.t < tfar) { h.majorant = P.u.vol_majorant; h.state = ST_COLLIDE; }
         else h.state = segment_end_state(shadow);
         return true;
     }
@@ -875,6 +925,13 @@ VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
     h.t = tnear + 1e-6f;
     h.tau = neg_log_1m(rng(h.seed));
     h.state = ST_MARCH;
+#if VR_CLEAN_FLAG
+    {   // a finite ray of moderate size (see seg_clean): every comparison fails for NaN, and inf * 0 is NaN
+        const bool clean = (int)(abs_(h.ipos.x) < kCleanBound) & (int)(abs_(h.ipos.y) < kCleanBound) & (int)(abs_(h.ipos.z) < kCleanBound) &
+                           (int)(abs_(h.idir.x) * tfar < kCleanBound) & (int)(abs_(h.idir.y) * tfar < kCleanBound) & (int)(abs_(h.idir.z) * tfar < kCleanBound);
+        h.far = clean ? tfar : -tfar;
+    }
+#endif
     return true;
 }
 
@@ -926,20 +983,24 @@ constexpr int32_t kMarchSteps = VR_MARCH_STEPS;
 // the two-step form written out (the default; the generic loop below compiles ~1 % slower for the same arithmetic)
 struct MarchIO { float dt1, dt2, t1; uint32_t maj1, maj2; int32_t i1, i2; bool go1, go2; };     // i*: majorant cell or -1 (outside: majorant 0); maj*: as loaded (majorant_fetch)
 VR_HD void march_idle(MarchIO& io) { io.i1 = io.i2 = VR_MAJ_OUTSIDE_CELL ? 0 : -1; io.dt1 = io.dt2 = io.t1 = 0.0f; io.go1 = io.go2 = false; }      // a lane that is not marching (its loads: cell 0)
-template <int DENSE = 2, int MAJB = 2>
+// CLEAN: every path the call runs for is on a clean segment (seg_clean).  The second step is prepared also when the first one leaves [near, far) (go2 false: its
+// results are discarded); its point may then lie beyond the bound, which the clean forms tolerate -- an index is only formed for cells inside the table, and a
+// discarded step's NaN is discarded with it
+template <int DENSE = 2, int MAJB = 2, bool CLEAN = false>
 VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
-    io.go1 = h.t < h.far;
+    const float far = seg_far(h);
+    io.go1 = h.t < far;
     const v3 c1 = axpy(h.ipos, h.t, h.idir);
     const int32_t m1 = round_mip_q(h.mipq);
-    io.i1 = majorant_index<DENSE, MAJB>(P.density, c1, m1);
-    io.dt1 = step_dda(c1, h.ri, m1);
+    io.i1 = majorant_index<DENSE, MAJB, CLEAN>(P.density, c1, m1);
+    io.dt1 = step_dda<CLEAN>(c1, h.ri, m1);
     io.t1 = h.t + io.dt1;
     const int32_t q2 = h.mipq < 12 ? h.mipq + 1 : 12;              // mip = min(mip + 0.25, 3)
     const int32_t m2 = round_mip_q(q2);
-    io.go2 = io.t1 < h.far;
+    io.go2 = io.t1 < far;
     const v3 c2 = axpy(h.ipos, io.t1, h.idir);
-    io.i2 = majorant_index<DENSE, MAJB>(P.density, c2, m2);
-    io.dt2 = step_dda(c2, h.ri, m2);
+    io.i2 = majorant_index<DENSE, MAJB, CLEAN>(P.density, c2, m2);
+    io.dt2 = step_dda<CLEAN>(c2, h.ri, m2);
 }
 // the loads: unconditional and for every lane of the wavefront (an idle lane reads cell 0), so that they sit in straight-line
 // code and the compiler's wait counts are exact
@@ -994,7 +1055,7 @@ VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     }
     t += tau / maj;
     h.t = t; h.tau = tau; h.mipq = q;
-    if (t >= h.far) { h.state = segment_end_state(h.shadow); return; }
+    if (t >= seg_far(h)) { h.state = segment_end_state(h.shadow); return; }
     h.majorant = maj;
     h.state = ST_COLLIDE;
 }
@@ -1009,17 +1070,17 @@ VR_HD void march_idle(MarchIO& io) {             // a lane that is not marching
 #pragma unroll
     for (int k = 0; k < kMarchSteps; ++k) { io.idx[k] = VR_MAJ_OUTSIDE_CELL ? 0 : -1; io.dt[k] = io.t[k] = 0.0f; io.go[k] = false; }
 }
-template <int DENSE = 2, int MAJB = 2>
+template <int DENSE = 2, int MAJB = 2, bool CLEAN = false>
 VR_HD void march_prep(const Hot& h, const SceneParams& P, MarchIO& io) {
     float t = h.t;
     int32_t q = h.mipq;
 #pragma unroll
     for (int k = 0; k < kMarchSteps; ++k) {
-        io.go[k] = t < h.far;
+        io.go[k] = t < seg_far(h);
         const v3 c = axpy(h.ipos, t, h.idir);
         const int32_t m = round_mip_q(q);
-        io.idx[k] = majorant_index<DENSE, MAJB>(P.density, c, m);
-        io.dt[k] = step_dda(c, h.ri, m);
+        io.idx[k] = majorant_index<DENSE, MAJB, CLEAN>(P.density, c, m);
+        io.dt[k] = step_dda<CLEAN>(c, h.ri, m);
         t = t + io.dt[k];
         io.t[k] = t;
         q = q < 12 ? q + 1 : 12;                                   // mip = min(mip + 0.25, 3)
@@ -1055,7 +1116,7 @@ VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
 tentative_collision:
     t += tau / maj;
     h.t = t; h.tau = tau; h.mipq = q;
-    if (t >= h.far) { h.state = segment_end_state(h.shadow); return; }
+    if (t >= seg_far(h)) { h.state = segment_end_state(h.shadow); return; }
     h.majorant = maj;
     h.state = ST_COLLIDE;
 }
@@ -1063,7 +1124,7 @@ tentative_collision:
 // one iteration (sequential form; the scheduler uses the two-phase form above)
 template <bool TF, int DENSE = 2, int MAJB = 2>
 VR_HD void do_march(Hot& h, const SceneParams& P) {
-    if (!(h.t < h.far)) { h.state = segment_end_state(h.shadow); return; }
+    if (!(h.t < seg_far(h))) { h.state = segment_end_state(h.shadow); return; }
     const v3 curr = axpy(h.ipos, h.t, h.idir);
     const int32_t m = round_mip_q(h.mipq);
     const float majorant = majorant_at<TF, DENSE, MAJB>(P, curr, m);
@@ -1073,7 +1134,7 @@ VR_HD void do_march(Hot& h, const SceneParams& P) {
     h.mipq = h.mipq < 12 ? h.mipq + 1 : 12;                 // mip = min(mip + 0.25, 3)
     if (h.tau > 0.0f) return;
     h.t += h.tau / majorant;
-    if (h.t >= h.far) { h.state = segment_end_state(h.shadow); return; }
+    if (h.t >= seg_far(h)) { h.state = segment_end_state(h.shadow); return; }
     h.majorant = majorant;
     h.state = ST_COLLIDE;
 }
@@ -1090,14 +1151,16 @@ template <class K> struct CollideIO {
 // PE: where the emission grid's view and transform are read from.  The scheduler passes the kernel arguments behind a pointer there
 // (event_args(), vr_pathtrace.h): ~45 uniform dwords that only the emission tap needs are then fetched by scalar loads inside the collision
 // code instead of living in scalar registers through the whole scheduler loop (the emission kernels were the ones spilling them).
-template <class K>
+// CLEAN: the path stands on a clean segment (seg_clean) -- its collision point, t < far, is finite: the density tap needs no NaN guard (the emission tap keeps
+// it: its point goes through one more transform)
+template <class K, bool CLEAN = false>
 VR_HD void collide_prep(Hot& h, const SceneParams& P, const SceneParams& PE, CollideIO<K>& io) {
     const v3 ip = axpy(h.ipos, h.t, h.idir);
     if (K::tf) {
-        trilinear_prep<K::dense>(P.density, ip, io.tri);
+        trilinear_prep<K::dense, !CLEAN>(P.density, ip, io.tri);
     } else {
         int32_t tx, ty, tz;
-        tricubic_tap(ip, h.seed, tx, ty, tz);
+        tricubic_tap<!CLEAN>(ip, h.seed, tx, ty, tz);
         io.a = tap_addr<K::dense>(P.density, tx, ty, tz);
     }
     io.ea.cell = io.ea.off = 0u; io.ea.in = false;
@@ -1119,8 +1182,8 @@ VR_HD void collide_idle(CollideIO<K>& io) {      // a lane that is not colliding
     io.ea.cell = io.ea.off = 0u; io.ea.in = false;
     if (K::tf) trilinear_idle(io.tri);
 }
-template <class K>
-VR_HD void collide_prep(Hot& h, const SceneParams& P, CollideIO<K>& io) { collide_prep<K>(h, P, P, io); }
+template <class K, bool CLEAN = false>
+VR_HD void collide_prep(Hot& h, const SceneParams& P, CollideIO<K>& io) { collide_prep<K, CLEAN>(h, P, P, io); }
 template <class K>
 VR_HD void collide_load(const SceneParams& P, const SceneParams& PE, CollideIO<K>& io) {      // unconditional, like march_load
     if (K::tf) trilinear_load<K::dense, K::pair_d>(P.density, io.tri);
@@ -1183,7 +1246,7 @@ VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const ScenePara
     if (global) {
         // stays in ST_COLLIDE while the ray is inside the box
         h.t = h.t + neg_log_1m(rng(h.seed)) * u.vol_inv_majorant;
-        if (!(h.t < h.far)) h.state = segment_end_state(h.shadow);
+        if (!(h.t < seg_far(h))) h.state = segment_end_state(h.shadow);
         return;
     }
     h.tau = neg_log_1m(rng(h.seed));
@@ -1192,10 +1255,10 @@ VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const ScenePara
 }
 template <class K, class Cold, bool CACHED = false>
 VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const CollideIO<K>& io, const float* tf_lut) { collide_finish<K, Cold, CACHED>(h, c, P, P, io, tf_lut); }
-template <class K, class Cold>
+template <class K, class Cold, bool CLEAN = false>
 VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
     CollideIO<K> io;
-    collide_prep<K>(h, P, io);
+    collide_prep<K, CLEAN>(h, P, io);
     collide_load<K>(P, io);
     collide_finish<K>(h, c, P, io, P.tf_lut);
 }
@@ -1471,8 +1534,9 @@ VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, 
         do_new<K>(h, c, P, wu, next_item++);
         if (h.first) { stash.dir = h.ipos; stash.item = f2u(h.Tr); first_resume(h, P); }      // = HotStore::save_new + load_resume
         break;
-    case ST_MARCH: { MarchIO io; march_prep<K::dense, K::majb>(h, P, io); march_load<K::tf>(P, io); march_finish<K::tf>(h, P, io); break; }     // two DDA steps, as on the device
-    case ST_COLLIDE: do_collide<K>(h, c, P); break;
+    // two DDA steps, as on the device; a path on a clean segment in the forms the device runs for a wavefront of such paths
+    case ST_MARCH: { MarchIO io; if (seg_clean(h)) march_prep<K::dense, K::majb, true>(h, P, io); else march_prep<K::dense, K::majb, false>(h, P, io); march_load<K::tf>(P, io); march_finish<K::tf>(h, P, io); break; }
+    case ST_COLLIDE: if (seg_clean(h)) do_collide<K, Cold, true>(h, c, P); else do_collide<K, Cold, false>(h, c, P); break;
     case ST_NEE: do_nee<K>(h, c, c, P); break;
     case ST_POSTNEE: do_postnee<K>(h, c, P, wu); break;
     case ST_ESCAPE: do_escape(h, c, P, wu); break;
