@@ -138,8 +138,10 @@ static void check_grid_bytes(size_t bytes, const char* what, const int32_t nb[3]
 // padded power-of-two extent of the majorant levels (vr_scene.h); brick records and atlas blocks have exact pitches
 static void set_layout(BrickGridHIP& out) {
     for (int i = 0; i < 3; ++i) out.mshift[i] = std::max(3, ceil_log2((uint32_t)out.nb[i]));
-    if (out.mshift[0] + out.mshift[1] + out.mshift[2] > 30 || (uint64_t)out.nb[0] * out.nb[1] * out.nb[2] > (1ull << 30))
-        throw std::runtime_error("grid upload: more than 2^30 bricks");
+    // (4e8 bricks: a tap addresses its cache line of the atlas by a 32-bit line index, 5 lines per brick -- 10 in a paired atlas --: vr_trace.h tap_load; such a
+    // grid's atlas alone is 256 GB)
+    if (out.mshift[0] + out.mshift[1] + out.mshift[2] > 30 || (uint64_t)out.nb[0] * out.nb[1] * out.nb[2] > 400000000ull)
+        throw std::runtime_error("grid upload: more than 4e8 bricks");
     if ((uint64_t)out.nb[1] * out.nb[2] >= (1ull << 24) || out.nb[0] >= (1 << 24))
         throw std::runtime_error("grid upload: brick counts beyond the 24-bit index arithmetic of the kernels (n_bricks.y * n_bricks.z < 2^24)");
     const size_t cells = majorant_table_cells((uint32_t)(out.mshift[0] + out.mshift[1] + out.mshift[2]));

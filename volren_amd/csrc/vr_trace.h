@@ -195,13 +195,20 @@ VR_HD TapAddr tap_addr(const GridView& g, int32_t x, int32_t y, int32_t z) {
     if (!a.in) { a.cell = 0u; a.off = 0u; }       // the loads are unconditional: an outside tap reads cell 0 and is discarded
     return a;
 }
+#ifndef VR_TAP_LINE_INDEX
+#define VR_TAP_LINE_INDEX 1
+#endif
 template <int DENSE = 2, int PAIR = 0>
 VR_HD TapData tap_load(const GridView& g, TapAddr a) {
     TapData d;
     if (PAIR != 0) {
         // paired atlas: ten lines of [rmin_d, rdiff_d, rmin_e, rdiff_e | 56 x (density, emission)] per brick
         const uint32_t line = pair_voxel_line(a.off);
+#if VR_TAP_LINE_INDEX
+        const uint8_t* ln = g.atlas + ((size_t)(a.cell * (kPairBlockBytes / 128u) + line) << 7);      // see the brick atlas below
+#else
         const uint8_t* ln = g.atlas + ((size_t)a.cell * kPairBlockBytes + (size_t)(line * 128u));
+#endif
         const float* rec = reinterpret_cast<const float*>(ln) + (PAIR == 2 ? 2 : 0);
 #if defined(VR_TAP_NT) && defined(__HIP_DEVICE_COMPILE__)
         // build-time experiment (round 5): the paired atlas of a large grid streams through the L2 (450 MB touched on c5cloud); non-temporal taps would leave the L2
@@ -221,7 +228,13 @@ VR_HD TapData tap_load(const GridView& g, TapAddr a) {
 #if VR_BRICK_HEADERS
         // the voxel's line of the brick's block: [rmin, rdiff | 120 voxels] -- range and voxel come from one cache line
         const uint32_t line = brick_voxel_line(a.off);
+#if VR_TAP_LINE_INDEX
+        // the line's index in the atlas as ONE 32-bit number (cell * 5 + line: fewer than 2^32 lines = 512 GiB, checked at upload), shifted into the 64-bit
+        // address once -- instead of a 64-bit product, two 64-bit selects and two 64-bit additions (round 5; fewer instructions, no measurable gain: profiles/r5p_*)
+        const uint8_t* ln = g.atlas + ((size_t)(a.cell * (kBrickBlockBytes / 128u) + line) << 7);
+#else
         const uint8_t* ln = g.atlas + ((size_t)a.cell * kBrickBlockBytes + (size_t)(line * 128u));
+#endif
         const float* rec = reinterpret_cast<const float*>(ln);
         d.rmin = rec[0]; d.rdiff = rec[1];
         d.raw = ln[kBrickLineHeader + a.off - line * kBrickLineVoxels];
