@@ -30,8 +30,9 @@ ROOT = T.ROOT
 COST = {"simple": 1.75, "fma": 1.85, "vop3": 2.75, "cvt": 2.65, "cmp": 3.2, "cnd_vcc": 1.7, "cnd_sgpr": 2.8, "trans": 5.2, "div": 3.3, "lane": 3.0, "minmax": 2.55, "lshl": 2.65,
         "mul24": 2.6, "u64": 2.86, "pk": 2.86, "sgpr_src": 0.9}
 TOP = {   # innermost function / section -> top-level block (None: inherit from the block before)
-    "march": ("march_prep", "step_dda", "majorant_index", "march_finish", "majorant_fetch", "majorant_value", "march_load", "march_idle", "majorant_cell_index", "majorant_level_offset", "round_mip_q"),
-    "collide": ("tricubic_tap", "tricubic_axis_fast", "tricubic_fast_test", "tricubic_axis_weights", "tap_addr", "tap_load", "tap_value", "collide_prep", "collide_finish", "collide_load",
+    "march": ("march_prep", "step_dda", "majorant_index", "march_finish", "majorant_fetch", "majorant_value", "march_load", "march_idle", "majorant_cell_index", "majorant_level_offset", "round_mip_q",
+              "cvt_flr", "seg_far", "majorant_of"),
+    "collide": ("tricubic_tap", "tricubic_tap_t", "tricubic_axis_fast", "tricubic_fast_test", "tricubic_axis_weights", "tap_addr", "tap_load", "tap_value", "collide_prep", "collide_finish", "collide_load",
                 "collide_idle", "nan_guard", "rng_skip9", "trilinear_prep", "trilinear_load", "trilinear_value", "axis_cells", "tf_lookup_at", "brick_voxel_line", "pair_voxel_line", "voxel_index"),
     "new": ("do_new", "tea32", "make_unit"),
     "nee": ("do_nee", "sample_environment", "env_warp_level", "shle_park"),
@@ -89,7 +90,7 @@ def parse_blocks(path, want):
 
     def new_block(label):
         nonlocal cur
-        cur = dict(label=label, n=0, valu=0, cyc=0.0, classes=collections.Counter(), funcs=collections.Counter(), secs=collections.Counter(), branch=None, salu=0, vmem=0, lds=0, smem=0, nops=0, waits=0)
+        cur = dict(label=label, n=0, valu=0, cyc=0.0, classes=collections.Counter(), funcs=collections.Counter(), secs=collections.Counter(), branch=None, salu=0, vmem=0, lds=0, smem=0, nops=0, waits=0, clean_marks=0)
         blocks.append(cur)
     new_block("entry")
     cfile, cline = None, 0
@@ -109,6 +110,8 @@ def parse_blocks(path, want):
         if cur["branch"] is not None:
             new_block(cur["label"] + "+")             # the instruction after a branch starts a block of its own
         cur["n"] += 1
+        if op.startswith("v_cvt_flr_i32_f32"):
+            cur["clean_marks"] += 1                   # only the CLEAN form of the march (vr_trace.h seg_clean) converts with floor
         r = T.region_of(cfile, cline, tr, pt)
         if r:
             if r.startswith("trace:") or r.startswith("helper:"):
@@ -179,6 +182,28 @@ def assign(blocks, tf_kernel=False):
             # to 256 entries (the bench's): a copy that reads LDS counts, one that reads global memory does not, the rest (no load in the block) half
             mult = 1.0 if b["lds"] > 0 else (0.0 if b["vmem"] > 0 else 0.5)
         b["mult"] = mult
+    # Round 5 (clean segments): the hot pair is compiled in two forms -- VR_HOT_PAIRS copies of the CLEAN form, which is what runs, and one copy of the general form for
+    # wavefronts that hold a path on a segment that is not clean (degenerate rays: never in the bench scenes).  A copy = a run of march blocks followed by its collide
+    # blocks; a copy with the floor conversion of the clean march is a clean one.  When there are clean copies the general copy counts as never executed.
+    copies, cur_copy, last = [], None, None
+    for b in blocks:
+        if b["top"] in ("march", "collide"):
+            starts_march = b["top"] == "march" and (b["funcs"].get("step_dda", 0) + b["funcs"].get("majorant_index", 0) + b["funcs"].get("march_prep", 0)) >= 8
+            if cur_copy is None or (starts_march and any(x["top"] == "collide" for x in cur_copy)):      # (a few instructions of march_finish's inlined helpers also sit inside the collision code)
+                cur_copy = []
+                copies.append(cur_copy)
+            cur_copy.append(b)
+            last = b["top"]
+        else:
+            if b["top"] not in ("glue",) and b["n"] > 0 and b["top"] in ("park", "decision", "resume", "escape", "postnee", "new", "nee", "tail"):
+                cur_copy, last = None, None
+    n_clean = sum(1 for c in copies if any(x["clean_marks"] for x in c))
+    if n_clean:
+        for c in copies:
+            if not any(x["clean_marks"] for x in c):
+                for x in c:
+                    x["mult"] = 0.0
+    blocks[0]["hot_copies"] = n_clean if n_clean else len(copies)
     return blocks
 
 
@@ -199,7 +224,7 @@ def main():
         iters_per_sample = 15.7 / 64.0
     # the hot pair is compiled VR_HOT_PAIRS times (straight-line copies, vr_pathtrace.h); the STATS counters count every copy's executions, so a copy's cost
     # is the static total / copies
-    copies = float(arg("--hot-pairs", "1"))
+    copies = float(blocks[0].get("hot_copies") or arg("--hot-pairs", "1"))       # counted from the text (assign); --hot-pairs only for a text without any
     tot = collections.defaultdict(lambda: collections.Counter())
     for b in blocks:
         w = b["mult"] / (copies if b["top"] in ("march", "collide") else 1.0)
