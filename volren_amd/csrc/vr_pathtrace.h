@@ -414,7 +414,18 @@ __device__ __forceinline__ const KernelArgs& event_args() {
 template <class K, bool STATS>
 __global__ void __launch_bounds__(64 * kWgWaves, waves_per_simd<K>())
 pathtrace_kernel(const KernelArgs A) {
+#ifndef VR_PIN_TAP_POINTERS
+#define VR_PIN_TAP_POINTERS 0
+#endif
+#if VR_PIN_TAP_POINTERS
+    // experiment (round 5): the density grid's tap pointer as an opaque scalar value -- the register allocator treats a kernel-argument load as free to repeat and
+    // re-loaded it in the collision code of every pass (s_load + wait in front of the tap)
+    SceneParams Ppin = A.P;
+    asm volatile("" : "+s"(Ppin.density.atlas), "+s"(Ppin.density.dense));
+    const SceneParams& P = Ppin;
+#else
     const SceneParams& P = A.P;           // hot pair only; events use event_args()
+#endif
     const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     constexpr int32_t NS = pool_slots<K>();           // path slots of this kernel's wavefronts (shadows the global maximum below)
 
