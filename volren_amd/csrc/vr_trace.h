@@ -264,8 +264,8 @@ VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
     const TapAddr a = tap_addr<DENSE>(g, x, y, z);
     return tap_value<DENSE>(g, tap_load<DENSE>(g, a), a.in);
 }
-// index of the majorant cell floor(ipos) >> (3 + mip) in the padded table, or -1 outside the grid (or NaN): reads 0 there.
-// The padded layout (vr_scene.h) holds 0 in every cell beyond the real extent of a level, so only the padded extent -- the
+// index of the majorant cell floor(ipos) >> (3 + mip) in the padded table, or -- outside the padded box, or NaN -- of the table's "outside" cell.
+// The padded layout (vr_scene.h) holds the outside value in every cell beyond the real extent of a level, so only the padded extent -- the
 // same for all levels -- is tested, on the floats (floor(x) in [0, n) <=> x in [0, n) for integer n; NaN fails), after
 // which truncation equals floor.
 // VR_MAJ_OUTSIDE_CELL (round 5, default): "outside" is the index of the table's last cell, which holds what the reference computes there (vr_scene.h
@@ -328,7 +328,7 @@ template <bool TF>
 VR_HD uint32_t majorant_fetch(const GridView& g, int32_t idx) {
     const int32_t i = VR_MAJ_OUTSIDE_CELL ? idx : (idx < 0 ? 0 : idx);
 #if VR_MAJ_OUTSIDE_CELL && defined(__clang__)
-    __builtin_assume(i >= 0 && i <= (1 << 30));      // a table index (set_layout: at most 2^30 cells): the address is base + a 32-bit byte offset, no 64-bit arithmetic
+    __builtin_assume(i >= 0);                        // a table index (at most 73/64 x 2^30 cells, vr_scene.h): zero- instead of sign-extended into the 64-bit address
 #endif
     return TF ? f2u(g.majorant[i]) : (uint32_t)g.majorant16[i];
 }
