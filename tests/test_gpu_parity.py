@@ -1771,3 +1771,62 @@ def test_random_parameter_sets_match_oracle():
             setattr(r, k, v)
         r.render(spp)
         _assert_same(r.framebuffer(), o.render(spp), "random set %d: %s %dx%d %d spp %s" % (i, base, w, h, spp, fields))
+
+
+@pytest.mark.gpu
+def test_nan_ray_parameter_on_a_clean_segment():
+    """A free-flight draw of exactly 0 (one in 2^24 segments) that meets an empty first cell makes the reference's step back to the collision point 0 / 0: the ray
+    parameter is NaN from there on, the collision at "NaN" is still evaluated (every fetch outside the grid, a null collision, its draws consumed) and the segment ends.
+    The kernels' CLEAN form of the collision code (vr_trace.h seg_clean: no NaN guard on the density tap) relies on such a tap landing on index -1 by itself (NaN
+    converts to voxel 0, every filter test compares false, 0 + 0 - 1) -- this grid's only dense brick sits at voxel 0, where a tap that did not would scatter.
+    2^26 camera segments through mostly empty space: four such draws expected; the frame must equal the oracle's bit for bit."""
+    import encoder_ref
+    vox = np.zeros((64, 64, 64), np.float16)
+    vox[0:8, 0:8, 0:8] = np.float16(5.0)
+    w = h = 1024
+    spp = 64
+    o = scenes.oracle_scene("c1", w, h)
+    o.set_volume(encoder_ref.encode_dense_fp16(vox))
+    r = scenes.hip_scene("c1", w, h)
+    r.set_volume_dense_f16(vox)
+    for x in (o, r):
+        x.bounces = 3
+        x.density_scale = 50.0
+    want = o.render(spp)
+    r.render(spp)
+    _assert_same(r.framebuffer(), want, "NaN ray parameter on a clean segment")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["c2", "c5:64"])
+def test_environment_whose_warp_table_fails_the_division_check(scene):
+    """The kernels compiled for one scene kind take the environment warp's quotients -- and the march's step back -- by vr_math.h div_core, the IEEE sequence
+    without its rescaling guards, which is only the same thing for operands of moderate size.  An environment with thresholds below 2^-76 (a texel 1e-30 beside
+    texels of 1: env_cdf_kernel's check fails) and a density scale outside [2^-16, 2^24] are therefore rendered by the run-time variant, which divides in full --
+    from the grids' own atlases when the scene has an emission grid.  Either way the frame is the oracle's, bit for bit."""
+    rs = np.random.RandomState(3)
+    env = rs.uniform(0.2, 1.0, (8, 16, 3)).astype(np.float32)
+    o = scenes.oracle_scene(scene, 56, 40)
+    r = scenes.hip_scene(scene, 56, 40)
+    assert r.env_div_safe == 1                                  # the bench's HDR
+    o.set_envmap(env)
+    r.set_envmap(env)
+    assert r.env_div_safe == 1
+    r.render(4)
+    _assert_same(r.framebuffer(), o.render(4).copy(), "random environment")
+    env[2:5, 4:7] = 1e-30                                      # a flat dark patch: where it meets the bilinear ramp to its neighbours the fine levels' thresholds are ~1e-28
+    env[4, 11] = 0.0                                           # (an exactly black texel is no problem: 0 and NaN thresholds are NaN / 0 either way)
+    for x in (o, r):
+        x.set_envmap(env)
+        x.reset()
+    assert r.env_div_safe == 0
+    r.render(4)
+    _assert_same(r.framebuffer(), o.render(4).copy(), "environment with thresholds below 2^-76")
+    env = rs.uniform(0.2, 1.0, (8, 16, 3)).astype(np.float32)
+    for x in (o, r):
+        x.set_envmap(env)
+        x.density_scale = 1e-6                                 # outside [2^-16, 2^24]
+        x.reset()
+    assert r.env_div_safe == 1
+    r.render(4)
+    _assert_same(r.framebuffer(), o.render(4).copy(), "density scale 1e-6")

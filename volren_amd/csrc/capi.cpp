@@ -318,6 +318,7 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "majorant_blocked") {          // what the current frame's next launch will use
             vr::SceneParams P; R.fill_params(P); *v = P.density.maj_blocked;
         }
+        else if (n == "env_div_safe") *v = R.environment && R.environment->cdf_div_safe ? 1 : 0;      // the environment's warp table passed env_cdf_kernel's check (vr_math.h div_core)
         else if (n == "pending_samples") *v = R.pending_samples();
         else if (n == "tf_float_atlas") *v = R.tf_float_atlas ? 1 : 0;
         else if (n == "gpu_encoder") *v = R.gpu_encoder ? 1 : 0;

@@ -48,9 +48,13 @@ void Environment::build(const float* rgb, int w, int h) {
     launch_build_impmap(envmap->as<float>(), w, h, (int)DIMENSION, impmap->as<float>(), nullptr);
     VR_HIP(hipGetLastError());
     cdf = make_device_buffer(env_cdf_table_floats((int32_t)num_mip_levels() - 2) * sizeof(float));      // levels 0 .. base mip - 1
-    launch_build_env_cdf(impmap->as<float>(), (int)DIMENSION, cdf->as<float>(), nullptr);
+    DeviceBufferPtr unsafe = make_device_buffer(sizeof(uint32_t));
+    launch_build_env_cdf(impmap->as<float>(), (int)DIMENSION, cdf->as<float>(), unsafe->as<uint32_t>(), nullptr);
     VR_HIP(hipGetLastError());
     VR_HIP(hipStreamSynchronize(nullptr));
+    uint32_t flag = 1u;
+    unsafe->download(&flag, sizeof flag);
+    cdf_div_safe = flag == 0u;
 }
 
 uint32_t Environment::num_mip_levels() const { return 1 + (uint32_t)std::floor(std::log2((float)DIMENSION)); }

@@ -28,6 +28,7 @@ public:
     DeviceBufferPtr impmap;      // R32F pyramid: 512^2, 256^2, ..., 1
     DeviceBufferPtr cdf;         // per-2x2-block warp thresholds derived from the pyramid (see vr_trace.h sample_environment)
     int width = 0, height = 0;
+    bool cdf_div_safe = false;   // every threshold of `cdf` is NaN, 0 or in [2^-76, 1]: the kernels' warp may use the division without its guard instructions (vr_math.h div_core)
 
     std::vector<float> download_impmap() const;
 

@@ -389,7 +389,9 @@ void RendererHIP::fill_params(SceneParams& P) {
         const mat4 efd = eti * dt;
         memcpy(P.emission_from_density, efd.m, sizeof efd.m);
         // the kernel compiled for two brick grids (DDA trackers) reads them from their paired atlas; every other kernel reads each grid's own
-        P.paired = (integrator == 0 && density.atlas_paired && density.atlas_paired == emission.atlas_paired) ? 1 : 0;
+        // (an environment that fails the warp table's check is rendered by the run-time variant, from the grids' own atlases: vr_kernels.hip pathtrace_variant)
+        const bool scale_ok = u.vol_density_scale >= 1.0f / 65536.0f && u.vol_density_scale <= 16777216.0f;      // (the same goes for a density scale the fixed kernels' march does not divide by)
+        P.paired = (integrator == 0 && environment->cdf_div_safe && scale_ok && density.atlas_paired && density.atlas_paired == emission.atlas_paired) ? 1 : 0;
         // ... and is the one kernel compiled for both layouts of the majorant table's fine levels: blocked for the grids commit() marked (or as majorant_layout says)
         if (P.paired) P.density = make_view(density, true, majorant_layout < 0 ? density.maj_blocked : majorant_layout == 1);
         P.emission = make_view(emission, P.paired != 0);
@@ -415,6 +417,7 @@ void RendererHIP::fill_params(SceneParams& P) {
     P.impmap = environment->impmap->as<float>();
     P.imp_dim = (int)environment->dimension();
     P.env_cdf = environment->cdf->as<float>();
+    P.env_div_safe = environment->cdf_div_safe ? 1 : 0;
     u.resolution[0] = resolution.x; u.resolution[1] = resolution.y;
     u.integrator = integrator;
 }

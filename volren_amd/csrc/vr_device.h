@@ -36,7 +36,7 @@ void launch_pathtrace(const PathtraceTuning& T, const SceneParams& P, float* fb,
 void launch_build_impmap(const float* envmap_rgba, int32_t env_w, int32_t env_h, int32_t dim, float* pyramid, hipStream_t stream);
 
 // warp table of sample_environment: float4 per 2x2 block of every pyramid level (coarsest first); (dim^2 - 1) / 3 records
-void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipStream_t stream);
+void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, uint32_t* unsafe_flag, hipStream_t stream);
 
 // effective majorant of every cell of every range mip:
 //   m = density_scale * float(range.y);  with a LUT: m = vol_majorant * tf_lookup(m * vol_inv_majorant).a

@@ -127,7 +127,11 @@ static const PtLaunch kPtLaunch[2][kPtVariants] = { { vr_pt_launch_0, vr_pt_laun
 
 // which compiled variant serves a scene (see vr_pathtrace.hip)
 static int pathtrace_variant(const SceneParams& P) {
-    if (P.u.integrator != 0) return 3;
+    // (an environment whose warp table failed the check of env_cdf_kernel -- thresholds below 2^-76: the kernels of one scene kind divide by vr_math.h div_core there --
+    // goes to the run-time variant, which divides in full; RendererHIP::fill_params pairs no atlases for it)
+    // -- and so does a density scale outside [2^-16, 2^24]: the CLEAN form of the march divides by majorants = density_scale x an fp16 number (vr_trace.h march_finish)
+    const bool scale_ok = P.u.vol_density_scale >= 1.0f / 65536.0f && P.u.vol_density_scale <= 16777216.0f;
+    if (P.u.integrator != 0 || !P.env_div_safe || !scale_ok) return 3;
     // variant 2: both grids in brick form -- and, when the kernels are built for the paired atlas, sharing one (same brick layout: RendererHIP::commit)
     // (4 = 2 compiled for majorant levels 0-1 in 4x4x4-cell blocks; every other kernel of a fixed layout reads linear tables: RendererHIP::fill_params only
     // sets maj_blocked on the views of frames this variant -- or the run-time variant -- serves)
@@ -233,7 +237,7 @@ impmap_mip_kernel(const float* __restrict__ src, int32_t d, float* __restrict__ 
 // warp table of sample_environment (see vr_trace.h; layout: vr_scene.h env_cdf_index): one thread per 2x2 block of pyramid
 // level `mip` = one record of table level k = top - mip
 __global__ void __launch_bounds__(256)
-env_cdf_kernel(const float* __restrict__ level, int32_t d, int32_t top, int32_t k, float* __restrict__ table) {
+env_cdf_kernel(const float* __restrict__ level, int32_t d, int32_t top, int32_t k, float* __restrict__ table, uint32_t* __restrict__ unsafe) {
     const int32_t hd = d >> 1;
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= hd * hd) return;
@@ -243,16 +247,21 @@ env_cdf_kernel(const float* __restrict__ level, int32_t d, int32_t top, int32_t 
     const float q0 = w0 + w2, q1 = w1 + w3;
     float* o = table + env_cdf_index(top, k, (uint32_t)x, (uint32_t)y);
     o[0] = q0 / max_(1e-8f, q0 + q1); o[1] = w0 / q0; o[2] = w1 / q1;
+    // may sample_environment's quotients use div_core (vr_math.h)?  Every threshold NaN (0 / 0 of an empty block: NaN either way), 0, or in [2^-76, 1]
+    bool ok = true;
+    for (int j = 0; j < 3; ++j) { const float v = o[j]; ok = ok && (v != v || v == 0.0f || (v >= 1.3234890e-23f && v <= 1.0f)); }
+    if (!ok) atomicOr(unsafe, 1u);
     if (k == top) { o[3] = w0; o[4] = w1; o[5] = w2; o[6] = w3; }      // finest level: the texels themselves (pdf of the sampled direction)
 }
-void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, hipStream_t stream) {
+void launch_build_env_cdf(const float* pyramid, int32_t dim, float* table, uint32_t* unsafe_flag, hipStream_t stream) {
     // levels base-1 .. 0; level m lives at pyramid offset imp_level_offset(dim, m) and has (dim >> m)^2 texels
     int32_t base = 0;
     while ((1 << base) < dim) ++base;
     (void)hipMemsetAsync(table, 0, env_cdf_table_floats(base - 1) * sizeof(float), stream);      // padding words and unused child records
+    (void)hipMemsetAsync(unsafe_flag, 0, sizeof(uint32_t), stream);
     for (int32_t mip = base - 1; mip >= 0; --mip) {
         const int32_t d = dim >> mip, n = (d >> 1) * (d >> 1);
-        hipLaunchKernelGGL(env_cdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pyramid + imp_level_offset(dim, mip), d, base - 1, base - 1 - mip, table);
+        hipLaunchKernelGGL(env_cdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pyramid + imp_level_offset(dim, mip), d, base - 1, base - 1 - mip, table, unsafe_flag);
     }
 }
 

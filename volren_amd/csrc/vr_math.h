@@ -77,6 +77,34 @@ VR_HD float rcp_exact(float x) {
     return 1.0f / x;
 #endif
 }
+// The IEEE division sequence the compiler emits for n / d, WITHOUT its three guard instructions (v_div_scale_f32 x 2, v_div_fixup_f32; v_div_fmas_f32 becomes an fma):
+// the same eight operations on the same values whenever no operand needs rescaling and no special case applies (round 5; 19 instead of 30 issue cycles per
+// quotient, c2 +1.6 %, c4 +1.4 %: profiles/r5x_*).  Used only where the call site has established div_core_domain for its operands -- or operands for which both forms
+// give NaN (0 / 0, a NaN operand) and only the NaN-ness matters downstream.  VR_DIV_CORE=0: n / d everywhere.
+#ifndef VR_DIV_CORE
+#define VR_DIV_CORE 1
+#endif
+// The operands div_core is used on (each call site establishes this before it runs; tests/tools_div_core.hip checks the identity over the whole set on the hardware):
+// the denominator normal with 2^-100 <= |d| <= 2^100, the numerator +0 or 2^-100 <= |n| <= 2^100, the quotient's magnitude in [2^-100, 2^100] -- far inside the
+// conditions under which v_div_scale_f32 leaves both operands alone (denominator and its reciprocal normal, numerator's exponent field above 23, quotient neither
+// denormal nor within 2^-32 of overflow), where v_div_fmas_f32 is an fma and v_div_fixup_f32 returns its first operand.
+VR_HD bool div_core_domain(float n, float d) {
+    const int32_t en = (int32_t)((f2u(n) >> 23) & 255u), ed = (int32_t)((f2u(d) >> 23) & 255u);
+    const bool d_ok = ed >= 27 && ed <= 227;
+    const bool n_ok = f2u(n) == 0u || (en >= 27 && en <= 227 && en - ed >= -100 && en - ed <= 100);
+    return d_ok && n_ok;
+}
+VR_HD float div_core(float n, float d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !VR_FAST_DEVICE && VR_DIV_CORE
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    const float q0 = n * r1;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+#else
+    return n / d;
+#endif
+}
 VR_HD float inf_() { return u2f(0x7F800000u); }
 VR_HD float nan_() { return u2f(0x7FC00000u); }
 

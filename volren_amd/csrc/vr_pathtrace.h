@@ -694,7 +694,7 @@ pathtrace_kernel(const KernelArgs A) {
             // empty asm that takes both values as operands keeps the two loads above it, back to back.
             asm volatile("" : "+v"(mio.maj1), "+v"(mio.maj2));
 #endif
-            if (is_m) march_finish<K::tf, K::maj_reuse>(l, P, mio);
+            if (is_m) march_finish<K::tf, K::maj_reuse, CLEAN>(l, P, mio);
 #else
             for (int32_t k = 0; k < 2; ++k)            // diagnostic: two plain steps, one majorant load each, only where a step runs
                 if (slot >= 0 && l.state == ST_MARCH) do_march<K::tf, K::dense, K::majb>(l, P);

@@ -174,6 +174,8 @@ struct SceneParams {
     const float* impmap;               // importance pyramid, level 0 (dim^2) first, 2x2 box mips after it
     int32_t imp_dim;
     const float* env_cdf;              // warp table: (d, e0, e1) per 2x2 block of every pyramid level, two levels per block; the finest with its texels (env_cdf_index)
+    int32_t env_div_safe;              // every d, e0, e1 of the table is NaN, 0 or in [2^-76, 1] (checked when the table is built): the warp's quotients may use div_core --
+                                       // which the kernels compiled for one scene kind do unconditionally: any other environment is rendered by the run-time variant
     float cam_z;                       // -.5f / tan(.5f * M_PI * cam_fov / 180.f), common.glsl:78 (uniform per frame)
 };
 

@@ -278,14 +278,16 @@ VR_HD float brick_value(const GridView& g, int32_t x, int32_t y, int32_t z) {
 #define VR_MAJ_LEVEL_TEST 0
 #endif
 // ---- "clean" segments (round 5, VR_CLEAN_FLAG) ------------------------------------------------------------------------------------------------------------
-// begin_segment marks a segment whose ray is finite and of moderate size -- |ipos| < 2^20 and |idir| * far < 2^20 per axis, all comparisons that fail for NaN --
+// begin_segment marks a segment whose ray is finite and of moderate size -- |ipos| < 2^20, |idir| < 2^20 and |idir| * far < 2^20 per axis, |idir| >= 2^-20 on one
+// axis at least; all comparisons that fail for NaN --
 // in the sign of Hot::far (clean: far as computed, >= 0; not clean: -far; every reader takes |far|, seg_far).  On such a segment every point the trackers
 // evaluate, p = ipos + t * idir with t < far, is finite with |p| < 2^21, and then:
 //   * floor(p) converts to int exactly, so "inside the padded table" is an INTEGER test on the cell coordinates the index needs anyway (three right shifts, an
 //     or3, one compare) instead of six float compares -- same set: 0 <= floor(x) < lim <=> 0 <= x < lim for the integer lim, and -0 is inside either way;
 //   * the three candidates of a DDA step are never NaN (the bracket floor(p / dim) * dim + o - p is exact and its modulus >= 0.5, and 1 / idir is finite or
 //     +-inf, never NaN): min(tx, min(ty, tz)) is ONE v_min3_f32 -- which differs from the reference's comparisons only in what it does with NaN;
-//   * a tap's coordinates are not NaN: no NaN guard on the voxel index.
+//   * a tap's coordinates are finite -- or, when the ray parameter itself has become NaN (0 / 0 in the step back to the collision point), NaN on all three axes, where
+//     the tap lands on index -1 by itself: no NaN guard on the voxel index (argument at nan_guard).
 // The scheduler (vr_pathtrace.h) runs the hot pair in the CLEAN form while every marching path of the wavefront is clean and in the general form otherwise; the
 // host harness picks the form per path (lane_step), so both are checked against the oracle on the CPU.
 #ifndef VR_CLEAN_FLAG
@@ -345,6 +347,13 @@ VR_HD float majorant_at(const SceneParams& P, v3 ipos, int32_t mip) {
     const int32_t idx = majorant_index<DENSE, MAJB>(P.density, ipos, mip);
     return majorant_of<TF>(P, idx, majorant_fetch<TF>(P.density, idx));
 }
+// A point of a CLEAN segment (seg_clean) needs no guard.  Its coordinates are finite with |p| < 2^21 -- or NaN on ALL THREE axes, when the ray parameter itself is NaN:
+// the reference's `t += tau / majorant` is 0 / 0 when a free-flight draw of exactly 0 meets an empty first cell (2^-24 per segment: dozens of times in a bench frame),
+// after which it still evaluates the collision there (every fetch outside, a null collision, the draws consumed) before the loop ends.  With NaN coordinates every
+// filter test of the stochastic tap compares false (fast form: x = NaN, and the call's min |x| stays +inf: not "unsure"; reference's form: r < NaN), so the tap is
+// floor + 0 - 1 with floor = (int)NaN = 0 on the device: index -1 on every axis, outside the grid, as the oracle's "NaN converts to outside"; and the trilinear lookup's
+// weights are NaN, so its value is NaN whatever its corners hold.  tests/test_gpu_parity.py::test_nan_ray_parameter_on_a_clean_segment renders 2^26 segments of that kind
+// of scene against the oracle.
 // a NaN coordinate must read "outside": on the device voxel_index turns NaN into index o, so one index is forced negative
 VR_HD int32_t nan_guard(int32_t ix, float fx, float fy, float fz) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -377,7 +386,7 @@ VR_HD void trilinear_prep(const GridView& g, v3 ipos, TriIO& io) {
     const float flx = floor_(qx), fly = floor_(qy), flz = floor_(qz);
     io.fx = qx - flx; io.fy = qy - fly; io.fz = qz - flz;
     const int32_t ix0 = voxel_index(flx, 0), ix1 = voxel_index(flx, 1);
-    const int32_t ix = GUARD ? nan_guard(ix0, flx, fly, flz) : ix0, iy = voxel_index(fly, 0), iz = voxel_index(flz, 0);     // GUARD = false: a point of a clean segment, not NaN
+    const int32_t ix = GUARD ? nan_guard(ix0, flx, fly, flz) : ix0, iy = voxel_index(fly, 0), iz = voxel_index(flz, 0);     // GUARD = false: a point of a clean segment (see nan_guard)
     const int32_t x1 = GUARD ? nan_guard(ix1, flx, fly, flz) : ix1, y1 = voxel_index(fly, 1), z1 = voxel_index(flz, 1);
     const bool dense = grid_is_dense<DENSE>(g);
     const uint32_t lg = dense ? 2u : 3u;
@@ -551,7 +560,7 @@ VR_HD void tricubic_fast_test(float k, float w, float s, bool& yes, bool& no) {
 
 // FAST: the guarded fast decision first, the reference's code only for a call with a draw inside a band (the device; the host harness can switch it on);
 // otherwise the reference's code always.  Both are compiled everywhere: tests/tools_tricubic_band.cpp runs one against the other.
-// GUARD = false: the coordinates are known not to be NaN (a tap on a clean segment): no NaN guard on the index
+// GUARD = false: a tap on a clean segment -- its coordinates are finite, or NaN on all three axes, which needs no guard (see nan_guard)
 template <bool FAST, bool GUARD = true>
 VR_HD void tricubic_tap_t(v3 ipos, uint32_t& seed, int32_t& tx, int32_t& ty, int32_t& tz) {
     int32_t jx = 0, jy = 0, jz = 0;
@@ -727,13 +736,22 @@ VR_HD v3 lookup_environment(const SceneParams& P, v3 dir) {
 // cell is in the line its parent's record came from.
 // one level of the descent (common.glsl:118-131: "if (r < p) r /= p; else { pos += 1; r = (r - p) / (1 - p); }" per axis, written
 // as operand selects + ONE division so that a wavefront whose lanes go both ways does not execute two); returns the child 0..3
+// SAFE: the two quotients by vr_math.h div_core -- in the kernels compiled for one scene kind, which are only launched with an environment whose table passed the check
+// when it was built (SceneParams::env_div_safe; vr_kernels.hip pathtrace_variant sends every other environment to the run-time variant, which divides in full).  The
+// domain holds by induction over the levels: a threshold is NaN, 0 or in [2^-76, 1]; a coordinate p starts as k 2^-24 and stays +0, NaN or in [2^-99, 1] -- "left"
+// (p < d, so d >= 2^-76) gives p / d in [p, 1); "right" gives (p - d) / (1 - d) with 1 - d >= 2^-24 (d <= p < 1) and p - d zero or at least an ulp of d, >= 2^-99,
+// at most 1 - d.  The exceptions are NaN either way and nothing but their NaN-ness is used afterwards: a NaN threshold (an empty block's 0 / 0), and 0 / 0 when p has
+// been rounded up to exactly 1 and meets a threshold of 1.
+template <bool SAFE = false>
 VR_HD int32_t env_warp_level(const float* rec, float& px, float& py, int32_t& posx, int32_t& posy) {
     const float d = rec[0], e0 = rec[1], e1 = rec[2];
     const bool right = !(px < d);
     const float e = right ? e1 : e0;
-    px = (right ? px - d : px) / (right ? 1.0f - d : d);
+    const float nx = right ? px - d : px, dx = right ? 1.0f - d : d;
+    px = SAFE ? div_core(nx, dx) : nx / dx;
     const bool up = !(py < e);
-    py = (up ? py - e : py) / (up ? 1.0f - e : e);
+    const float ny = up ? py - e : py, dy = up ? 1.0f - e : e;
+    py = SAFE ? div_core(ny, dy) : ny / dy;
     posx = 2 * posx + (right ? 1 : 0);
     posy = 2 * posy + (up ? 1 : 0);
     return (up ? 2 : 0) + (right ? 1 : 0);
@@ -742,7 +760,8 @@ VR_HD int32_t env_warp_level(const float* rec, float& px, float& py, int32_t& po
 #define VR_ENV_BLOCK_LOADS 1
 #endif
 // BLOCK: load a pair of levels' 64-byte block at once (below); off in the everything-at-run-time kernel, which has no registers for it
-template <bool BLOCK = true>
+// ENVDC: the warp's quotients by div_core (env_warp_level<true>): only for an environment whose table passed the check (SceneParams::env_div_safe)
+template <bool BLOCK = true, bool ENVDC = false>
 VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i, v3& Le, float& pdf_out) {
     int32_t posx = 0, posy = 0;
     float px = r0, py = r1;
@@ -751,7 +770,7 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
     float w_texel = 0.0f;                                       // importance of the texel the descent ends in == imp_fetch(P, posx, posy, 0)
     int32_t k = 0;
     if ((top & 1) == 0) {                                       // odd number of levels: level 0 alone
-        const int32_t c = env_warp_level(blk, px, py, posx, posy);
+        const int32_t c = env_warp_level<ENVDC>(blk, px, py, posx, posy);
         if (top == 0) w_texel = blk[3 + c];
         blk += kEnvCdfBlockFloats; k = 1;
     }
@@ -763,26 +782,26 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
         // levels instead of two dependent ones (the second was a hit in the line the first had fetched, but a round trip all the same)
         const float4 q0 = reinterpret_cast<const float4*>(b)[0], q1 = reinterpret_cast<const float4*>(b)[1], q2 = reinterpret_cast<const float4*>(b)[2], q3 = reinterpret_cast<const float4*>(b)[3];
         const float parent[3] = { q0.x, q0.y, q0.z };
-        const int32_t c = env_warp_level(parent, px, py, posx, posy);
+        const int32_t c = env_warp_level<ENVDC>(parent, px, py, posx, posy);
         const bool c_right = (c & 1) != 0, c_up = (c & 2) != 0;          // children: c0 = (q0.w q1.x q1.y)  c1 = (q1.z q1.w q2.x)  c2 = (q2.y q2.z q2.w)  c3 = (q3.x q3.y q3.z)
         const float lo_d = c_right ? q1.z : q0.w, lo_e0 = c_right ? q1.w : q1.x, lo_e1 = c_right ? q2.x : q1.y;
         const float hi_d = c_right ? q3.x : q2.y, hi_e0 = c_right ? q3.y : q2.z, hi_e1 = c_right ? q3.z : q2.w;
         const float child[3] = { c_up ? hi_d : lo_d, c_up ? hi_e0 : lo_e0, c_up ? hi_e1 : lo_e1 };
-        env_warp_level(child, px, py, posx, posy);
+        env_warp_level<ENVDC>(child, px, py, posx, posy);
         } else
 #endif
         {
-        const int32_t c = env_warp_level(b, px, py, posx, posy);
-        env_warp_level(b + 3 + 3 * c, px, py, posx, posy);
+        const int32_t c = env_warp_level<ENVDC>(b, px, py, posx, posy);
+        env_warp_level<ENVDC>(b + 3 + 3 * c, px, py, posx, posy);
         }
         blk += (size_t)kEnvCdfBlockFloats << (2 * k);
     }
     if (k < top) {                                              // the last pair: one 128-byte line, the finest records carry their four texels
         const int32_t s = (top & 1) ? 0 : 1;
         const float* b = P.env_cdf + env_cdf_last_pair_floats(s, (top + 1 - s) / 2) + kEnvCdfLastBlockFloats * (size_t)((posy << k) + posx);
-        const int32_t c = env_warp_level(b, px, py, posx, posy);
+        const int32_t c = env_warp_level<ENVDC>(b, px, py, posx, posy);
         const float* child = b + kEnvCdfLastChild0 + kEnvCdfLastChildFloats * c;
-        const int32_t c2 = env_warp_level(child, px, py, posx, posy);
+        const int32_t c2 = env_warp_level<ENVDC>(child, px, py, posx, posy);
         w_texel = child[3 + c2];
     }
     const float u = ((float)posx + px) * P.u.env_imp_inv_dim[0];
@@ -940,8 +959,12 @@ VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t sha
     h.state = ST_MARCH;
 #if VR_CLEAN_FLAG
     {   // a finite ray of moderate size (see seg_clean): every comparison fails for NaN, and inf * 0 is NaN
+        const float ax = abs_(h.idir.x), ay = abs_(h.idir.y), az = abs_(h.idir.z), amax = __builtin_fmaxf(ax, __builtin_fmaxf(ay, az));
         const bool clean = (int)(abs_(h.ipos.x) < kCleanBound) & (int)(abs_(h.ipos.y) < kCleanBound) & (int)(abs_(h.ipos.z) < kCleanBound) &
-                           (int)(abs_(h.idir.x) * tfar < kCleanBound) & (int)(abs_(h.idir.y) * tfar < kCleanBound) & (int)(abs_(h.idir.z) * tfar < kCleanBound);
+                           (int)(ax * tfar < kCleanBound) & (int)(ay * tfar < kCleanBound) & (int)(az * tfar < kCleanBound) &
+                           // ... and for the quotient by div_core (march_finish): DDA steps of moderate length.  (The largest component: a NaN one drops out of the
+                           // maximum and has failed its test above.  The majorants' size is the launch's business: vr_kernels.hip pathtrace_variant.)
+                           (int)(amax < kCleanBound) & (int)(amax >= 1.0f / kCleanBound);
         h.far = clean ? tfar : -tfar;
     }
 #endif
@@ -1049,7 +1072,12 @@ VR_HD void march_load_lds(const SceneParams& P, MarchIO& io, const T* lds, int32
     io.maj1 = majorant_fetch_lds<TF, T>(P.density, io.i1, lds, first, all_resident);
     io.maj2 = majorant_fetch_lds<TF, T>(P.density, io.i2, lds, first, all_resident);
 }
-template <bool TF, bool REUSE = false>
+// CLEAN (and no transfer function): the step back to the collision point, tau / majorant, by vr_math.h div_core.  Its domain: the majorant is density_scale x an fp16
+// range maximum, in [2^-40, 2^40] for the scales the kernels with a CLEAN form are launched with (2^-16 ... 2^24: vr_kernels.hip pathtrace_variant); tau = (what was left) - majorant x dt <= 0 with dt in [2^-22, 2^27] (a clean
+// segment's |idir| lies in [2^-20, 2^20] on one axis at least and below 2^20 on all: step_dda's bracket is between 0.5 and 65), so tau is +0 or has a modulus of at
+// least an ulp of the smaller operand, >= 2^-25 majorant dt >= 2^-87, and at most majorant dt: the quotient lies in [2^-48, 2^28].  A majorant of 0 only meets a
+// tau of -0 (a free-flight draw of exactly 0 in an empty cell): NaN by either form, and only its NaN-ness is used.
+template <bool TF, bool REUSE = false, bool CLEAN = false>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     if (!io.go1) { h.state = segment_end_state(h.shadow); return; }
     float t = io.t1, maj = majorant_of<TF>(P, io.i1, io.maj1);
@@ -1066,7 +1094,7 @@ VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
         q = q < 12 ? q + 1 : 12;
         if (tau > 0.0f) { h.t = t; h.tau = tau; h.mipq = q; return; }
     }
-    t += tau / maj;
+    t += (CLEAN && !TF) ? div_core(tau, maj) : tau / maj;
     h.t = t; h.tau = tau; h.mipq = q;
     if (t >= seg_far(h)) { h.state = segment_end_state(h.shadow); return; }
     h.majorant = maj;
@@ -1110,7 +1138,7 @@ template <bool TF, class T>
 VR_HD void march_load_lds(const SceneParams&, MarchIO&, const T*, int32_t) { static_assert(sizeof(T) == 0, "VR_MAJ_LDS is written for VR_MARCH_STEPS == 2"); }
 template <bool TF>
 VR_HD void march_load_reuse(const SceneParams& P, MarchIO& io, const Hot&) { march_load<TF>(P, io); }      // (majorant reuse is written for VR_MARCH_STEPS == 2)
-template <bool TF, bool REUSE = false>
+template <bool TF, bool REUSE = false, bool CLEAN = false>
 VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     static_assert(!REUSE, "majorant reuse is written for VR_MARCH_STEPS == 2");
     float tau = h.tau, maj = 0.0f, t = h.t;
@@ -1127,7 +1155,7 @@ VR_HD void march_finish(Hot& h, const SceneParams& P, const MarchIO& io) {
     h.t = t; h.tau = tau; h.mipq = q;                              // still marching
     return;
 tentative_collision:
-    t += tau / maj;
+    t += (CLEAN && !TF) ? div_core(tau, maj) : tau / maj;
     h.t = t; h.tau = tau; h.mipq = q;
     if (t >= seg_far(h)) { h.state = segment_end_state(h.shadow); return; }
     h.majorant = maj;
@@ -1164,8 +1192,8 @@ template <class K> struct CollideIO {
 // PE: where the emission grid's view and transform are read from.  The scheduler passes the kernel arguments behind a pointer there
 // (event_args(), vr_pathtrace.h): ~45 uniform dwords that only the emission tap needs are then fetched by scalar loads inside the collision
 // code instead of living in scalar registers through the whole scheduler loop (the emission kernels were the ones spilling them).
-// CLEAN: the path stands on a clean segment (seg_clean) -- its collision point, t < far, is finite: the density tap needs no NaN guard (the emission tap keeps
-// it: its point goes through one more transform)
+// CLEAN: the path stands on a clean segment (seg_clean) -- its collision point is finite, or NaN on all three axes (t = NaN): the density tap needs no NaN guard
+// (the emission tap keeps it: its point goes through one more transform)
 template <class K, bool CLEAN = false>
 VR_HD void collide_prep(Hot& h, const SceneParams& P, const SceneParams& PE, CollideIO<K>& io) {
     const v3 ip = axpy(h.ipos, h.t, h.idir);
@@ -1248,7 +1276,10 @@ VR_HD void collide_finish(Hot& h, Cold& c, const SceneParams& P, const ScenePara
         }
     } else {
         if (rng(h.seed) * h.majorant < d) {
-            h.Tr *= max_(0.0f, 1.0f - u.vol_majorant / h.majorant);
+            // (kernels of one scene kind without a transfer function: both majorants are density_scale x an fp16 number, density_scale in [2^-16, 2^24] -- vr_kernels.hip
+            // pathtrace_variant --, the quotient in [1, 2^40]: div_core's domain.  The lane of a NaN collision point, whose cell majorant is 0, does not get here: 0 < 0.)
+            const float ratio = (K::global == 0 && !K::tf) ? div_core(u.vol_majorant, h.majorant) : u.vol_majorant / h.majorant;
+            h.Tr *= max_(0.0f, 1.0f - ratio);
             if (h.Tr < 0.1f) {
                 const float prob = 1.0f - h.Tr;
                 if (rng(h.seed) < prob) { h.Tr = 0.0f; h.state = ST_POSTNEE; return; }
@@ -1311,7 +1342,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     const float r0 = rng(h.seed), r1 = rng(h.seed);
     float pdf;
     v3 w_i, Le;
-    sample_environment<K::global != 2>(P, r0, r1, w_i, Le, pdf);
+    sample_environment<K::global != 2, K::global != 2>(P, r0, r1, w_i, Le, pdf);      // (the kernels of one scene kind; the run-time variant loads record by record and divides in full)
     c.st(C_SHPDF, pdf);
     if (pdf > 0.0f) {
         const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
@@ -1548,7 +1579,7 @@ VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, 
         if (h.first) { stash.dir = h.ipos; stash.item = f2u(h.Tr); first_resume(h, P); }      // = HotStore::save_new + load_resume
         break;
     // two DDA steps, as on the device; a path on a clean segment in the forms the device runs for a wavefront of such paths
-    case ST_MARCH: { MarchIO io; if (seg_clean(h)) march_prep<K::dense, K::majb, true>(h, P, io); else march_prep<K::dense, K::majb, false>(h, P, io); march_load<K::tf>(P, io); march_finish<K::tf>(h, P, io); break; }
+    case ST_MARCH: { MarchIO io; if (seg_clean(h)) march_prep<K::dense, K::majb, true>(h, P, io); else march_prep<K::dense, K::majb, false>(h, P, io); march_load<K::tf>(P, io); if (seg_clean(h)) march_finish<K::tf, false, true>(h, P, io); else march_finish<K::tf, false, false>(h, P, io); break; }
     case ST_COLLIDE: if (seg_clean(h)) do_collide<K, Cold, true>(h, c, P); else do_collide<K, Cold, false>(h, c, P); break;
     case ST_NEE: do_nee<K>(h, c, c, P); break;
     case ST_POSTNEE: do_postnee<K>(h, c, P, wu); break;
