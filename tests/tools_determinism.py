@@ -1,5 +1,6 @@
 """Diagnostic: the same frame rendered N times by fresh and reused renderers, in the bit-exact and the tolerance mode -- every CRC of a mode must be the same.
-usage: tools_determinism.py [cfg] [size] [spp] [n]"""
+With `poison` the workspace and the sample pool are filled with NaN patterns before every launch (VR_TEST_POISON_WORKSPACE=2, renderer.cpp).
+usage: tools_determinism.py [cfg] [size] [spp] [n] [poison]"""
 import os, sys, zlib
 sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))]
 import numpy as np
@@ -9,6 +10,8 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+if len(sys.argv) > 5 and sys.argv[5] == "poison":
+    os.environ["VR_TEST_POISON_WORKSPACE"] = "2"
 crcs = {0: [], 1: []}
 keep = []
 for k in range(n):

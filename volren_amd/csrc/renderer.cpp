@@ -600,6 +600,12 @@ void RendererHIP::submit(const LaunchInputs& in, int first, int n) {
         // test hook: no path may depend on what its cold line held before the path wrote it (tests/test_gpu_parity.py)
         if (const char* e = std::getenv("VR_TEST_POISON_WORKSPACE"); e && *e == '1') VR_HIP(hipMemsetAsync(workspace_->get(), 0xFF, workspace_->size_bytes(), stream));
     }
+    // test hook, value 2: NaN patterns in the workspace AND the sample pool before EVERY submit -- a frame must not depend on what an earlier frame (of this or of
+    // another mode's kernels) left in either (tests/tools_determinism.py, test_frames_are_reproducible_on_every_compiled_instance)
+    if (const char* e = std::getenv("VR_TEST_POISON_WORKSPACE"); e && *e == '2') {
+        VR_HIP(hipMemsetAsync(workspace_->get(), 0xFF, workspace_->size_bytes(), stream));
+        VR_HIP(hipMemsetAsync(pool_->get(), 0xFF, pool_->size_bytes(), stream));
+    }
     const int integ = P.u.integrator;
     const bool pt_kernel = !(integ == 3 || (integ == 2 && has_tf));      // launch_pathtrace records the events around the path-tracing kernel only
     // Launch sizing by time (round 4): no sub-launch is PLANNED to take longer than launch_target_ms.  The plan uses the rate of this renderer's last

@@ -658,6 +658,12 @@ pathtrace_kernel(const KernelArgs A) {
 #ifndef VR_HOT_PAIR_MIN
 #define VR_HOT_PAIR_MIN 44
 #endif
+        // VR_DRAIN (round 6, build-time experiment): once the work queue is empty a wavefront's pool only shrinks, and the launch ends with the latency of the deepest
+        // path (profiles/r4f_*).  1: a draining wavefront runs its further copies of the hot pair for any number of lanes and, when hungry, EVERY non-empty event batch
+        // per iteration instead of the largest only (nothing is left to fill the others up)
+#ifndef VR_DRAIN
+#define VR_DRAIN 0
+#endif
         // VR_BALLOT_VALID (round 5): `slot` does not change inside the hot pair, so "the lane holds a path" is ONE ballot per scheduler iteration and the pair's
         // counts are ballots of a single compare ANDed with it on the scalar unit; a ballot of `slot >= 0 && state == X` costs a v_cndmask + v_cmp more each
 #ifndef VR_BALLOT_VALID
@@ -675,7 +681,7 @@ pathtrace_kernel(const KernelArgs A) {
         auto hot_pair = [&](auto clean_tag, const int hot_rep_) __attribute__((always_inline)) -> bool {
             constexpr bool CLEAN = decltype(clean_tag)::value;
 #if VR_BALLOT_VALID
-            if (hot_rep_ > 0 && popc_s(holds_path & wave_ballot((uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) return false;
+            if (hot_rep_ > 0 && popc_s(holds_path & wave_ballot((uint32_t)(l.state - ST_MARCH) < 2u)) < (VR_DRAIN && exhausted ? 1 : VR_HOT_PAIR_MIN)) return false;
 #else
             if (hot_rep_ > 0 && popc(wave_ballot(slot >= 0 && (uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) return false;
 #endif
@@ -788,10 +794,11 @@ pathtrace_kernel(const KernelArgs A) {
         if (cnt_nee > big) big = cnt_nee;
         if (cnt_post > big) big = cnt_post;
         if (cnt_esc > big) big = cnt_esc;
+        const bool drain_all = VR_DRAIN && exhausted;
         const bool want_new = c_new > 0 && (c_new >= VR_THR_NEW || (hungry && c_new == big));
-        const bool want_nee = cnt_nee > 0 && (cnt_nee >= VR_THR_NEE || (hungry && cnt_nee == big));
-        const bool want_post = cnt_post > 0 && (cnt_post >= VR_THR_POST || (hungry && cnt_post == big));
-        const bool want_esc = cnt_esc > 0 && (cnt_esc >= VR_THR_ESC || (hungry && cnt_esc == big));
+        const bool want_nee = cnt_nee > 0 && (cnt_nee >= VR_THR_NEE || (hungry && (cnt_nee == big || drain_all)));
+        const bool want_post = cnt_post > 0 && (cnt_post >= VR_THR_POST || (hungry && (cnt_post == big || drain_all)));
+        const bool want_esc = cnt_esc > 0 && (cnt_esc >= VR_THR_ESC || (hungry && (cnt_esc == big || drain_all)));
         if (want_new || want_nee || want_post || want_esc) {
             // the lanes double as batch workers.  VR_BATCH_REGS=1: the batch path lives in its own register set `b` and the
             // marching path `l` stays put; =0: the marching path is saved to its LDS slot and `l` is reused (fewer VGPRs)
