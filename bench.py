@@ -499,11 +499,12 @@ def run_sharded(args):
              launches=l0, samples_per_launch=(own0 * 256.0 * spp if len(devices) > 1 else samples) / l0)
     crc = zlib.crc32(s.framebuffer().tobytes()) & 0xFFFFFFFF
     transport = s.transport
+    collective = s.collective if transport == "rccl" else None
     s.close()
     out = {
         "metric": "Msamples/s (pixels x spp / s), volume path tracing",
         "value": m["value"], "unit": "Msamples/s", "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "host": "sharded", "transport": transport,
+        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "host": "sharded", "transport": transport, "collective": collective,
         "devices": devices, "distinct_devices": len(set(devices)),
         "frame_crc32": crc, "vs_baseline": None, "dtype": "f32",
         "data": ("synthetic grid (tests/scenes.py generator) + reference envmap" if args.config[:2] in ("c4", "c5") else "reference fixtures (smoke.brick, table_mountain_2_puresky_1k.hdr)" + (", lut.txt" if args.config == "c3" else "")),
@@ -527,7 +528,7 @@ def sharded_leg(args, world):
                                                                  "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "NCCL_ASYNC")))}
         cmd = [sys.executable, os.path.abspath(__file__), "--host", "sharded", "--gpus", str(world), "--devices", ",".join(str(d) for d in devices), "--steps", str(args.steps),
                "--warmup", str(args.warmup), "--config", args.config, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--cpu-budget", "0"]
-        proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("VOLREN_SHARDED_LEG_TIMEOUT", "150")))
+        proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("VOLREN_SHARDED_LEG_TIMEOUT", "120")))
         lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
         if proc.returncode != 0 or not lines:
             return {"error": "exit %d: %s" % (proc.returncode, (proc.stderr or proc.stdout)[-600:])}
@@ -701,6 +702,16 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             time.sleep(1.0)                                    # the other ranks are exiting
+            # the headline measurement is safe before the leg starts (a kill of rank 0 during the leg's up to VOLREN_SHARDED_LEG_TIMEOUT seconds would
+            # otherwise lose it): the line as it stands goes to stderr and to gpurun_out/bench_headline.json; stdout still gets exactly ONE line, below
+            try:
+                sys.stderr.write("bench.py: headline before the sharded leg: " + json.dumps(out) + "\n")
+                sys.stderr.flush()
+                os.makedirs(os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out"), exist_ok=True)
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out", "bench_headline.json"), "w") as f:
+                    json.dump(out, f)
+            except OSError:
+                pass
             leg = sharded_leg(args, world)
             out["sharded"] = leg
             out["value_sharded"] = leg.get("value")

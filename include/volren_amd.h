@@ -100,6 +100,11 @@ int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
  *     renderer's parts; default), 2 = always.  Results never depend on the order) (int);  "tonemap_exposure" "tonemap_gamma" "albedo"(3) "phase" "density_scale"
  *     "emission_scale" "vol_clip_min"(3) "vol_clip_max"(3) "env_strength" "env_transform"(9) "env_rot"(1, degrees about +y,
  *     main.cpp:382) "tf_window_left" "tf_window_width" "cam_pos"(3) "cam_dir"(3) "cam_up"(3) "cam_fov" "volume_transform"(16) (float) */
+/* read-only through vr_get_int: "kernel_variant" (the compiled path-tracing kernel the next launch uses: 0 brick grid, 1 dense fp16 grid, 2 / 4 brick grid +
+ *     emission grid, 3 everything decided at run time -- correct for every scene, up to an order of magnitude slower) and "kernel_variant_reason" (what sent the
+ *     scene to variant 3, a mask: 1 integrator != 0, 2 the environment's warp table has thresholds below 2^-76 ("env_div_safe" = 0), 4 density scale outside
+ *     [2^-16, 2^24], 8 emission grid with a dense grid / brick grids of different layouts; 0: the scene has a kernel of its own kind).  Reasons 2 and 4 are also
+ *     said once per process on stderr: a caller cannot see them coming */
 int vr_set_int(vr_renderer* r, const char* name, int value);
 int vr_get_int(vr_renderer* r, const char* name, int* value);
 int vr_set_float(vr_renderer* r, const char* name, const float* values, int count);
@@ -153,8 +158,9 @@ int vr_unpack_tiles(vr_renderer* r, const int32_t* tile_ids_device, int n_tiles,
  *     SURVEY.md 8e; volren_amd/csrc/sharded.h).  vr_sharded_create makes n_parts renderers, part i on HIP device devices[i] (vr_create each).
  *     The scene is REPLICATED by the caller: apply the scene calls of this header (vr_load_volume, vr_set_float, ...) to every
  *     vr_sharded_part(s, i).  vr_sharded_render deals the frame's 16x16 tiles diagonally (owner = (tx + ty) mod n_parts), lets every part
- *     render `spp` more samples of its tiles on its own stream, and gathers the accumulated radiance with ONE grouped ncclAllGather per frame
- *     (RCCL over xGMI; librccl.so.1 is opened at run time); afterwards part 0's framebuffer (vr_framebuffer / vr_save_png on
+ *     render `spp` more samples of its tiles on its own stream, and gathers the accumulated radiance with ONE collective per frame
+ *     (RCCL over xGMI; librccl.so.1 is opened at run time): grouped ncclSend / ncclRecv to part 0 ("gather", the default: only part 0 needs -- and
+ *     allocates -- the whole frame), or a grouped ncclAllGather with VR_SHARDED_COLLECTIVE=allgather (rounds 4-5); vr_sharded_collective says which; afterwards part 0's framebuffer (vr_framebuffer / vr_save_png on
  *     vr_sharded_part(s, 0)) holds the whole frame, bit-identical to a single-device render.  Parts that share a device (logical shards:
  *     devices = {0, 0, 0}) exchange their tiles with device-to-device copies instead -- vr_sharded_transport says which: "rccl", "copy", or
  *     "none" for one part; environment VR_SHARDED_TRANSPORT=copy|rccl overrides (rccl also with ONE part: a one-rank communicator).
@@ -166,6 +172,7 @@ void vr_sharded_destroy(vr_sharded* s);
 int vr_sharded_parts(vr_sharded* s);
 vr_renderer* vr_sharded_part(vr_sharded* s, int i);
 const char* vr_sharded_transport(vr_sharded* s);
+const char* vr_sharded_collective(vr_sharded* s);         /* "gather" | "allgather": what the rccl transport runs per frame */
 int vr_sharded_reset(vr_sharded* s);                      /* vr_reset on every part */
 int vr_sharded_render(vr_sharded* s, int spp);
 int vr_sharded_synchronize(vr_sharded* s);

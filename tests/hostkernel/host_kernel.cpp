@@ -104,9 +104,9 @@ static void trace_access(const Hot& h, const SceneParams& P) {
     if (g_trace_n >= g_trace_cap) return;
     const v3 c = axpy(h.ipos, h.t, h.idir);
     if (h.state == ST_MARCH) {
-        if (!(h.t < h.far)) return;
+        if (!(h.t < seg_far(h))) return;                                               // (the sign of `far` carries the clean flag: vr_trace.h seg_clean)
         const int32_t idx = majorant_index<2>(P.density, c, round_mip_q(h.mipq));
-        if (idx >= 0) g_trace[g_trace_n++] = (uint32_t)idx >> 6;                       // 64 fp16 cells per 128-byte line
+        if (idx >= 0 && idx != P.density.maj_outside) g_trace[g_trace_n++] = (uint32_t)idx >> 6;      // 64 fp16 cells per 128-byte line; a step outside the table reads its one shared "outside" cell: not a gather
     } else {
         const int32_t x = (int32_t)floor_(c.x), y = (int32_t)floor_(c.y), z = (int32_t)floor_(c.z);
         if (x < 0 || y < 0 || z < 0) return;

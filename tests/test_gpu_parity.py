@@ -737,132 +737,111 @@ def test_volpy_grid_frames():
     assert np.array_equal(_bits(np.asarray(renderer.fbo_data()).reshape(H, W, 3)), _bits(ref[..., :3])), "edit after the unit cube"
 
 
-def test_volpy_runs_the_reference_script_bodies(tmp_path):
-    """The bodies of scripts/datagen_colmap.py:46-95 and scripts/datagen_denoise.py:85-117 (restated as calls, scaled down:
-    2 views / 2 images, a handful of samples) run against volren_amd.volpy with nothing changed but the module: glm-like
-    vec3 arithmetic, Volume.AABB(), resolution().x, the reference's ORDER of density_scale -> scale_and_move_to_unit_cube()
-    -> commit() (datagen_colmap.py:57-63: the unit-cube factor multiplies the caller's density scale), commit() of a file
-    volume WITHOUT the unit cube (datagen_denoise.py:85-86), TransferFunction.randomize(), transferfunc = None.  Every
-    frame is compared bit for bit with the oracle configured from the same numbers."""
-    import math
-    import random
-    from scipy.stats import qmc
+def _volpy_look_at_volume(volpy, renderer, u_pos, u_aim):
+    """Places the volpy camera on the bounding sphere of the density grid, aimed near its centre; u_pos / u_aim are points of [0, 1)^2 mapped to the
+    sphere by the cylinder projection.  Uses only what a volpy script has: Volume.AABB(), vec3 arithmetic, .length(), .normalize()."""
+    def on_sphere(u):
+        h = 1.0 - 2.0 * float(u[0])
+        rho = float(np.sqrt(max(0.0, 1.0 - h * h)))
+        a = 2.0 * np.pi * float(u[1])
+        return volpy.vec3(rho * float(np.cos(a)), rho * float(np.sin(a)), h)
+    lo, hi = renderer.volume.AABB("density")
+    mid = lo + (hi - lo) * 0.5
+    rad = (hi - mid).length()
+    renderer.cam_pos = mid + on_sphere(u_pos) * rad
+    renderer.cam_dir = (mid + on_sphere(u_aim) * rad * 0.1 - renderer.cam_pos).normalize()
+    return rad
+
+
+def _oracle_for_volpy(ob, renderer, w, h, unit_cube):
+    """The oracle set up from the numbers a volpy renderer holds (not from the calls that put them there)."""
+    o = ob.OracleRenderer(w, h)
+    o.load_envmap(scenes.HDR)
+    o.load_volume(scenes.SMOKE)                                    # leaves the unit-cube transform and density_scale = the cube's size
+    if not unit_cube:
+        o.volume_transform = np.eye(4, dtype=np.float32).reshape(16).copy()
+    return o
+
+
+def test_volpy_call_protocol_of_the_data_generation_scripts(tmp_path):
+    """The call protocol the reference's data-generation drivers rely on (scripts/datagen_colmap.py:46-95, scripts/datagen_denoise.py:83-121), exercised on
+    volren_amd.volpy and checked frame by frame, bit for bit, against the oracle:
+      A. density_scale set BEFORE scale_and_move_to_unit_cube() -> commit(): the cube's factor multiplies the caller's scale (src/renderer.cpp:240);
+         AABB() then reports the unit cube; the COLMAP helpers and resolution() answer; save_with_alpha() writes a file;
+      B. commit() of a file volume WITHOUT the unit cube keeps the file's transform; TransferFunction.randomize(n) + window, and transferfunc = None
+         switch kernels between frames; seed / bounces changed between two render() calls of one set-up; fbo_data() is (h, w, 3), bottom row first."""
     from oracle import binding as ob
     import volren_amd.volpy as volpy
     W, H = 64, 48
+    rng = np.random.RandomState(20260)
 
-    def sample_unit_sphere(sample):                                       # datagen_colmap.py:12-17
-        z = 1.0 - 2.0 * sample[0]
-        r = math.sqrt(max(0.0, 1.0 - z * z))
-        phi = 2.0 * math.pi * sample[1]
-        return volpy.vec3(r * math.cos(phi), r * math.sin(phi), z)
-
-    # ---- datagen_colmap.py ----
-    N_VIEWS, ALBEDO, PHASE, DENSITY_SCALE, ENV_STRENGTH, SAMPLES, BOUNCES, FOVY, SEED = 2, volpy.vec3(0.9, 0.9, 0.9), 0.5, 0.75, 2.0, 4, 16, 70, 42
+    # ---- A: unit cube, several views of one set-up ----
     renderer = volpy.Renderer(W, H)
     renderer.init()
     renderer.draw()
-    renderer.seed = SEED
-    renderer.bounces = BOUNCES
-    renderer.volume = volpy.Volume(scenes.SMOKE)
-    renderer.albedo = ALBEDO
-    renderer.phase = PHASE
-    renderer.density_scale = DENSITY_SCALE
-    renderer.environment = volpy.Environment(scenes.HDR)
-    renderer.environment.strength = ENV_STRENGTH
-    renderer.show_environment = True
-    renderer.tonemapping = True
+    for name, value in (("seed", 42), ("bounces", 16), ("volume", volpy.Volume(scenes.SMOKE)), ("albedo", volpy.vec3(0.9, 0.9, 0.9)), ("phase", 0.5),
+                        ("density_scale", 0.75), ("environment", volpy.Environment(scenes.HDR)), ("show_environment", True), ("tonemapping", True)):
+        setattr(renderer, name, value)
+    renderer.environment.strength = 2.0
     renderer.scale_and_move_to_unit_cube()
     renderer.commit()
-    xyz, rgb = np.array(renderer.volume.AABB("density")[0]), np.array(renderer.volume.AABB("density")[1])
-    assert np.allclose(xyz, [-0.25, -0.5, -0.25], atol=1e-6) and np.allclose(rgb, [0.25, 0.5, 0.25], atol=1e-6)      # smoke.brick in the unit cube
-    params = np.array([renderer.colmap_focal_length(), renderer.resolution().x // 2, renderer.resolution().y // 2])
-    assert params[1] == 32 and params[2] == 24
-    samplerOut, samplerIn = qmc.Sobol(d=2, seed=SEED + 1), qmc.Sobol(d=2, seed=SEED + 2)
-    o = ob.OracleRenderer(W, H)
-    o.load_envmap(scenes.HDR)
-    o.load_volume(scenes.SMOKE)                                           # unit cube: density_scale = size
-    o.density_scale = float(np.float32(DENSITY_SCALE) * np.float32(o.density_scale))
-    o.env_strength, o.albedo, o.phase, o.bounces, o.seed = ENV_STRENGTH, (0.9, 0.9, 0.9), PHASE, BOUNCES, SEED
+    lo, hi = (np.array(v) for v in renderer.volume.AABB("density"))
+    assert np.allclose(lo, [-0.25, -0.5, -0.25], atol=1e-6) and np.allclose(hi, [0.25, 0.5, 0.25], atol=1e-6)
+    assert (renderer.resolution().x // 2, renderer.resolution().y // 2) == (W // 2, H // 2) and renderer.colmap_focal_length() > 0
+    o = _oracle_for_volpy(ob, renderer, W, H, unit_cube=True)
+    o.density_scale = float(np.float32(0.75) * np.float32(o.density_scale))
     assert abs(renderer.density_scale - o.density_scale) < 1e-4 * o.density_scale
-    for i in range(N_VIEWS):
-        bb_min, bb_max = renderer.volume.AABB("density")
-        center = bb_min + (bb_max - bb_min) * 0.5
-        radius = (bb_max - center).length()
-        renderer.cam_pos = center + sample_unit_sphere(samplerOut.random()[0, 0:2]) * radius
-        renderer.cam_dir = (center + sample_unit_sphere(samplerIn.random()[0, 0:2]) * radius * 0.1 - renderer.cam_pos).normalize()
-        renderer.cam_fov = FOVY
-        renderer.render(SAMPLES)
+    o.env_strength, o.albedo, o.phase, o.bounces, o.seed = 2.0, (0.9, 0.9, 0.9), 0.5, 16, 42
+    for view in range(2):
+        _volpy_look_at_volume(volpy, renderer, rng.rand(2), rng.rand(2))
+        renderer.cam_fov = 70
+        renderer.render(4)
         renderer.draw()
-        renderer.save_with_alpha(os.path.join(str(tmp_path), "view_%06d.png" % i))
-        qvec, tvec = np.array(renderer.colmap_view_rot())[[3, 0, 1, 2]], np.array(renderer.colmap_view_trans())
-        assert qvec.shape == (4,) and tvec.shape == (3,) and abs(np.linalg.norm(qvec) - 1) < 1e-5
-        o.cam_pos, o.cam_dir, o.cam_fov = tuple(np.array(renderer.cam_pos).tolist()), tuple(np.array(renderer.cam_dir).tolist()), FOVY
-        o.sample = 0
-        _assert_same(renderer._r.framebuffer(), o.render(SAMPLES), "datagen_colmap view %d" % i)
+        out = os.path.join(str(tmp_path), "view_%06d.png" % view)
+        renderer.save_with_alpha(out)
+        assert os.path.getsize(out) > 0
+        q, t = np.array(renderer.colmap_view_rot()), np.array(renderer.colmap_view_trans())
+        assert q.shape == (4,) and t.shape == (3,) and abs(np.linalg.norm(q) - 1) < 1e-5
+        o.cam_pos, o.cam_dir, o.cam_fov, o.sample = tuple(np.array(renderer.cam_pos).tolist()), tuple(np.array(renderer.cam_dir).tolist()), 70, 0
+        _assert_same(renderer._r.framebuffer(), o.render(4), "unit cube, view %d" % view)
     renderer.shutdown()
 
-    # ---- datagen_denoise.py ----
-    random.seed(7)
-    N_SAMPLES_TARGET = 12
+    # ---- B: the file's own transform, kernels switched between images, two renders per set-up ----
     renderer = volpy.Renderer(W, H)
     renderer.init()
     renderer.draw()
-    SIZE = renderer.resolution()
-
-    def uniform_sample_sphere():
-        z = 1.0 - 2.0 * random.random()
-        r = math.sqrt(max(0.0, 1.0 - z * z))
-        phi = 2.0 * math.pi * random.random()
-        return volpy.vec3(r * math.cos(phi), r * math.sin(phi), z)
-
-    for i, use_tf in enumerate((False, True)):
-        p = dict(samples=random.randint(1, 8), max_bounces=random.randint(1, 33), seed_input=random.randint(0, 2 ** 31 - 1), seed_target=random.randint(0, 2 ** 31 - 1),
-                 env_strength=0.5 + random.random() * 10, env_show=random.random() < 0.5, lut_n_bins=random.randint(2, 33), lut_window_left=random.random() * 0.25,
-                 lut_window_width=random.random(), vol_albedo=volpy.vec3(random.random(), random.random(), random.random()), vol_phase=-0.9 + random.random() * 1.8,
-                 vol_density_scale=0.01 + random.random() * 5, cam_pos_sample=uniform_sample_sphere(), cam_dir_sample=uniform_sample_sphere(), cam_fov=25 + random.random() * 70)
+    for image, lut_bins in enumerate((0, 9)):
+        albedo = tuple(float(v) for v in rng.rand(3))
+        setup = dict(phase=float(rng.uniform(-0.9, 0.9)), density_scale=float(rng.uniform(0.01, 5.0)), show_environment=bool(rng.rand() < 0.5))
+        strength, fov, bounces = float(rng.uniform(0.5, 10.0)), float(rng.uniform(25, 95)), int(rng.randint(1, 34))
         renderer.volume = volpy.Volume(scenes.SMOKE)
-        renderer.commit()                                                 # no unit cube: the file's own transform
-        renderer.albedo = p["vol_albedo"]
-        renderer.phase = p["vol_phase"]
-        renderer.density_scale = p["vol_density_scale"]
+        renderer.commit()
+        renderer.albedo = volpy.vec3(*albedo)
+        for name, value in setup.items():
+            setattr(renderer, name, value)
         renderer.environment = volpy.Environment(scenes.HDR)
-        renderer.environment.strength = p["env_strength"]
-        renderer.show_environment = p["env_show"]
-        if use_tf:
+        renderer.environment.strength = strength
+        o = _oracle_for_volpy(ob, renderer, W, H, unit_cube=False)
+        if lut_bins:
             renderer.transferfunc = volpy.TransferFunction()
-            renderer.transferfunc.randomize(p["lut_n_bins"])
-            renderer.transferfunc.window_left = p["lut_window_left"]
-            renderer.transferfunc.window_width = p["lut_window_width"]
+            renderer.transferfunc.randomize(lut_bins)
+            renderer.transferfunc.window_left, renderer.transferfunc.window_width = 0.1, 0.8
+            o.set_transferfunc(renderer.transferfunc.lut)
+            o.tf_window_left, o.tf_window_width = 0.1, 0.8
         else:
             renderer.transferfunc = None
-        bb_min, bb_max = renderer.volume.AABB("density")
-        center = bb_min + (bb_max - bb_min) * 0.5
-        radius = (bb_max - center).length()
-        assert radius > 50                                                # world units of the file: not the unit cube
-        renderer.cam_pos = center + p["cam_pos_sample"] * radius
-        renderer.cam_dir = (center + p["cam_dir_sample"] * radius * 0.1 - renderer.cam_pos).normalize()
-        renderer.cam_fov = p["cam_fov"]
-        o = ob.OracleRenderer(W, H)
-        o.load_envmap(scenes.HDR)
-        o.load_volume(scenes.SMOKE)
-        o.volume_transform = np.eye(4, dtype=np.float32).reshape(16).copy()   # commit() without scale_and_move_to_unit_cube()
-        o.density_scale = p["vol_density_scale"]
-        o.albedo, o.phase, o.env_strength, o.show_environment = tuple(np.array(p["vol_albedo"]).tolist()), p["vol_phase"], p["env_strength"], p["env_show"]
-        if use_tf:
-            o.set_transferfunc(renderer.transferfunc.lut)
-            o.tf_window_left, o.tf_window_width = p["lut_window_left"], p["lut_window_width"]
-        o.cam_pos, o.cam_dir, o.cam_fov = tuple(np.array(renderer.cam_pos).tolist()), tuple(np.array(renderer.cam_dir).tolist()), p["cam_fov"]
-        for seed, spp, what in ((p["seed_input"], p["samples"], "input"), (p["seed_target"], N_SAMPLES_TARGET, "target")):
-            renderer.seed = seed
-            renderer.bounces = p["max_bounces"]
+        assert _volpy_look_at_volume(volpy, renderer, rng.rand(2), rng.rand(2)) > 50       # world units of the file, not the unit cube
+        renderer.cam_fov = fov
+        o.albedo, o.phase, o.density_scale, o.show_environment, o.env_strength = albedo, setup["phase"], setup["density_scale"], setup["show_environment"], strength
+        o.cam_pos, o.cam_dir, o.cam_fov = tuple(np.array(renderer.cam_pos).tolist()), tuple(np.array(renderer.cam_dir).tolist()), fov
+        for seed, spp in ((int(rng.randint(0, 2 ** 31 - 1)), int(rng.randint(1, 9))), (int(rng.randint(0, 2 ** 31 - 1)), 12)):
+            renderer.seed, renderer.bounces = seed, bounces
             renderer.render(spp)
-            data = np.flip(np.array(renderer.fbo_data()), axis=0)
-            chw = np.transpose(data.astype(np.float16), [2, 1, 0])
-            assert chw.shape == (3, SIZE.y, SIZE.x)
+            rows = np.array(renderer.fbo_data())
+            assert np.transpose(np.flip(rows, axis=0), [2, 1, 0]).shape == (3, renderer.resolution().y, renderer.resolution().x)
             renderer.draw()
-            o.seed, o.bounces, o.sample = seed, p["max_bounces"], 0
-            _assert_same(renderer._r.framebuffer(), o.render(spp), "datagen_denoise image %d %s" % (i, what))
+            o.seed, o.bounces, o.sample = seed, bounces, 0
+            _assert_same(renderer._r.framebuffer(), o.render(spp), "file transform, image %d, %d spp" % (image, spp))
     renderer.shutdown()
 
 
@@ -1812,6 +1791,8 @@ def test_environment_whose_warp_table_fails_the_division_check(scene):
     o.set_envmap(env)
     r.set_envmap(env)
     assert r.env_div_safe == 1
+    own_kind = {"c2": 0, "c5:64": 2}[scene]
+    assert (r.kernel_variant, r.kernel_variant_reason) == (own_kind, 0)      # the scene's own kernel (vr_get_int "kernel_variant", include/volren_amd.h)
     r.render(4)
     _assert_same(r.framebuffer(), o.render(4).copy(), "random environment")
     env[2:5, 4:7] = 1e-30                                      # a flat dark patch: where it meets the bilinear ramp to its neighbours the fine levels' thresholds are ~1e-28
@@ -1820,6 +1801,7 @@ def test_environment_whose_warp_table_fails_the_division_check(scene):
         x.set_envmap(env)
         x.reset()
     assert r.env_div_safe == 0
+    assert (r.kernel_variant, r.kernel_variant_reason) == (3, 2)             # the fallback is visible to the caller, with its reason (and said once on stderr)
     r.render(4)
     _assert_same(r.framebuffer(), o.render(4).copy(), "environment with thresholds below 2^-76")
     env = rs.uniform(0.2, 1.0, (8, 16, 3)).astype(np.float32)
@@ -1828,5 +1810,6 @@ def test_environment_whose_warp_table_fails_the_division_check(scene):
         x.density_scale = 1e-6                                 # outside [2^-16, 2^24]
         x.reset()
     assert r.env_div_safe == 1
+    assert (r.kernel_variant, r.kernel_variant_reason) == (3, 4)
     r.render(4)
     _assert_same(r.framebuffer(), o.render(4).copy(), "density scale 1e-6")

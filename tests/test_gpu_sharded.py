@@ -3,7 +3,8 @@ one process, N renderers, the frame's 16x16 tiles dealt diagonally, one gather p
 
 A test box has ONE GPU: the parts are logical shards of device 0 (`devices = [0, 0, 0]`: device-to-device copies stand in for
 the collective, everything else is the multi-device code path), and RCCL itself is exercised with a one-rank communicator
-(VR_SHARDED_TRANSPORT=rccl: librccl opened at run time, ncclCommInitAll, a grouped ncclAllGather on the part's stream).
+(VR_SHARDED_TRANSPORT=rccl: librccl opened at run time, ncclCommInitAll, and the frame's collective on the part's stream -- the gather's
+group, which with one rank holds part 0's own copy only, and with VR_SHARDED_COLLECTIVE=allgather a grouped ncclAllGather).
 N > 1 PHYSICAL devices is not verified anywhere (no such machine was available)."""
 import os
 import subprocess
@@ -52,13 +53,20 @@ def test_one_part_is_the_plain_renderer_and_rccl_carries_one_rank(monkeypatch):
     assert np.array_equal(_bits(s.framebuffer()), _bits(ref))
     s.close()
     monkeypatch.setenv("VR_SHARDED_TRANSPORT", "rccl")
-    s = _sharded("c1", w, h, [0])
-    assert s.transport == "rccl"                      # a one-rank communicator: the collective runs, on the part's stream
-    s.render(spp)
-    assert np.array_equal(_bits(s.framebuffer()), _bits(ref))
-    s.reset(); s.render(spp)
-    assert np.array_equal(_bits(s.framebuffer()), _bits(ref))
-    s.close()
+    for collective in ("gather", "allgather"):        # round 6: ncclSend / ncclRecv to part 0 by default, round 4's ncclAllGather behind the switch
+        monkeypatch.setenv("VR_SHARDED_COLLECTIVE", collective)
+        s = _sharded("c1", w, h, [0])
+        assert s.transport == "rccl" and s.collective == collective      # a one-rank communicator: the collective runs, on the part's stream
+        s.render(spp)
+        assert np.array_equal(_bits(s.framebuffer()), _bits(ref))
+        s.reset(); s.render(spp)
+        assert np.array_equal(_bits(s.framebuffer()), _bits(ref))
+        s.close()
+    monkeypatch.setenv("VR_SHARDED_COLLECTIVE", "scatter")
+    import volren_amd
+    with pytest.raises(volren_amd.VolrenError):
+        volren_amd.ShardedRenderer(w, h, [0])
+    monkeypatch.delenv("VR_SHARDED_COLLECTIVE")
     import volren_amd
     with pytest.raises(volren_amd.VolrenError):       # RCCL refuses two ranks on one device: said up front, not found out in ncclCommInitAll
         volren_amd.ShardedRenderer(w, h, [0, 0])

@@ -19,7 +19,7 @@ SYMBOLS = [
     "vr_last_kernel_ms", "vr_last_pathtrace_ms", "vr_framebuffer", "vr_framebuffer_device", "vr_draw", "vr_display", "vr_save_png",
     "vr_set_tiles", "vr_set_stream", "vr_pack_tiles", "vr_unpack_tiles", "vr_get_uniforms", "vr_uniforms_size",
     "vr_volume_add_grid_frame_dense", "vr_volume_update_grid_frame_dense", "vr_volume_n_grid_frames", "vr_impmap_floats", "vr_get_impmap", "vr_test_alloc_cap_mb", "vr_set_sched", "vr_sched_stats", "vr_grid_checksums", "vr_math_probe", "vr_encode_dense_stats", "vr_write_brick_from_dense", "vr_write_dense",
-    "vr_sharded_create", "vr_sharded_destroy", "vr_sharded_parts", "vr_sharded_part", "vr_sharded_transport", "vr_sharded_reset", "vr_sharded_render", "vr_sharded_synchronize", "vr_tile_owners", "vr_wave_timeline",
+    "vr_sharded_create", "vr_sharded_destroy", "vr_sharded_parts", "vr_sharded_part", "vr_sharded_transport", "vr_sharded_collective", "vr_sharded_reset", "vr_sharded_render", "vr_sharded_synchronize", "vr_tile_owners", "vr_wave_timeline",
 ]
 
 _lib = None
@@ -98,6 +98,8 @@ def load():
     L.vr_sharded_part.restype = vp
     L.vr_sharded_transport.argtypes = [vp]
     L.vr_sharded_transport.restype = C.c_char_p
+    L.vr_sharded_collective.argtypes = [vp]
+    L.vr_sharded_collective.restype = C.c_char_p
     L.vr_sharded_reset.argtypes = [vp]
     L.vr_sharded_render.argtypes = [vp, ci]
     L.vr_sharded_synchronize.argtypes = [vp]

@@ -25,7 +25,7 @@ struct vr_renderer {
 struct vr_sharded {
     std::vector<vr_renderer*> parts;
     std::unique_ptr<vr::ShardedRenderer> impl;
-    std::string transport;
+    std::string transport, collective;
 };
 
 static thread_local std::string g_last_error;
@@ -318,6 +318,11 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
         else if (n == "majorant_blocked") {          // what the current frame's next launch will use
             vr::SceneParams P; R.fill_params(P); *v = P.density.maj_blocked;
         }
+        else if (n == "kernel_variant" || n == "kernel_variant_reason") {      // which compiled kernel the next launch uses, and what sent it to the run-time one (vr_device.h PathtraceVariantReason)
+            vr::SceneParams P; R.fill_params(P);
+            int why = 0; const int variant = vr::pathtrace_variant_of(P, &why);
+            *v = n == "kernel_variant" ? variant : why;
+        }
         else if (n == "env_div_safe") *v = R.environment && R.environment->cdf_div_safe ? 1 : 0;      // the environment's warp table passed env_cdf_kernel's check (vr_math.h div_core)
         else if (n == "pending_samples") *v = R.pending_samples();
         else if (n == "tf_float_atlas") *v = R.tf_float_atlas ? 1 : 0;
@@ -510,6 +515,7 @@ int vr_sharded_create(vr_sharded** out, const int* devices, int n_parts, int wid
         }
         s->impl = std::make_unique<vr::ShardedRenderer>(impls, devs);
         s->transport = s->impl->transport();
+        s->collective = s->impl->collective();
     });
     if (rc != VR_OK) { const std::string keep = g_last_error; vr_sharded_destroy(s); g_last_error = keep; return rc; }
     *out = s;
@@ -524,6 +530,7 @@ void vr_sharded_destroy(vr_sharded* s) {
 int vr_sharded_parts(vr_sharded* s) { return s ? (int)s->parts.size() : 0; }
 vr_renderer* vr_sharded_part(vr_sharded* s, int i) { return (s && i >= 0 && i < (int)s->parts.size()) ? s->parts[(size_t)i] : nullptr; }
 const char* vr_sharded_transport(vr_sharded* s) { return s ? s->transport.c_str() : ""; }
+const char* vr_sharded_collective(vr_sharded* s) { return s ? s->collective.c_str() : ""; }
 int vr_sharded_reset(vr_sharded* s) {
     if (!s) return fail(VR_ERR_ARG, "null sharded renderer");
     return guard([&] { s->impl->reset(); });

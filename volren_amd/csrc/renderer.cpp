@@ -565,8 +565,11 @@ void RendererHIP::capture(LaunchInputs& in) {
 int RendererHIP::samples_per_launch(const LaunchInputs& in, int n_tiles) const {
     const size_t per_sample = pathtrace_pool_floats(in.tuning, n_tiles, 1) * sizeof(float);
     int per_launch = (int)std::max<size_t>(1, in.sample_pool_bytes / per_sample);
-    // item indices inside a sub-launch are 32-bit (WorkUnit::base, C_ITEM): keep n_tiles * 256 * per_launch below 2^32
-    per_launch = (int)std::min<size_t>((size_t)per_launch, std::max<size_t>(1, ((size_t)1 << 32) / ((size_t)n_tiles * 256u) - 32u));
+    // item indices inside a sub-launch are 32-bit (WorkUnit::base, C_ITEM): keep n_tiles * 256 * (per_launch rounded up to whole units of at most 8 samples)
+    // below 2^32.  Saturating: for frames beyond 2^27 pixels the quotient is smaller than the margin (the unsigned difference wrapped and the clamp
+    // stopped limiting anything); launch_pathtrace refuses a launch whose items do not fit.
+    const size_t lim = (size_t)0xFFFFFFFFu / ((size_t)n_tiles * 256u);
+    per_launch = (int)std::min<size_t>((size_t)per_launch, lim > 8 ? lim - 8 : 1);
     if (per_launch > 32) per_launch -= per_launch % 32;          // whole sample chunks (32 is a multiple of every unit size)
     return per_launch;
 }

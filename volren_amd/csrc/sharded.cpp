@@ -32,6 +32,8 @@ struct Rccl {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -57,6 +59,8 @@ Rccl& rccl() {
         R.CommInitAll = reinterpret_cast<decltype(R.CommInitAll)>(sym("ncclCommInitAll"));
         R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
         R.AllGather = reinterpret_cast<decltype(R.AllGather)>(sym("ncclAllGather"));
+        R.Send = reinterpret_cast<decltype(R.Send)>(sym("ncclSend"));
+        R.Recv = reinterpret_cast<decltype(R.Recv)>(sym("ncclRecv"));
         R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
         R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
         R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
@@ -89,6 +93,11 @@ ShardedRenderer::ShardedRenderer(const std::vector<RendererHIP*>& parts, const s
     const std::string forced = want ? want : "";
     if (!forced.empty() && forced != "rccl" && forced != "copy") throw std::runtime_error("VR_SHARDED_TRANSPORT must be rccl or copy");
     if (forced == "rccl" && distinct.size() != devices_.size()) throw std::runtime_error("ShardedRenderer: RCCL needs distinct devices (two parts share one)");
+    // the collective of the rccl transport (SURVEY 8e names both): "gather" (default) = grouped ncclSend / ncclRecv to part 0, the only part that needs the whole frame;
+    // VR_SHARDED_COLLECTIVE=allgather keeps round 4's grouped ncclAllGather (every part then holds -- and allocates -- all N tile buffers)
+    const char* coll = std::getenv("VR_SHARDED_COLLECTIVE");
+    collective_ = coll && *coll ? coll : "gather";
+    if (collective_ != "gather" && collective_ != "allgather") throw std::runtime_error("VR_SHARDED_COLLECTIVE must be gather or allgather");
     if (parts_.size() == 1 && forced != "rccl") transport_ = "none";
     else if (forced == "copy" || distinct.size() != devices_.size()) transport_ = "copy";
     else transport_ = "rccl";
@@ -174,7 +183,7 @@ void ShardedRenderer::setup(int width, int height) {
         buf_[i].pack_ids = make_device_buffer(pack.size() * sizeof(int32_t));
         buf_[i].pack_ids->upload(pack.data(), pack.size() * sizeof(int32_t), buf_[i].stream);
         buf_[i].packed = make_device_buffer(packed_bytes);
-        buf_[i].gathered = (i == 0 || transport_ == "rccl") ? make_device_buffer(packed_bytes * n) : nullptr;
+        buf_[i].gathered = (i == 0 || (transport_ == "rccl" && collective_ == "allgather")) ? make_device_buffer(packed_bytes * n) : nullptr;
         unpack.insert(unpack.end(), lists[i].begin(), lists[i].end());
         unpack.resize((i + 1) * (size_t)n_max_, -1);
     }
@@ -219,12 +228,28 @@ void ShardedRenderer::render(int spp) {
         for (const std::exception_ptr& e : errors) if (e) std::rethrow_exception(e);
     }
     if (transport_ == "none") return;
-    if (transport_ == "rccl") {
+    if (transport_ == "rccl" && collective_ == "allgather") {
         Rccl& R = rccl();
         RcclGroup group;
         for (size_t i = 0; i < n; ++i) {
             VR_HIP(hipSetDevice(devices_[i]));
             rccl_check(R.AllGather(buf_[i].packed->get(), buf_[i].gathered->get(), count, ncclFloat, (ncclComm_t)comms_[i], buf_[i].stream), "ncclAllGather");
+        }
+        group.end();
+    } else if (transport_ == "rccl") {
+        // gather to part 0: its own buffer moves on its stream, every other part sends its buffer and part 0 posts the matching receives -- ONE group, so the
+        // N - 1 transfers over the N - 1 xGMI links into device 0 run concurrently.  Stream order does the rest: a part's send follows its pack, part 0's
+        // receives follow its unpack of the frame before (which reads the buffer they fill) and precede this frame's.
+        Rccl& R = rccl();
+        float* gathered = buf_[0].gathered->as<float>();
+        VR_HIP(hipSetDevice(devices_[0]));
+        VR_HIP(hipMemcpyAsync(gathered, buf_[0].packed->get(), count * sizeof(float), hipMemcpyDeviceToDevice, buf_[0].stream));
+        RcclGroup group;
+        for (size_t i = 1; i < n; ++i) {
+            VR_HIP(hipSetDevice(devices_[0]));
+            rccl_check(R.Recv(gathered + i * count, count, ncclFloat, (int)i, (ncclComm_t)comms_[0], buf_[0].stream), "ncclRecv");
+            VR_HIP(hipSetDevice(devices_[i]));
+            rccl_check(R.Send(buf_[i].packed->get(), count, ncclFloat, 0, (ncclComm_t)comms_[i], buf_[i].stream), "ncclSend");
         }
         group.end();
     } else {

@@ -3,7 +3,8 @@
 // No reference counterpart (the reference drives one GL context, src/main.cpp:524-557); this is SURVEY 8(e) inside the product
 // rather than inside a benchmark harness: the scene is replicated on every device, the frame's 16x16 tiles (the reference's work
 // group, shader/pathtracer_brick.glsl:3) are dealt diagonally, owner(tx, ty) = (tx + ty) mod N, every part renders all samples of
-// its tiles with no communication on its own stream, and ONE grouped ncclAllGather per frame (RCCL over xGMI) of the compact
+// its tiles with no communication on its own stream, and ONE gather per frame (RCCL over xGMI: grouped ncclSend / ncclRecv to part 0; round 4-5: a grouped
+// ncclAllGather, still there behind VR_SHARDED_COLLECTIVE=allgather) of the compact
 // per-part tile buffers puts the accumulated radiance together; part 0 scatters it back into its framebuffer, which then holds the
 // whole frame -- bit-identical to a single-device render, because a pixel-sample depends on (seed, pixel, sample) only
 // (pathtracer_brick.glsl:28-36).
@@ -48,19 +49,20 @@ struct ShardedRenderer {
     void render(int spp = 0);
     void synchronize();                   // waits for all parts; throws if a kernel watchdog tripped
     const std::string& transport() const { return transport_; }      // "rccl" | "copy" | "none" (one part, nothing to exchange)
+    const std::string& collective() const { return collective_; }    // of the rccl transport: "gather" (ncclSend / ncclRecv to part 0) | "allgather"
 
 private:
     void setup(int width, int height);   // tile deal + buffers for the current resolution
     void release();                       // everything this object created; the parts get their previous streams back
     std::vector<RendererHIP*> parts_;
     std::vector<int> devices_;
-    std::string transport_;
+    std::string transport_, collective_;
     int width_ = 0, height_ = 0, n_max_ = 0;
     struct PartBuffers {
         hipStream_t stream = nullptr;     // owned
         hipEvent_t packed_ready = nullptr;
         int n_own = 0;                    // tiles this part renders
-        DeviceBufferPtr pack_ids, packed, gathered;      // gathered: rccl transport on every part, copy transport on part 0 only
+        DeviceBufferPtr pack_ids, packed, gathered;      // gathered: on part 0 (every part under VR_SHARDED_COLLECTIVE=allgather)
     };
     std::vector<PartBuffers> buf_;
     DeviceBufferPtr unpack_ids_;          // on part 0's device: every part's tile ids in part order, -1 = padding

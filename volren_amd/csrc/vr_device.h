@@ -29,6 +29,15 @@ size_t pathtrace_workspace_floats();      // cold path state of all resident wav
 void launch_pathtrace(const PathtraceTuning& T, const SceneParams& P, float* fb, float* sample_pool, float* workspace, uint32_t* unit_counter, const int32_t* tiles, int32_t n_tiles,
                       int32_t first_sample, int32_t n_samples, uint32_t* status, hipStream_t stream, bool fast_math = false,
                       hipEvent_t ev_kernel_begin = nullptr, hipEvent_t ev_kernel_end = nullptr);      // optional: bracket the path-tracing kernel alone
+// which compiled kernel variant (vr_pathtrace.hip: 0 bricks, 1 dense fp16, 2 / 4 bricks + emission grid, 3 everything at run time) serves a scene, and -- *why, a mask --
+// what sent it to the run-time variant (0: nothing, the scene has a kernel of its own kind)
+enum PathtraceVariantReason : int {
+    VR_VARIANT_INTEGRATOR = 1,        // a global-majorant / ray-marching integrator was asked for
+    VR_VARIANT_ENV_DIVISION = 2,      // the environment's warp table failed env_cdf_kernel's check (thresholds below 2^-76: vr_math.h div_core does not apply)
+    VR_VARIANT_DENSITY_SCALE = 4,     // density scale outside [2^-16, 2^24] (the clean march divides by majorants without rescaling)
+    VR_VARIANT_GRID_FORMS = 8         // emission grid with a dense grid on either side, or brick grids of different layouts (no paired atlas)
+};
+int pathtrace_variant_of(const SceneParams& P, int* why);
 // fast_math: the opt-in tolerance-mode kernels (hardware transcendentals, reciprocal division; vr_math.h VR_FAST_MATH); the default
 // kernels are bit-identical to the CPU oracle
 

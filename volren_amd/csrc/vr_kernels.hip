@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <stdexcept>
+#include <string>
 
 #include "vr_device.h"
 #include "vr_pathtrace.h"
@@ -125,18 +127,44 @@ static const PtOccupancy kPtOccupancy[2][kPtVariants] = { { vr_pt_occupancy_0, v
 static const PtLaunch kPtLaunch[2][kPtVariants] = { { vr_pt_launch_0, vr_pt_launch_1, vr_pt_launch_2, vr_pt_launch_3, vr_pt_launch_4 },
                                                     { vr_pt_launch_0_fast, vr_pt_launch_1_fast, vr_pt_launch_2_fast, vr_pt_launch_3_fast, vr_pt_launch_4_fast } };
 
-// which compiled variant serves a scene (see vr_pathtrace.hip)
-static int pathtrace_variant(const SceneParams& P) {
+// which compiled variant serves a scene (see vr_pathtrace.hip), and why -- `why` is a mask of PathtraceVariantReason (vr_device.h): the run-time variant (3) is an
+// order of magnitude slower than the kernels of one scene kind on some scenes (one copy of the hot pair, general forms only, everything decided per wavefront), so a
+// scene that lands there for a reason its caller did not ask for is told so (launch_pathtrace, vr_get_int "kernel_variant_reason")
+int pathtrace_variant_of(const SceneParams& P, int* why) {
     // (an environment whose warp table failed the check of env_cdf_kernel -- thresholds below 2^-76: the kernels of one scene kind divide by vr_math.h div_core there --
     // goes to the run-time variant, which divides in full; RendererHIP::fill_params pairs no atlases for it)
     // -- and so does a density scale outside [2^-16, 2^24]: the CLEAN form of the march divides by majorants = density_scale x an fp16 number (vr_trace.h march_finish)
     const bool scale_ok = P.u.vol_density_scale >= 1.0f / 65536.0f && P.u.vol_density_scale <= 16777216.0f;
-    if (P.u.integrator != 0 || !P.env_div_safe || !scale_ok) return 3;
+    int reason = 0;
+    if (P.u.integrator != 0) reason |= VR_VARIANT_INTEGRATOR;
+    if (!P.env_div_safe) reason |= VR_VARIANT_ENV_DIVISION;
+    if (!scale_ok) reason |= VR_VARIANT_DENSITY_SCALE;
+    int variant;
+    if (reason) variant = 3;
     // variant 2: both grids in brick form -- and, when the kernels are built for the paired atlas, sharing one (same brick layout: RendererHIP::commit)
     // (4 = 2 compiled for majorant levels 0-1 in 4x4x4-cell blocks; every other kernel of a fixed layout reads linear tables: RendererHIP::fill_params only
     // sets maj_blocked on the views of frames this variant -- or the run-time variant -- serves)
-    if (P.u.has_emission) return (P.density.dense || P.emission.dense || (VR_PAIRED_ATLAS && !P.paired)) ? 3 : (P.density.maj_blocked ? 4 : 2);
-    return P.density.dense ? 1 : 0;
+    else if (P.u.has_emission) {
+        const bool mixed = P.density.dense || P.emission.dense || (VR_PAIRED_ATLAS && !P.paired);
+        if (mixed) reason |= VR_VARIANT_GRID_FORMS;
+        variant = mixed ? 3 : (P.density.maj_blocked ? 4 : 2);
+    } else variant = P.density.dense ? 1 : 0;
+    if (why) *why = reason;
+    return variant;
+}
+static int pathtrace_variant(const SceneParams& P) {
+    int why = 0;
+    const int variant = pathtrace_variant_of(P, &why);
+    // the two reasons a caller cannot see coming: said once per process, on stderr
+    if (why & (VR_VARIANT_ENV_DIVISION | VR_VARIANT_DENSITY_SCALE)) {
+        static std::once_flag once;
+        std::call_once(once, [&] {
+            fprintf(stderr, "volren_amd: note: this scene is rendered by the run-time kernel variant (slower; results unchanged):%s%s\n",
+                    (why & VR_VARIANT_ENV_DIVISION) ? " the environment's warp table has thresholds below 2^-76 (vr_get_int env_div_safe = 0);" : "",
+                    (why & VR_VARIANT_DENSITY_SCALE) ? " the density scale lies outside [2^-16, 2^24];" : "");
+        });
+    }
+    return variant;
 }
 
 // resident workgroups of a kernel instance on the CURRENT device: occupancy query x CU count, cached per (device, instance)
@@ -172,6 +200,9 @@ void launch_pathtrace(const PathtraceTuning& T, const SceneParams& P, float* fb,
     const int variant = pathtrace_variant(P);
     D.spu = std::min(n_samples, samples_per_unit(T, variant));
     const int32_t chunks = (n_samples + D.spu - 1) / D.spu;
+    // item indices are 32-bit (WorkUnit::base, the sample pool's slots): RendererHIP::samples_per_launch sizes sub-launches below that; anything else is a caller's bug
+    if ((uint64_t)chunks * (uint64_t)n_tiles * 4u * (uint64_t)(D.spu * 64) > 0xFFFFFFFFull)
+        throw std::runtime_error("launch_pathtrace: " + std::to_string(n_tiles) + " tiles x " + std::to_string(n_samples) + " samples do not fit the 32-bit item index of one launch");
     D.n_units = (uint32_t)chunks * (uint32_t)n_tiles * 4u;
     D.chunks = (uint32_t)chunks;
     D.seg_len = (D.n_units + kQueueSegments - 1u) / kQueueSegments;

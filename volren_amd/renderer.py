@@ -49,7 +49,7 @@ class Renderer:
 
     # ---- fields ----
     def __getattr__(self, name):
-        if name in _INT_FIELDS or name in ("n_grid_frames", "last_launches", "pending_samples", "majorant_blocked", "env_div_safe"):
+        if name in _INT_FIELDS or name in ("n_grid_frames", "last_launches", "pending_samples", "majorant_blocked", "env_div_safe", "kernel_variant", "kernel_variant_reason"):
             v = C.c_int()
             _lib.check(self._L.vr_get_int(self._h, name.encode(), C.byref(v)))
             return bool(v.value) if name in ("show_environment", "tonemapping") else v.value
@@ -334,6 +334,11 @@ class ShardedRenderer:
     @property
     def transport(self):
         return self._L.vr_sharded_transport(self._h).decode()
+
+    @property
+    def collective(self):
+        """What the rccl transport runs per frame: "gather" (ncclSend / ncclRecv to part 0) or "allgather" (VR_SHARDED_COLLECTIVE)."""
+        return self._L.vr_sharded_collective(self._h).decode()
 
     def reset(self):
         _lib.check(self._L.vr_sharded_reset(self._h))
