@@ -1593,6 +1593,54 @@ def test_results_do_not_depend_on_the_scheduler(config):
     assert np.array_equal(_bits(r.framebuffer()), _bits(want)), "trace() x spp"
 
 
+@pytest.mark.parametrize("config", ["c2", "c3", "c4:64", "c4:64+lut", "c5:32", "c5:32+lut", "c5:32+blocked", "c2+global", "c3+global"])
+def test_frames_are_reproducible_on_every_compiled_instance(config, monkeypatch):
+    """Verdict r5 #5: one of seven bench runs of round 5 reported a tolerance-mode frame 30 x further from the bit-exact one than usual, once, under rocprofv3, and
+    it never came back (200 + 60 full-size frames with NaN-filled workspace and sample pool between them, plain and under rocprofv3 --kernel-trace: one CRC per
+    mode, tests/tools_determinism.py, profiles/r6_determinism.txt).  What CAN be pinned is pinned here: on every compiled kernel instance -- each variant, with and
+    without a transfer function, the bit-exact arithmetic and, where the mode is offered (no transfer function), the tolerance mode -- 20 frames rendered in turn
+    by fresh and reused renderers, the bit-exact and the tolerance kernels alternating on the SAME workspace and pool, both NaN-filled before every launch
+    (VR_TEST_POISON_WORKSPACE=2), give ONE frame per mode; the bit-exact one is the oracle's."""
+    import zlib
+    monkeypatch.setenv("VR_TEST_POISON_WORKSPACE", "2")
+    w, h, spp = 80, 48, 5
+    name, _, mod = config.partition("+")
+
+    def fresh():
+        r = scenes.hip_scene(name, w, h)
+        if mod == "global":
+            r.integrator = 1
+        if mod == "lut":
+            r.load_transferfunc(scenes.LUT)
+        if mod == "blocked":
+            r.majorant_layout = 1                      # variant 4: the kernel for majorant tables in 4x4x4-cell blocks
+        return r
+
+    o = scenes.oracle_scene(name, w, h)
+    if mod == "global":
+        o.integrator = 1
+    if mod == "lut":
+        o.load_transferfunc(scenes.LUT)
+    want = o.render(spp)
+    has_tf = mod == "lut" or name == "c3"
+    modes = (0,) if has_tf else (0, 1)                 # the tolerance mode is refused behind a transfer function (include/volren_amd.h "fast_math")
+    crcs = {m: set() for m in modes}
+    keep = []
+    for k in range(20):
+        if k % 3 == 0:
+            keep = (keep + [fresh()])[-2:]             # two renderers alive at a time, as bench.py's tolerance-mode leg has them
+        r = keep[-1 - (k % len(keep))] if len(keep) > 1 else keep[-1]
+        for m in modes:
+            r.fast_math = m
+            r.reset()
+            r.render(spp)
+            fb = r.framebuffer()
+            crcs[m].add(zlib.crc32(np.ascontiguousarray(fb).tobytes()))
+            if m == 0 and k in (0, 19):
+                _assert_same(fb, want, "%s, frame %d" % (config, k))
+    assert all(len(v) == 1 for v in crcs.values()), (config, {m: sorted(v) for m, v in crcs.items()})
+
+
 def test_tile_order_inside_a_launch_never_changes_the_image():
     """order_tiles (default on): a launch works through its tiles costliest first -- by the chord of the pixel rays through the volume's box -- instead of in
     raster order; with a tile subset (a rank's share) the subset is reordered.  Same image bit for bit; and the per-wavefront timeline of an instrumented

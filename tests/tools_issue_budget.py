@@ -143,7 +143,7 @@ def parse_blocks(path, want):
     return blocks
 
 
-def assign(blocks, tf_kernel=False):
+def assign(blocks, tf_kernel=False, no_environment=False):
     """top-level block of every basic block + its execution count relative to ONE execution of that top-level block (loops, rare paths)"""
     prev = "prologue"
     for b in blocks:
@@ -181,6 +181,8 @@ def assign(blocks, tf_kernel=False):
             # transfer-function kernels carry collide_finish twice (LUT in LDS / in global memory: address spaces are compile-time); the LDS one runs for LUTs of up
             # to 256 entries (the bench's): a copy that reads LDS counts, one that reads global memory does not, the rest (no load in the block) half
             mult = 1.0 if b["lds"] > 0 else (0.0 if b["vmem"] > 0 else 0.5)
+        if no_environment and b["top"] == "escape" and (fs.get("lookup_environment", 0) + fs.get("env_texture", 0) + fs.get("wrap_repeat", 0) + fs.get("clampi", 0)) >= 0.3 * max(1, sum(fs.values())):
+            mult = 0.0                                   # show_environment = 0 (a scene with a transfer function, src/main.cpp:76): an escaping path looks nothing up
         b["mult"] = mult
     # Round 5 (clean segments): the hot pair is compiled in two forms -- VR_HOT_PAIRS copies of the CLEAN form, which is what runs, and one copy of the general form for
     # wavefronts that hold a path on a segment that is not clean (degenerate rays: never in the bench scenes).  A copy = a run of march blocks followed by its collide
@@ -197,6 +199,35 @@ def assign(blocks, tf_kernel=False):
         else:
             if b["top"] not in ("glue",) and b["n"] > 0 and b["top"] in ("park", "decision", "resume", "escape", "postnee", "new", "nee", "tail"):
                 cur_copy, last = None, None
+    # Round 6 (verdict r5 #6: the model counted 118 % of SQ_INSTS_VALU on the transfer-function kernel): that kernel carries collide_finish TWICE in every copy of the
+    # hot pair -- LUT in LDS / LUT in global memory, the address space is a compile-time property -- and round 5 weighted the two instances block by block on the
+    # share of collide_finish / tf_lookup_at / trilinear_value lines in a block, which left the blocks dominated by inlined helpers (the free-flight draw: rng +
+    # neg_log_1m, 37 instructions; the real / null decision) counted once per INSTANCE, i.e. twice.  Now the instances are found structurally: inside a copy's collision
+    # code an instance starts where the lines of trilinear_value start; the one whose LUT reads are LDS reads runs (LUTs of up to 256 entries: the bench's), the
+    # other never does.
+    if tf_kernel:
+        for c in copies:
+            col = [x for x in c if x["top"] == "collide"]
+            starts = [i for i, x in enumerate(col) if x["funcs"].get("trilinear_value", 0) > 0 and (i == 0 or col[i - 1]["funcs"].get("trilinear_value", 0) == 0)]
+            if len(starts) != 2:
+                continue
+            inst = [col[starts[0]:starts[1]], col[starts[1]:]]
+            uses_lds = [any(x["lds"] > 0 and x["funcs"].get("tf_lookup_at", 0) > 0 for x in blk) for blk in inst]
+            if uses_lds[0] == uses_lds[1]:
+                continue
+            for blk, runs in zip(inst, uses_lds):
+                for x in blk:
+                    byte_corner = (x["funcs"].get("tap_load", 0) + x["funcs"].get("tap_value", 0)) >= 0.5 * max(1, sum(x["funcs"].values()))
+                    x["mult"] = 0.0 if (byte_corner or not runs) else 1.0
+    if no_environment:
+        # ... and the direction -> (u, v) arithmetic in front of the look-up (atan2, acos of vr_math.h: blocks without a function of vr_trace.h on their lines)
+        for i, b in enumerate(blocks):
+            if b["top"] == "escape" and b["funcs"].get("lookup_environment", 0) > 0 and b["mult"] == 0.0:
+                j = i - 1
+                while j >= 0 and blocks[j]["top"] == "escape" and not blocks[j]["funcs"] and not blocks[j]["secs"]:
+                    blocks[j]["mult"] = 0.0
+                    j -= 1
+                break
     n_clean = sum(1 for c in copies if any(x["clean_marks"] for x in c))
     if n_clean:
         for c in copies:
@@ -211,7 +242,7 @@ def main():
     path = sys.argv[1]
     arg = lambda k, d=None: (sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d)
     want = arg("--kernel", "TraceCfgILb0E")
-    blocks = assign(parse_blocks(path, want), tf_kernel="TraceCfgILb1E" in want)
+    blocks = assign(parse_blocks(path, want), tf_kernel="TraceCfgILb1E" in want, no_environment="--no-environment" in sys.argv)
     stats = json.load(open(arg("--stats"))) if arg("--stats") else None
     # executions of each top-level block per scheduler iteration
     if stats:

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Build container: the issue-cycle budget of every bench configuration's kernel from the inputs tests/tools_issue_reconcile.sh left under gpurun_out/issue
 # (STATS counters + rocprofv3 instruction counters of the same launches).  Writes profiles/r5_issue_budget.txt and profiles/r5_issue_budget.json.
-# usage: bash tests/tools_issue_budget_all.sh [hot pairs per iteration, default 4] [round prefix, default r5]
+# usage: bash tests/tools_issue_budget_all.sh [hot pairs per iteration, default 4] [round prefix, default r6]
 set -e
-HP=${1:-4}; R=${2:-r5}
+HP=${1:-4}; R=${2:-r6}
 mkdir -p build/asm
 for v in 0 1 4; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -fno-slp-vectorize -DVR_PT_VARIANT=$v --cuda-device-only -gline-tables-only -S volren_amd/csrc/vr_pathtrace.hip -o build/asm/ptg_$v.s 2>/dev/null &
@@ -34,7 +34,7 @@ for name, tag, asm, kernel in cfgs:
             if "pathtrace_kernel" in row["Kernel_Name"] and not row["Kernel_Name"].rstrip().endswith("true>(vr::KernelArgs)"):
                 wave[row["Counter_Name"]] += float(row["Counter_Value"])
     js = os.path.join(root, "build/asm/budget_%s.json" % name)
-    cmd = [sys.executable, "tests/tools_issue_budget.py", "build/asm/" + asm, "--kernel", kernel, "--stats", sj, "--hot-pairs", hp, "--valu-per-sample", "%.3f" % per["SQ_INSTS_VALU"], "--msamples", "%.1f" % (st["samples"] / st["ms"] / 1e3 * 1.27), "--json", js]
+    cmd = [sys.executable, "tests/tools_issue_budget.py", "build/asm/" + asm] + (["--no-environment"] if name == "c3" else []) + ["--kernel", kernel, "--stats", sj, "--hot-pairs", hp, "--valu-per-sample", "%.3f" % per["SQ_INSTS_VALU"], "--msamples", "%.1f" % (st["samples"] / st["ms"] / 1e3 * 1.27), "--json", js]
     txt = subprocess.check_output(cmd).decode()
     j = json.load(open(js))
     j["pmc_per_sample"] = per
@@ -62,7 +62,8 @@ for name, tag, asm, kernel in cfgs:
         out_txt.append("counter: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = %.3f of a wavefront's resident time in VALU instructions; x 4 resident wavefronts = %.2f VALU pipelines' worth per SIMD, of the %.2f a SIMD sustains at this mix's %.2f cycles per instruction (4 / cycles per instruction) -> VALU issue at %.0f %% of its ceiling\n" % (
             j["valu_active_share_of_wave_cycles"], 4 * j["valu_active_share_of_wave_cycles"], 4.0 / j["cycles_per_valu_op"], j["cycles_per_valu_op"], 100 * j["valu_active_share_of_wave_cycles"] * j["cycles_per_valu_op"]))
 open(os.path.join(root, "profiles/%s_issue_budget.txt" % R), "w").write(
-    "# Round 5: issue-cycle budget of the path-tracing kernel per scheduler section (tests/tools_issue_budget.py; inputs: tests/tools_issue_reconcile.sh on one MI355X).\n"
+    "# Round " + R[1:] + ": issue-cycle budget of the path-tracing kernel per scheduler section (tests/tools_issue_budget.py; inputs: tests/tools_issue_reconcile.sh on one MI355X;\n"
+    "# round 6: the execution counts come from instrumented kernels built with -DVR_STATS_LEVEL=1 -- counters in LDS, the production kernels' registers, no scratch).\n"
     "# static ISA of the production kernel (per basic block, attributed to the scheduler's blocks by source line) x executions per iteration (STATS counters of the same run)\n"
     "# x issue cycles per opcode class (profiles/r5_instruction_costs.txt).  `model / PMC`: the model's VALU wave-instructions per sample against rocprofv3 SQ_INSTS_VALU of the\n"
     "# plain launches of the same run.\n\n" + "\n".join(out_txt))

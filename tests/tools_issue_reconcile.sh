@@ -1,6 +1,8 @@
 #!/bin/bash
 # Diagnostic (round 5): the inputs of tests/tools_issue_budget.py from ONE run per configuration -- the STATS kernels' execution counts (JSON) and the
 # instruction counters of the same launches (rocprofv3 --pmc: the instrumented launch and the plain warm-up launch before it are separate dispatches).
+# Round 6: run it with VOLREN_AMD_LIB=$PWD/build/exp_stats1/libvolren_amd.so (VARIANTS="0 1 2 4" bash tests/tools_build_variant.sh stats1 -DVR_STATS_LEVEL=1): instrumented
+# kernels that only count executions, with the production kernels' registers and no scratch -- their counts describe the schedule of the kernels the budget prices.
 # usage: bash tests/tools_issue_reconcile.sh "c2 1024 128" "c4:512 1024 32" ...
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/issue

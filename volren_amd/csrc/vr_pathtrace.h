@@ -427,7 +427,8 @@ pathtrace_kernel(const KernelArgs A) {
     const SceneParams& P = A.P;           // hot pair only; events use event_args()
 #endif
     const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    constexpr int32_t NS = pool_slots<K>();           // path slots of this kernel's wavefronts (shadows the global maximum below)
+    // path slots of this kernel's wavefronts (shadows the global maximum below); the instrumented instances give three of them up for their counters (lds_stat)
+    constexpr int32_t NS = pool_slots<K>() - (STATS ? 3 : 0);
 
     static_assert(!cold_in_regs<K>() || kWgWaves == 4, "the cold-state-in-registers experiment runs 3 workgroups of 4 wavefronts per CU");
     __shared__ uint8_t lds_q[kWgWaves * Q_COUNT * NS];
@@ -528,23 +529,41 @@ pathtrace_kernel(const KernelArgs A) {
     hot_init(l);
     int32_t slot = -1;                // path held in this lane's registers (-1: none)
 
-    const unsigned long long t_begin_rt = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // VR_STATS_LEVEL (round 6): what the instrumented (STATS) instances carry.  2 (default): everything -- executions and lanes per block, cycles per block, pool
+    // occupancy, the wavefront's timeline; those instances spill 3-28 vector registers to scratch and run ~25 % slower than the production kernels.  1: executions and
+    // lanes per block, resumes / parks / iterations only -- what tests/tools_issue_budget.py weights the static instruction stream with -- so that those counts come
+    // from kernels that schedule like production (no scratch: profiles/r6_kernel_resources.txt); a library built with it reports zero cycles and occupancy
+#ifndef VR_STATS_LEVEL
+#define VR_STATS_LEVEL 2
+#endif
+    constexpr bool STATS_T = STATS && VR_STATS_LEVEL >= 2;
+    const unsigned long long t_begin_rt = STATS_T ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t iters = 0u, idle_iters = 0u;     // scheduler iterations: in all (statistics), since the last finished path or pulled unit (watchdog)
     if (VR_PRIO_EVENTS != VR_PRIO_HOT) __builtin_amdgcn_s_setprio(VR_PRIO_HOT);      // (the priority the loop starts with)
     uint32_t t_last = (uint32_t)__builtin_readcyclecounter(), t_elapsed = 0u;
-    uint32_t st_exec[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, st_lanes[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 };
-    unsigned long long st_cyc[ST_DONE] = { 0, 0, 0, 0, 0, 0, 0 }, t_blk = 0ull, t_start = STATS ? __builtin_readcyclecounter() : 0ull;
+    // STATS instances: the counters of a wavefront live in LDS -- 32 words, word i = its index in the statistics buffer (2k / 2k+1 executions / lanes of block k,
+    // 14 / 15 resumes / parks, 16 iterations, 17 wavefronts, 18 + k cycles of block k, 26 + k pool occupancy); lane 0 adds, in wave-uniform control flow.  Round 5
+    // kept them as ~40 scalar variables: the instrumented kernels spilled 94-139 scalar and 3-28 vector registers (to scratch) and ran ~25 % slower than the
+    // production ones, whose schedule their counts are supposed to describe (verdict r5 #6).  Any value carried around the scheduler loop in a REGISTER does that --
+    // one more loop-carried VGPR tips these kernels (114-127 vector registers) over the allocator's edge -- the LDS words do not: at VR_STATS_LEVEL 1 the instrumented
+    // instances have the production kernels' registers and no scratch (profiles/r6_kernel_resources.txt); the timers of level 2 still cost 3-24 spilled VGPRs.
+    // Cycles are summed in 32 bits: instrumented launches are meant to be short (a wavefront may run 1.7 s before a block's sum wraps); the wavefront's lifetime
+    // [25] is taken in 64 bits at the end.
+    __shared__ uint32_t lds_stat[STATS ? kWgWaves * 32 : 1];
+    if (STATS) { if (lane < 32) lds_stat[wave * 32 + lane] = 0u; __builtin_amdgcn_wave_barrier(); }
+    auto stat_add = [&](int i, uint32_t n) __attribute__((always_inline)) { if (lane == 0) lds_stat[wave * 32 + i] += n; };
+    uint32_t t_blk = 0u;
+    const unsigned long long t_start = STATS_T ? __builtin_readcyclecounter() : 0ull;
 #ifndef VR_STAT_SCHED
 #define VR_STAT_SCHED 0
 #endif
 #if VR_STAT_SCHED
-    unsigned long long t_tail = 0ull;
+    uint32_t t_tail = 0u;
+    bool have_tail = false;
 #endif
-    unsigned long long occ[6] = { 0, 0, 0, 0, 0, 0 };      // summed per iteration: marching lanes, READY, NEE, POSTNEE, ESCAPE, FREE
     unsigned long long t_exhausted = 0ull;                 // STATS: constant-rate clock (100 MHz) when this wavefront found the work queue empty
-    uint32_t n_resume = 0u, n_park = 0u;                   // STATS: iterations in which a lane resumed / parked a path (the two bookkeeping blocks are skipped otherwise)
-#define VR_STAT(ST, N) do { if (STATS) { st_exec[ST] += 1u; st_lanes[ST] += (uint32_t)(N); t_blk = __builtin_readcyclecounter(); } } while (0)
-#define VR_STAT_END(ST) do { if (STATS) { st_cyc[ST] += __builtin_readcyclecounter() - t_blk; } } while (0)
+#define VR_STAT(ST, N) do { if (STATS) { stat_add(2 * (ST), 1u); stat_add(2 * (ST) + 1, (uint32_t)(N)); if (STATS_T) t_blk = (uint32_t)__builtin_readcyclecounter(); } } while (0)
+#define VR_STAT_END(ST) do { if (STATS_T) { stat_add(18 + (ST), (uint32_t)__builtin_readcyclecounter() - t_blk); } } while (0)
 // push the slots of all lanes where COND holds onto stack QI (wave-synchronous)
 #define VR_PUSH(QI, CNT, COND, SLOTV) do { \
         const uint64_t m_ = wave_ballot(COND); \
@@ -603,9 +622,9 @@ pathtrace_kernel(const KernelArgs A) {
         }
 #if VR_STAT_SCHED
         // diagnostic build: the occupancy counters carry the cycles of the scheduler's sections instead (tests/tools_sched_stats.py --sections)
-        unsigned long long t_sec = STATS ? __builtin_readcyclecounter() : 0ull;
-        if (STATS && t_tail) occ[4] += t_sec - t_tail;                   // loop tail + head (watchdog, exit test)
-#define VR_SECTION(K) do { if (STATS) { const unsigned long long n_ = __builtin_readcyclecounter(); occ[K] += n_ - t_sec; t_sec = n_; } } while (0)
+        uint32_t t_sec = STATS_T ? (uint32_t)__builtin_readcyclecounter() : 0u;
+        if (STATS_T && have_tail) stat_add(26 + 4, t_sec - t_tail);         // loop tail + head (watchdog, exit test)
+#define VR_SECTION(K) do { if (STATS_T) { const uint32_t n_ = (uint32_t)__builtin_readcyclecounter(); stat_add(26 + (K), n_ - t_sec); t_sec = n_; } } while (0)
 #else
 #define VR_SECTION(K) do { } while (0)
 #endif
@@ -614,7 +633,7 @@ pathtrace_kernel(const KernelArgs A) {
             const uint64_t idle = wave_ballot(slot < 0);
             const int32_t take = min(popc(idle), cnt_ready);
             if (take > 0) {
-                if (STATS) ++n_resume;
+                if (STATS) stat_add(14, 1u);
                 if (slot < 0) {
                     const int32_t r = (int32_t)lane_rank(idle);
                     if (r < take) {
@@ -638,7 +657,7 @@ pathtrace_kernel(const KernelArgs A) {
         }
         VR_SECTION(0);                                                   // resume
 #if !VR_STAT_SCHED
-        if (STATS) { occ[0] += (unsigned)popc(wave_ballot(slot >= 0)); occ[1] += (unsigned)cnt_ready; occ[2] += (unsigned)cnt_nee; occ[3] += (unsigned)cnt_post; occ[4] += (unsigned)cnt_esc; occ[5] += (unsigned)cnt_free; }
+        if (STATS_T) { stat_add(26, (uint32_t)popc(wave_ballot(slot >= 0))); stat_add(27, (uint32_t)cnt_ready); stat_add(28, (uint32_t)cnt_nee); stat_add(29, (uint32_t)cnt_post); stat_add(30, (uint32_t)cnt_esc); stat_add(31, (uint32_t)cnt_free); }
 #endif
         // (2) the hot pair: two DDA steps for the marching lanes, then the collision code for every lane that now stands at a
         // tentative collision (after two steps that is most of them, so both blocks run nearly full width).  Two memory round
@@ -654,6 +673,12 @@ pathtrace_kernel(const KernelArgs A) {
 #ifndef VR_HOT_PAIRS
 #define VR_HOT_PAIRS 4
 #endif
+        // ... per kernel instance (round 6): the transfer-function kernel with an emission grid -- 8 corner taps, the LUT and a stochastic emission tap in one collision
+        // block -- spills 34 scalar registers with four clean copies and the general one, 20 with VR_HOT_PAIRS_TF_EMISSION copies (profiles/r6_kernel_resources.txt)
+#ifndef VR_HOT_PAIRS_TF_EMISSION
+#define VR_HOT_PAIRS_TF_EMISSION 1
+#endif
+        constexpr int kHotPairs = (K::tf && K::emission == 1) ? (VR_HOT_PAIRS_TF_EMISSION < VR_HOT_PAIRS ? VR_HOT_PAIRS_TF_EMISSION : VR_HOT_PAIRS) : VR_HOT_PAIRS;
 
 #ifndef VR_HOT_PAIR_MIN
 #define VR_HOT_PAIR_MIN 44
@@ -677,7 +702,12 @@ pathtrace_kernel(const KernelArgs A) {
 #ifndef VR_CLEAN_FORMS
 #define VR_CLEAN_FORMS VR_CLEAN_FLAG
 #endif
-        const bool all_clean = VR_CLEAN_FORMS && (holds_path & wave_ballot((int32_t)f2u(l.far) < 0)) == 0ull;
+        // (VR_CLEAN_FORMS_TF_EMISSION, round 6: whether the transfer-function kernel with an emission grid carries the clean form too)
+#ifndef VR_CLEAN_FORMS_TF_EMISSION
+#define VR_CLEAN_FORMS_TF_EMISSION 1
+#endif
+        constexpr bool kCleanForms = VR_CLEAN_FORMS && ((K::tf && K::emission == 1) ? VR_CLEAN_FORMS_TF_EMISSION != 0 : true);
+        const bool all_clean = kCleanForms && (holds_path & wave_ballot((int32_t)f2u(l.far) < 0)) == 0ull;
         auto hot_pair = [&](auto clean_tag, const int hot_rep_) __attribute__((always_inline)) -> bool {
             constexpr bool CLEAN = decltype(clean_tag)::value;
 #if VR_BALLOT_VALID
@@ -685,7 +715,7 @@ pathtrace_kernel(const KernelArgs A) {
 #else
             if (hot_rep_ > 0 && popc(wave_ballot(slot >= 0 && (uint32_t)(l.state - ST_MARCH) < 2u)) < VR_HOT_PAIR_MIN) return false;
 #endif
-            if (STATS) t_blk = __builtin_readcyclecounter();
+            if (STATS_T) t_blk = (uint32_t)__builtin_readcyclecounter();
             const bool is_m = slot >= 0 && l.state == ST_MARCH;
 #if VR_MARCH_SPECULATIVE
             MarchIO mio;
@@ -705,7 +735,8 @@ pathtrace_kernel(const KernelArgs A) {
             for (int32_t k = 0; k < 2; ++k)            // diagnostic: two plain steps, one majorant load each, only where a step runs
                 if (slot >= 0 && l.state == ST_MARCH) do_march<K::tf, K::dense, K::majb>(l, P);
 #endif
-            if (STATS) { const int32_t nm = popc(wave_ballot(is_m)); if (nm) { st_exec[ST_MARCH] += 1u; st_lanes[ST_MARCH] += (uint32_t)nm; } const unsigned long long t_now = __builtin_readcyclecounter(); st_cyc[ST_MARCH] += t_now - t_blk; t_blk = t_now; }
+            if (STATS) { const int32_t nm = popc(wave_ballot(is_m)); if (nm) { stat_add(2 * ST_MARCH, 1u); stat_add(2 * ST_MARCH + 1, (uint32_t)nm); } }
+            if (STATS_T) { const uint32_t t_now = (uint32_t)__builtin_readcyclecounter(); stat_add(18 + ST_MARCH, t_now - t_blk); t_blk = t_now; }
 #if VR_DIAG_PAD_VALU > 0
             {   // diagnostic: VR_DIAG_PAD_VALU extra dependent-free vector instructions per pass -> how issue-bound is the pass?
                 float pad_ = l.t;
@@ -735,31 +766,35 @@ pathtrace_kernel(const KernelArgs A) {
                 CollideIO<K> cio;
                 collide_idle<K>(cio);
                 const SceneParams& PE = VR_EMISSION_BY_POINTER && K::emission != 0 ? event_args().P : P;      // see collide_prep
-                if (is_c) collide_prep<K, CLEAN>(l, P, PE, cio);
-                collide_load<K>(P, PE, cio);
+                // (VR_COLLIDE_BY_POINTER, round 6: the run-time variant with a transfer function evaluates its collisions on uniforms read through the kernarg pointer too --
+                // scalar loads in the collision code instead of ~20 more scalar registers held through the whole scheduler loop)
+#ifndef VR_COLLIDE_BY_POINTER
+#define VR_COLLIDE_BY_POINTER 1
+#endif
+                const SceneParams& PF = (VR_COLLIDE_BY_POINTER && K::tf && (K::global == 2 || K::emission == 1)) ? event_args().P : P;
+                if (is_c) collide_prep<K, CLEAN>(l, PF, PE, cio);
+                collide_load<K>(PF, PE, cio);
                 if (is_c) {
                     ColdT c = VR_COLD(slot);
-                    if (lut_in_lds) collide_finish<K, ColdT, true>(l, c, P, PE, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
-                    else collide_finish<K, ColdT, true>(l, c, P, PE, cio, P.tf_lut);
+                    if (lut_in_lds) collide_finish<K, ColdT, true>(l, c, PF, PE, cio, lds_lut);      // two instances: LDS reads need the address space at compile time
+                    else collide_finish<K, ColdT, true>(l, c, PF, PE, cio, PF.tf_lut);
                 }
-                if (STATS) { st_exec[ST_COLLIDE] += 1u; st_lanes[ST_COLLIDE] += (uint32_t)n_c; }
+                if (STATS) { stat_add(2 * ST_COLLIDE, 1u); stat_add(2 * ST_COLLIDE + 1, (uint32_t)n_c); }
             }
             // every load of the pass has been consumed or belongs to a lane that left early: say so, or the compiler carries
             // "possibly outstanding" around the loop and waits where nothing is pending
             __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0)
-            if (STATS) st_cyc[ST_COLLIDE] += __builtin_readcyclecounter() - t_blk;
+            if (STATS_T) stat_add(18 + ST_COLLIDE, (uint32_t)__builtin_readcyclecounter() - t_blk);
             return true;
         };
-        if (all_clean) {
+        if constexpr (kCleanForms) {
+            if (all_clean) {
 #pragma unroll
-            for (int hot_rep_ = 0; hot_rep_ < VR_HOT_PAIRS; ++hot_rep_) if (!hot_pair(std::true_type{}, hot_rep_)) break;
+                for (int hot_rep_ = 0; hot_rep_ < kHotPairs; ++hot_rep_) if (!hot_pair(std::true_type{}, hot_rep_)) break;
+            } else hot_pair(std::false_type{}, 0);
         } else {
-#if VR_CLEAN_FORMS
-            hot_pair(std::false_type{}, 0);
-#else
 #pragma unroll
-            for (int hot_rep_ = 0; hot_rep_ < VR_HOT_PAIRS; ++hot_rep_) if (!hot_pair(std::false_type{}, hot_rep_)) break;
-#endif
+            for (int hot_rep_ = 0; hot_rep_ < kHotPairs; ++hot_rep_) if (!hot_pair(std::false_type{}, hot_rep_)) break;
         }
         VR_SECTION(1);                                                   // hot pair (also in st_cyc[MARCH] + st_cyc[COLLIDE])
         // (3) park paths that reached an event
@@ -768,7 +803,7 @@ pathtrace_kernel(const KernelArgs A) {
             // one integer, so that every ballot below is a single v_cmp
             const int32_t ps = (slot >= 0 && l.state != ST_MARCH && l.state != ST_COLLIDE) ? l.state : -1;
             if (wave_ballot(ps >= 0)) {
-                if (STATS) ++n_park;
+                if (STATS) stat_add(15, 1u);
                 if (ps >= 0) {
                     hs.save_marched(l, slot);
                     if (emission_on && !l.shadow) {                                                    // EmissionCache: L back to the cold line, or -- a path without one -- to its slot
@@ -884,7 +919,7 @@ pathtrace_kernel(const KernelArgs A) {
                         if (lo < hi && v < hi - lo) { j = lo + v; break; }
                         ++seg_tries;                                        // this segment is used up for good
                     }
-                    if (j == 0xFFFFFFFFu) { exhausted = true; if (STATS) t_exhausted = __builtin_amdgcn_s_memrealtime(); }
+                    if (j == 0xFFFFFFFFu) { exhausted = true; if (STATS_T) t_exhausted = __builtin_amdgcn_s_memrealtime(); }
                     else { wu = make_unit(E.D, E.P.u.resolution[0], j, nullptr); cursor = 0u; idle_iters = 0u; t_elapsed = 0u; }
                 }
                 n = min(min(64, cnt_free), (int32_t)((uint32_t)wu.n_items - cursor));
@@ -946,27 +981,23 @@ pathtrace_kernel(const KernelArgs A) {
         if (VR_PRIO_EVENTS != VR_PRIO_HOT) __builtin_amdgcn_s_setprio(VR_PRIO_HOT);
         VR_SECTION(3);                                                   // batch decision + event batches (the events' own cycles are in st_cyc)
 #if VR_STAT_SCHED
-        t_tail = t_sec;
+        t_tail = t_sec; have_tail = true;
 #endif
         if (exhausted && cnt_free == VR_POOL) break;                        // every path of the pool has finished
     }
     unsigned long long* const stats = A.stats;
-    if (STATS && stats && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < ST_DONE; ++k) { atomicAdd(&stats[2 * k], (unsigned long long)st_exec[k]); atomicAdd(&stats[2 * k + 1], (unsigned long long)st_lanes[k]); }
-        atomicAdd(&stats[14], (unsigned long long)n_resume);
-        atomicAdd(&stats[15], (unsigned long long)n_park);
-        atomicAdd(&stats[16], (unsigned long long)iters);
-        atomicAdd(&stats[17], 1ull);
-#pragma unroll
-        for (int k = 0; k < ST_DONE; ++k) atomicAdd(&stats[18 + k], st_cyc[k]);
-        atomicAdd(&stats[25], __builtin_readcyclecounter() - t_start);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&stats[26 + k], occ[k]);
-        // per wavefront (diagnostic, tests/tools_wave_timeline.py): when it started, found the queue empty and ended, on the GPU's constant 100 MHz clock
-        stats[kStatsWaveBase + 3u * wave_index] = t_begin_rt;
-        stats[kStatsWaveBase + 3u * wave_index + 1u] = t_exhausted;
-        stats[kStatsWaveBase + 3u * wave_index + 2u] = __builtin_amdgcn_s_memrealtime();
+    if (STATS && stats) {
+        stat_add(16, iters);
+        stat_add(17, 1u);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32 && lane != 25) atomicAdd(&stats[lane], (unsigned long long)lds_stat[wave * 32 + lane]);
+        if (STATS_T && lane == 0) {
+            atomicAdd(&stats[25], __builtin_readcyclecounter() - t_start);
+            // per wavefront (diagnostic, tests/tools_wave_timeline.py): when it started, found the queue empty and ended, on the GPU's constant 100 MHz clock
+            stats[kStatsWaveBase + 3u * wave_index] = t_begin_rt;
+            stats[kStatsWaveBase + 3u * wave_index + 1u] = t_exhausted;
+            stats[kStatsWaveBase + 3u * wave_index + 2u] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 #undef VR_STAT
 #undef VR_COLD
