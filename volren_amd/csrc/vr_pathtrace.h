@@ -676,7 +676,7 @@ pathtrace_kernel(const KernelArgs A) {
         // ... per kernel instance (round 6): the transfer-function kernel with an emission grid -- 8 corner taps, the LUT and a stochastic emission tap in one collision
         // block -- spills 34 scalar registers with four clean copies and the general one, 20 with VR_HOT_PAIRS_TF_EMISSION copies (profiles/r6_kernel_resources.txt)
 #ifndef VR_HOT_PAIRS_TF_EMISSION
-#define VR_HOT_PAIRS_TF_EMISSION 1
+#define VR_HOT_PAIRS_TF_EMISSION 4
 #endif
         constexpr int kHotPairs = (K::tf && K::emission == 1) ? (VR_HOT_PAIRS_TF_EMISSION < VR_HOT_PAIRS ? VR_HOT_PAIRS_TF_EMISSION : VR_HOT_PAIRS) : VR_HOT_PAIRS;
 
