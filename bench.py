@@ -206,7 +206,7 @@ def issue_profile(cfg):
     """Opcode-weighted issue cost of the configuration's kernel (profiles/r5_issue_budget.json, tests/tools_issue_budget_all.sh): cycles per VALU wave-instruction of
     ITS instruction mix, the share of its issue cycles per scheduler section, and the counter SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the same run.  c5full runs the
     sibling of c5cloud's kernel (same code, linear majorant table): its entry is c5cloud's, marked approximate."""
-    j = profile_json("r5_issue_budget.json")
+    j = profile_json("r6_issue_budget.json") or profile_json("r5_issue_budget.json")
     if not j:
         return None, False
     key = {"c4:512": "c4"}.get(cfg, cfg)
@@ -221,7 +221,7 @@ def traffic_profile(cfg, w, h):
     """(entry, file, stale) of the newest committed PMC profile taken on this configuration AT THIS FRAME SIZE (the instruction and traffic mix per sample
     depends on the view: c4 at 1920x1080 is not c4 at 1024x1024), or (None, None, None).  Round 4's file is keyed by the bench line's config names and
     records the frame; older files only have the square frames of their rounds."""
-    for name in ("r5_hbm_traffic.json", "r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
+    for name in ("r6_hbm_traffic.json", "r5_hbm_traffic.json", "r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
         tj = profile_json(name)
         if not tj:
             continue
@@ -419,7 +419,7 @@ def roofline_of(config, w, h, spp, m, counted):
         issue = {"bound": "valu_issue", "achieved": ach_issue, "peak": peak_issue, "unit": "G wave-instructions/s", "frac": ach_issue / peak_issue,
                  "valu_wave_instructions_per_sample": valu, "lane_utilisation": tp.get("lane_utilisation"), "hbm_frac": achieved / HBM_PEAK_GBS,
                  "cycles_per_valu_op": cyc, "cycles_per_valu_op_cheapest": CYCLES_PER_VALU_OP, "frac_at_cheapest_opcode_cost": ach_issue / (SIMDS * CLOCK_GHZ / CYCLES_PER_VALU_OP),
-                 "cycles_source": ("profiles/r5_issue_budget.json (static ISA per scheduler section x STATS execution counts x profiles/r5_instruction_costs.txt)" + (", entry of the sibling kernel c5cloud" if approx else "")) if ip else "profiles/r2_valu_issue_rate.txt",
+                 "cycles_source": ("profiles/r6_issue_budget.json (static ISA per scheduler section x STATS execution counts x profiles/r5_instruction_costs.txt)" + (", entry of the sibling kernel c5cloud" if approx else "")) if ip else "profiles/r2_valu_issue_rate.txt",
                  "simds": SIMDS, "clock_ghz": CLOCK_GHZ, "counts_source": tp_file, "stale": bool(stale)}
         if ip:
             # the counter beside the model: quad-cycles a wavefront spends in VALU instructions / its resident quad-cycles, x resident wavefronts per SIMD = VALU pipelines'

@@ -127,19 +127,26 @@ struct hk_grid_desc {
 
 int hk_uniforms_size() { return (int)sizeof(Uniforms); }
 
-// env_rgb: texture order (row 0 bottom), 3 floats per texel.  Returns the number of lane steps executed.
-long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_grid_desc* emission, const float* lut,
-                    const float* env_rgb, int env_w, int env_h, const float* impmap, int imp_dim,
-                    float* fb, int x0, int y0, int x1, int y1, int first_sample, int n_samples) {
-    const Uniforms& u = *up;
+// the scene as the lane code sees it (SceneParams + the arrays its views point into), built from the oracle's arrays exactly as the product builds its device copies
+struct HostScene {
     SceneParams P{};
-    P.u = u;
     HostGrid dg, eg;
+    std::vector<uint16_t> blocked;
+    std::vector<float> env, cdf;
+};
+static void build_scene(HostScene& S, const Uniforms* up, const hk_grid_desc* density, const hk_grid_desc* emission, const float* lut,
+                        const float* env_rgb, int env_w, int env_h, const float* impmap, int imp_dim) {
+    SceneParams& P = S.P;
+    HostGrid& dg = S.dg; HostGrid& eg = S.eg;
+    std::vector<uint16_t>& blocked = S.blocked;
+    std::vector<float>& env = S.env; std::vector<float>& cdf = S.cdf;
+    const Uniforms& u = *up;
+    P.u = u;
     build_grid(dg, u, lut, density->nb, density->indirection, density->range, density->atlas_dim, density->atlas, density->n_mips, density->mips, true,
                // the majorant table's levels 0-1 in 4x4x4-cell blocks (a per-grid choice of the product since round 5; the lane code reads the view's flag at run time here)
                std::getenv("VR_HOST_MAJ_BLOCKED") != nullptr && std::getenv("VR_HOST_MAJ_BLOCKED")[0] == '1');
     P.density = dg.view;
-    std::vector<uint16_t> blocked;                 // == dense_grid_to_device: 4x4x4 blocks
+    // (blocked: == dense_grid_to_device: 4x4x4 blocks)
     if (density->dense) {
         const uint32_t dx = density->dim[0], dy = density->dim[1], dz = density->dim[2];
         const uint32_t bx = (dx + 3u) / 4u, by = (dy + 3u) / 4u, bz = (dz + 3u) / 4u;
@@ -159,12 +166,12 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
             P.emission_from_density[4 * c + r] = a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1] + a[8 + r] * b[4 * c + 2] + a[12 + r] * b[4 * c + 3];
     }
     P.tf_lut = lut;
-    std::vector<float> env((size_t)env_w * env_h * kEnvTexelFloats);
+    env.assign((size_t)env_w * env_h * kEnvTexelFloats, 0.0f);
     for (size_t i = 0; i < (size_t)env_w * env_h; ++i) for (int k = 0; k < 3; ++k) env[kEnvTexelFloats * i + k] = env_rgb[3 * i + k];
     P.envmap = env.data(); P.env_w = env_w; P.env_h = env_h;
     P.impmap = impmap; P.imp_dim = imp_dim;
     int base = 0; while ((1 << base) < imp_dim) ++base;
-    std::vector<float> cdf(env_cdf_table_floats(base - 1), 0.0f);
+    cdf.assign(env_cdf_table_floats(base - 1), 0.0f);
     {   // == env_cdf_kernel of vr_kernels.hip
         for (int mip = base - 1; mip >= 0; --mip) {
             const int d = imp_dim >> mip, hd = d >> 1;
@@ -181,6 +188,16 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
     }
     P.env_cdf = cdf.data();
     P.cam_z = -0.5f / tan_(0.5f * kPi * u.cam_fov / 180.f);
+}
+
+// env_rgb: texture order (row 0 bottom), 3 floats per texel.  Returns the number of lane steps executed.
+long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_grid_desc* emission, const float* lut,
+                    const float* env_rgb, int env_w, int env_h, const float* impmap, int imp_dim,
+                    float* fb, int x0, int y0, int x1, int y1, int first_sample, int n_samples) {
+    HostScene S;
+    build_scene(S, up, density, emission, lut, env_rgb, env_w, env_h, impmap, imp_dim);
+    const SceneParams& P = S.P;
+    const Uniforms& u = P.u;
     long long steps = 0;
     const int W = u.resolution[0], H = u.resolution[1];
     if (u.integrator == 2 && u.use_tf) {       // direct volume rendering: one call per (pixel, sample)
@@ -240,6 +257,165 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
             }
     return steps;
 }
+
+#if defined(VR_HOST_TRACE)
+// ---- L2 model (tests/tools_l2_breakdown.py, round 6): which class of access leaves one XCD's L2? ------------------------------------------------------------------
+// A population of `population` paths -- what one XCD keeps in flight: 1024 wavefronts x 188 pool slots -- works through the pixel-samples of a band of the frame (an
+// XCD's segment of the work queue is a contiguous band of tiles), every live path advancing by one state transition per round (a march pass of two DDA steps, a
+// tentative collision, an event), so that the paths' accesses interleave as a population's do.  Every access the DEVICE makes in that transition is presented, with
+// its device-layout address, to a model of the XCD's L2: `l2_bytes` in 128-byte lines, `ways`-way set associative, LRU, write-allocate without fetch.  The read-only
+// tables report through the hooks in vr_trace.h (VR_TRACE); the cold path state (64-byte slots, the accesses the device scheduler makes: vr_pathtrace.h) and the
+// sample pool are generated here.  Per class: accesses, accesses to a line other than the path's previous one of that class (what an L1 cannot merge), L2 misses.
+// Not modelled: the L1s, the Infinity Cache, the scheduler's batching (a path waits for its event batch on the device).
+}  // extern "C" (reopened below)
+namespace {
+enum SimClass { SC_MAJ_FINE = 0, SC_MAJ_COARSE, SC_TAP_DENSITY, SC_TAP_EMISSION, SC_ENV_WARP, SC_ENV_TEXEL, SC_COLD_READ, SC_COLD_WRITE, SC_SAMPLE_WRITE, SC_COUNT };
+struct L2Model {
+    uint32_t sets = 0, ways = 0;
+    std::vector<uint64_t> tag;      // [set][way], 0 = empty; line address + 1
+    std::vector<uint32_t> age;
+    std::vector<uint8_t> dirty;
+    uint32_t clock = 0;
+    unsigned long long writebacks = 0;
+    void init(size_t bytes, uint32_t w) { ways = w; sets = (uint32_t)(bytes / 128u / w); tag.assign((size_t)sets * w, 0); age.assign((size_t)sets * w, 0); dirty.assign((size_t)sets * w, 0); }
+    // returns true on a hit
+    bool access(uint64_t line, bool write) {
+        const uint64_t h = line ^ (line >> 11) ^ (line >> 23);
+        const size_t base = (size_t)(h % sets) * ways;
+        ++clock;
+        size_t victim = base; uint32_t oldest = 0xFFFFFFFFu;
+        for (size_t i = base; i < base + ways; ++i) {
+            if (tag[i] == line + 1) { age[i] = clock; if (write) dirty[i] = 1; return true; }
+            if (tag[i] == 0) { victim = i; oldest = 0; }
+            else if (oldest != 0 && age[i] < oldest) { victim = i; oldest = age[i]; }
+        }
+        if (tag[victim] != 0 && dirty[victim]) ++writebacks;
+        tag[victim] = line + 1; age[victim] = clock; dirty[victim] = write ? 1 : 0;
+        return false;
+    }
+};
+struct SimSink {
+    L2Model l2;
+    unsigned long long acc[SC_COUNT] = {}, newline[SC_COUNT] = {}, miss[SC_COUNT] = {};
+    uint64_t* last = nullptr;        // the current path's last line per class
+    const void* density_table = nullptr; const void* emission_table = nullptr; const void* maj_table = nullptr;
+    uint32_t maj_coarse_from = 0;    // first cell of majorant level 2
+    bool paired = false;             // density and emission taps read ONE paired atlas (vr_scene.h pair_voxel_line)
+    void touch(int cls, uint64_t space, uint64_t byte, uint32_t bytes, bool write) {
+        const uint64_t l0 = byte >> 7, l1 = (byte + bytes - 1) >> 7;
+        for (uint64_t l = l0; l <= l1; ++l) {
+            const uint64_t line = (space << 40) | l;
+            ++acc[cls];
+            if (last && last[cls] == line + 1) continue;          // the line this path touched last in this class, in this transition: one instruction (or the L1) serves it
+            if (last) last[cls] = line + 1;
+            ++newline[cls];
+            if (!l2.access(line, write)) ++miss[cls];
+        }
+    }
+};
+SimSink* g_sink = nullptr;
+}  // namespace
+namespace vr {
+void host_trace(int32_t cls, const void* table, size_t a, size_t b) {
+    SimSink* S = g_sink;
+    if (!S) return;
+    if (cls == TR_MAJORANT) {
+        if (table != S->maj_table) return;                          // (the emission grid's majorant table is never read)
+        S->touch(a >= S->maj_coarse_from ? SC_MAJ_COARSE : SC_MAJ_FINE, 1, (uint64_t)a * b, (uint32_t)b, false);
+    } else if (cls == TR_TAP) {
+        const bool em = table == S->emission_table;
+        if (!em && table != S->density_table) return;
+        // device layout: the paired atlas (ten 128-byte lines per brick: header + 56 (density, emission) voxel pairs each) or the grid's own brick-linear atlas
+        // (five lines per brick: header + 120 voxels each); header and voxel come from ONE line
+        const uint64_t line = S->paired ? (uint64_t)a * (kPairBlockBytes / 128u) + pair_voxel_line((uint32_t)b) : (uint64_t)a * (kBrickBlockBytes / 128u) + brick_voxel_line((uint32_t)b);
+        S->touch(em ? SC_TAP_EMISSION : SC_TAP_DENSITY, (S->paired || !em) ? 2 : 3, line << 7, 4, false);
+    } else if (cls == TR_ENV_WARP) {
+        S->touch(SC_ENV_WARP, 4, a, (uint32_t)b, false);
+    } else if (cls == TR_ENV_TEXEL) {
+        S->touch(SC_ENV_TEXEL, 5, a, (uint32_t)b, false);
+    }
+}
+}  // namespace vr
+extern "C" {
+// out: SC_COUNT x 3 counters (accesses, new-line accesses, L2 misses), then [27] dirty lines written back, [28] samples finished, [29] lane steps
+long long hk_l2_breakdown(const Uniforms* up, const hk_grid_desc* density, const hk_grid_desc* emission, const float* lut,
+                          const float* env_rgb, int env_w, int env_h, const float* impmap, int imp_dim,
+                          int x0, int y0, int x1, int y1, int spp, int population, long long l2_bytes, int ways, int paired, int lazy_emission,
+                          unsigned long long* out) {
+    HostScene S;
+    build_scene(S, up, density, emission, lut, env_rgb, env_w, env_h, impmap, imp_dim);
+    const SceneParams& P = S.P;
+    const Uniforms& u = P.u;
+    SimSink sink;
+    sink.l2.init((size_t)l2_bytes, (uint32_t)ways);
+    sink.density_table = P.density.atlas; sink.emission_table = u.has_emission ? P.emission.atlas : nullptr; sink.maj_table = P.density.majorant16;
+    sink.maj_coarse_from = majorant_level_offset((uint32_t)(P.density.mshift[0] + P.density.mshift[1] + P.density.mshift[2]), 2u);
+    sink.paired = paired != 0;
+    struct ColdHost {
+        float v[C_COUNT];
+        float ld(int32_t f) const { return v[f]; }
+        void st(int32_t f, float x) { v[f] = x; }
+    };
+    struct Path { Hot h; ColdHost c; FirstStash stash; uint64_t last[SC_COUNT]; bool scattered; };
+    std::vector<Path> paths((size_t)population);
+    for (Path& p : paths) { hot_init(p.h); p.h.state = ST_NEW; memset(p.last, 0, sizeof p.last); p.scattered = false; memset(&p.c, 0, sizeof p.c); p.stash = FirstStash{}; }
+    // work units: the 8x8 tiles of the band in raster order, all `spp` samples of a tile in one unit (the device's queue keeps a sub-tile's sample chunks adjacent)
+    const int tx0 = x0 & ~7, ty0 = y0 & ~7;
+    const int ntx = (x1 - tx0 + 7) / 8, nty = (y1 - ty0 + 7) / 8;
+    const size_t n_units = (size_t)ntx * nty;
+    std::vector<float> sbuf((size_t)64 * spp * 4, 0.0f);                       // (one unit's worth: the radiances themselves are not needed)
+    size_t unit = 0;
+    WorkUnit wu; uint32_t next_item = 0;
+    auto open_unit = [&](size_t k) { wu.px0 = tx0 + 8 * (int)(k % ntx); wu.py0 = ty0 + 8 * (int)(k / ntx); wu.first_sample = 1; wu.n_items = 64 * spp; wu.base = 0u; wu.out = sbuf.data(); next_item = 0; };
+    open_unit(0);
+    const bool emission_on = u.has_emission != 0;
+    unsigned long long finished = 0, steps = 0;
+    g_sink = &sink;
+    bool any = true;
+    while (any) {
+        any = false;
+        for (size_t i = 0; i < paths.size(); ++i) {
+            Path& p = paths[i];
+            Hot& l = p.h;
+            if (l.state == ST_DONE) continue;
+            if (l.state == ST_NEW) {
+                while (next_item >= (uint32_t)wu.n_items && unit + 1 < n_units) open_unit(++unit);
+                if (next_item >= (uint32_t)wu.n_items) { l.state = ST_DONE; continue; }
+                p.scattered = false;
+                memset(p.last, 0, sizeof p.last);
+            }
+            any = true;
+            memset(p.last, 0, sizeof p.last);                                  // merging only inside ONE transition (the dwordx4 loads of one block, a tap's header and voxel)
+            sink.last = p.last;
+            const uint64_t cold_byte = (uint64_t)i * 64u;                    // this slot's 64-byte cold slot in the XCD's share of the workspace
+            const int32_t st = l.state;
+            // the cold state as the DEVICE scheduler touches it (vr_pathtrace.h): a path has no cold line before its first scatter event (FirstStash; with an emission
+            // grid: lazy_emission kernels); the collision event reads the line (not on a path's first) and writes sector 0, the scatter event reads it and writes
+            // both sectors, the escape of a path that scattered reads it; emission kernels also read throughput and radiance when such a path is resumed for a
+            // camera / scatter segment and write the radiance back when it is parked
+            if (st == ST_NEE) { if (p.scattered) sink.touch(SC_COLD_READ, 6, cold_byte, 64, false); sink.touch(SC_COLD_WRITE, 6, cold_byte, p.scattered ? 32 : 64, true); }
+            else if (st == ST_POSTNEE) { sink.touch(SC_COLD_READ, 6, cold_byte, 64, false); sink.touch(SC_COLD_WRITE, 6, cold_byte, 64, true); }
+            else if (st == ST_ESCAPE) { if (p.scattered) sink.touch(SC_COLD_READ, 6, cold_byte, 64, false); sink.touch(SC_SAMPLE_WRITE, 7, finished * 16u, 16, true); }
+            const int32_t shadow_before = l.shadow;
+            if (u.use_tf) lane_step<TraceCfg<true, 2, 2, 2, 2>>(l, p.c, P, wu, next_item, p.stash); else lane_step<TraceCfg<false, 2, 2, 2, 2>>(l, p.c, P, wu, next_item, p.stash);
+            ++steps;
+            if (st == ST_NEE) p.scattered = true;
+            if (emission_on && (lazy_emission ? p.scattered : true)) {
+                // a camera / scatter segment begins (the path will be resumed: read thr + L) or ends (parked: write L) -- once per segment each
+                if ((st == ST_POSTNEE || (st == ST_NEW && !lazy_emission)) && (l.state == ST_MARCH || l.state == ST_COLLIDE) && !l.shadow) sink.touch(SC_COLD_READ, 6, cold_byte, 32, false);
+                if ((st == ST_MARCH || st == ST_COLLIDE) && !shadow_before && l.state != ST_MARCH && l.state != ST_COLLIDE) sink.touch(SC_COLD_WRITE, 6, cold_byte + 32u, 16, true);
+            }
+            if (st == ST_POSTNEE && l.state == ST_NEW) sink.touch(SC_SAMPLE_WRITE, 7, finished * 16u, 16, true);      // bounce cap / roulette: the scatter event writes the sample
+            if (st == ST_ESCAPE || (st == ST_POSTNEE && l.state == ST_NEW)) { ++finished; }
+            if (l.state == ST_NEW && st != ST_NEW) { /* the slot is free: it takes the next item in its next round */ }
+        }
+    }
+    g_sink = nullptr;
+    for (int c = 0; c < SC_COUNT; ++c) { out[3 * c] = sink.acc[c]; out[3 * c + 1] = sink.newline[c]; out[3 * c + 2] = sink.miss[c]; }
+    out[27] = sink.l2.writebacks; out[28] = finished; out[29] = steps;
+    return (long long)finished;
+}
+#endif
 
 void hk_set_trace(uint32_t* buf, unsigned long long cap) { g_trace = buf; g_trace_cap = (size_t)cap; g_trace_n = 0; }
 unsigned long long hk_trace_count() { return (unsigned long long)g_trace_n; }

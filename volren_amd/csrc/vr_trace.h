@@ -21,6 +21,18 @@
 #include "vr_math.h"
 #include "vr_scene.h"
 
+// Memory-access hooks of the HOST build used by tests/tools_l2_breakdown.py (round 6: which class of access misses the L2?).  Compiled to nothing everywhere else --
+// the product and the device never see them; tests/hostkernel/host_kernel.cpp defines the sink when it is built with -DVR_HOST_TRACE.
+#if defined(VR_HOST_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+namespace vr {
+enum TraceClass : int32_t { TR_MAJORANT = 0, TR_TAP = 1, TR_ENV_WARP = 2, TR_ENV_TEXEL = 3 };
+void host_trace(int32_t cls, const void* table, size_t a, size_t b);       // majorant: (cell index, -); tap: (cell, voxel offset); environment: (byte offset, bytes)
+}
+#define VR_TRACE(CLS, TABLE, A, B) ::vr::host_trace((CLS), (TABLE), (size_t)(A), (size_t)(B))
+#else
+#define VR_TRACE(CLS, TABLE, A, B) do { } while (0)
+#endif
+
 namespace vr {
 
 enum LaneState : int32_t {
@@ -201,6 +213,7 @@ VR_HD TapAddr tap_addr(const GridView& g, int32_t x, int32_t y, int32_t z) {
 template <int DENSE = 2, int PAIR = 0>
 VR_HD TapData tap_load(const GridView& g, TapAddr a) {
     TapData d;
+    VR_TRACE(1, g.atlas ? (const void*)g.atlas : (const void*)g.dense, a.cell, a.off);
     if (PAIR != 0) {
         // paired atlas: ten lines of [rmin_d, rdiff_d, rmin_e, rdiff_e | 56 x (density, emission)] per brick
         const uint32_t line = pair_voxel_line(a.off);
@@ -332,6 +345,7 @@ VR_HD uint32_t majorant_fetch(const GridView& g, int32_t idx) {
 #if VR_MAJ_OUTSIDE_CELL && defined(__clang__)
     __builtin_assume(i >= 0);                        // a table index (at most 73/64 x 2^30 cells, vr_scene.h): zero- instead of sign-extended into the 64-bit address
 #endif
+    VR_TRACE(0, g.majorant16, i, TF ? 4 : 2);
     return TF ? f2u(g.majorant[i]) : (uint32_t)g.majorant16[i];
 }
 template <bool TF>
@@ -709,6 +723,8 @@ VR_HD v3 env_texture(const SceneParams& P, float u, float v) {
     const float* t10 = P.envmap + kEnvTexelFloats * ((size_t)y0 * w + x1);
     const float* t01 = P.envmap + kEnvTexelFloats * ((size_t)y1 * w + x0);
     const float* t11 = P.envmap + kEnvTexelFloats * ((size_t)y1 * w + x1);
+    VR_TRACE(3, P.envmap, (t00 - P.envmap) * 4, 16); VR_TRACE(3, P.envmap, (t10 - P.envmap) * 4, 16);
+    VR_TRACE(3, P.envmap, (t01 - P.envmap) * 4, 16); VR_TRACE(3, P.envmap, (t11 - P.envmap) * 4, 16);
     v3 r;
     r.x = mix_(mix_(t00[0], t10[0], fx), mix_(t01[0], t11[0], fx), fy);
     r.y = mix_(mix_(t00[1], t10[1], fx), mix_(t01[1], t11[1], fx), fy);
@@ -770,12 +786,14 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
     float w_texel = 0.0f;                                       // importance of the texel the descent ends in == imp_fetch(P, posx, posy, 0)
     int32_t k = 0;
     if ((top & 1) == 0) {                                       // odd number of levels: level 0 alone
+        VR_TRACE(2, P.env_cdf, 0, 12);
         const int32_t c = env_warp_level<ENVDC>(blk, px, py, posx, posy);
         if (top == 0) w_texel = blk[3 + c];
         blk += kEnvCdfBlockFloats; k = 1;
     }
     for (; k + 1 < top; k += 2) {                               // levels k and k + 1: parent record, then the chosen child's in the same block
         const float* b = blk + kEnvCdfBlockFloats * (size_t)((posy << k) + posx);
+        VR_TRACE(2, P.env_cdf, (b - P.env_cdf) * 4, 64);
 #if VR_ENV_BLOCK_LOADS && defined(__HIP_DEVICE_COMPILE__)
         if (BLOCK) {
         // the whole 64-byte block at once -- parent record and all four children's -- and the child picked in registers: one memory round trip per pair of
@@ -799,6 +817,7 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
     if (k < top) {                                              // the last pair: one 128-byte line, the finest records carry their four texels
         const int32_t s = (top & 1) ? 0 : 1;
         const float* b = P.env_cdf + env_cdf_last_pair_floats(s, (top + 1 - s) / 2) + kEnvCdfLastBlockFloats * (size_t)((posy << k) + posx);
+        VR_TRACE(2, P.env_cdf, (b - P.env_cdf) * 4, 128);
         const int32_t c = env_warp_level<ENVDC>(b, px, py, posx, posy);
         const float* child = b + kEnvCdfLastChild0 + kEnvCdfLastChildFloats * c;
         const int32_t c2 = env_warp_level<ENVDC>(child, px, py, posx, posy);
