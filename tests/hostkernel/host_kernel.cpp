@@ -341,11 +341,16 @@ extern "C" {
 long long hk_l2_breakdown(const Uniforms* up, const hk_grid_desc* density, const hk_grid_desc* emission, const float* lut,
                           const float* env_rgb, int env_w, int env_h, const float* impmap, int imp_dim,
                           int x0, int y0, int x1, int y1, int spp, int population, long long l2_bytes, int ways, int paired, int lazy_emission,
-                          unsigned long long* out) {
+                          unsigned long long* out, int n_bands) {
+    // n_bands > 1: that many bands of y1 - y0 rows one after the other from y0 on (the frame's XCD segments), each with an L2 and a population of its own;
+    // out then holds the bands' counters one after the other (32 words each)
     HostScene S;
     build_scene(S, up, density, emission, lut, env_rgb, env_w, env_h, impmap, imp_dim);
     const SceneParams& P = S.P;
     const Uniforms& u = P.u;
+    const int band_rows = y1 - y0;
+    long long total = 0;
+    for (int band = 0; band < (n_bands > 0 ? n_bands : 1); ++band, y0 += band_rows, y1 += band_rows, out += 32) {
     SimSink sink;
     sink.l2.init((size_t)l2_bytes, (uint32_t)ways);
     sink.density_table = P.density.atlas; sink.emission_table = u.has_emission ? P.emission.atlas : nullptr; sink.maj_table = P.density.majorant16;
@@ -413,7 +418,9 @@ long long hk_l2_breakdown(const Uniforms* up, const hk_grid_desc* density, const
     g_sink = nullptr;
     for (int c = 0; c < SC_COUNT; ++c) { out[3 * c] = sink.acc[c]; out[3 * c + 1] = sink.newline[c]; out[3 * c + 2] = sink.miss[c]; }
     out[27] = sink.l2.writebacks; out[28] = finished; out[29] = steps;
-    return (long long)finished;
+    total += (long long)finished;
+    }
+    return total;
 }
 #endif
 

@@ -10,7 +10,10 @@ misses; the measured totals of the same configuration (rocprofv3, profiles/r5_pm
 Not modelled: the L1s (a CU's 16 wavefronts share 32 KiB: the "new line" column is what they cannot merge), the 256 MiB Infinity Cache behind the L2, the scheduler's
 batching (on the device a path waits for its event batch), the other seven XCDs (independent L2s, other bands).
 
-usage: tools_l2_breakdown.py [cfg=c5cloud] [frame=2048] [spp=2] [band rows=1/8 of the frame] [population=192512] [l2 MiB=4]"""
+The frame is simulated as the device works through it: eight bands of tile rows, one per XCD, each with its own L2 and population; the table is the sum over the
+bands, the per-band totals follow (the bands through the cloud carry most of the work).
+
+usage: tools_l2_breakdown.py [cfg=c5cloud] [frame=2048] [spp=2] [bands=8] [population=192512] [l2 MiB=4]"""
 import ctypes as C
 import json
 import os
@@ -25,7 +28,8 @@ import hk_binding  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c5cloud"
 frame = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-rows = int(sys.argv[4]) if len(sys.argv) > 4 else frame // 8
+bands = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+rows = frame // bands
 population = int(sys.argv[5]) if len(sys.argv) > 5 else 1024 * 188
 l2_mib = float(sys.argv[6]) if len(sys.argv) > 6 else 4.0
 
@@ -51,19 +55,19 @@ p = o.params()
 dd = hk_binding.grid_desc(o.density)
 ed = hk_binding.grid_desc(o.emission) if has_emission else None
 env, lut = o.env_tex, o.lut
-out = (C.c_ulonglong * 32)()
-# the band in the middle of the frame (where the volume is)
-y0 = max(0, frame // 2 - rows // 2) & ~15
+out = (C.c_ulonglong * (32 * bands))()
+y0 = 0
 t0 = time.time()
 n = L.hk_l2_breakdown(C.byref(p), C.byref(dd), C.byref(ed) if ed is not None else None, lut.ctypes.data_as(C.c_void_p) if lut is not None else None,
                       env.ctypes.data_as(C.c_void_p), env.shape[1], env.shape[0], o.impmap.ctypes.data_as(C.c_void_p), 512,
-                      0, y0, frame, y0 + rows, spp, population, C.c_longlong(int(l2_mib * (1 << 20))), 16, int(paired), 1, out)
+                      0, y0, frame, y0 + rows, spp, population, C.c_longlong(int(l2_mib * (1 << 20))), 16, int(paired), 1, out, bands)
 dt = time.time() - t0
 names = ["majorant table, levels 0-1", "majorant table, levels 2-3", "density tap", "emission tap", "environment warp table", "environment texels", "cold path state, reads",
          "cold path state, writes", "sample pool, writes"]
-acc = np.array([[out[3 * c + k] for k in range(3)] for c in range(9)], np.float64) / max(n, 1)
-print("# %s at %d^2, band of %d rows from row %d, %d spp: %d samples by %d concurrent paths, L2 model %.0f MiB 16-way; layouts: %s atlas, majorant levels 0-1 %s (%d active bricks); %.0f s on the host" % (
-    cfg, frame, rows, y0, spp, n, population, l2_mib, "paired" if paired else "own", "in 4x4x4-cell blocks" if blocked else "linear", n_active, dt))
+raw = np.array([[[out[32 * b + 3 * c + k] for k in range(3)] for c in range(9)] for b in range(bands)], np.float64)
+acc = raw.sum(0) / max(n, 1)
+print("# %s at %d^2 in %d bands of %d rows (one per XCD), %d spp: %d samples, %d concurrent paths and a %.0f MiB 16-way L2 per band; layouts: %s atlas, majorant levels 0-1 %s (%d active bricks); %.0f s on the host" % (
+    cfg, frame, bands, rows, spp, n, population, l2_mib, "paired" if paired else "own", "in 4x4x4-cell blocks" if blocked else "linear", n_active, dt))
 print("# per sample:                      accesses   to a new line   L2 misses   share of the read misses   fabric bytes (128 B per read miss; writes: 32 B per dirtied sector)")
 rd = [0, 1, 2, 3, 4, 5, 6]
 tot_miss = acc[rd, 2].sum()
@@ -71,7 +75,8 @@ for c, nm in enumerate(names):
     is_w = c >= 7
     print("  %-30s %9.2f %13.2f %11.2f %12s %20.0f" % (nm, acc[c, 0], acc[c, 1], acc[c, 2], "-" if is_w else "%.1f %%" % (100 * acc[c, 2] / max(tot_miss, 1e-9)), acc[c, 0] * 32 if is_w else acc[c, 2] * 128))
 print("  %-30s %9.2f %13.2f %11.2f %12s %20.0f   (reads only)" % ("all reads", acc[rd, 0].sum(), acc[rd, 1].sum(), tot_miss, "100 %", tot_miss * 128))
-print("  dirty lines written back by the model: %.2f per sample" % (out[27] / max(n, 1)))
+print("  dirty lines written back by the model: %.2f per sample" % (sum(out[32 * b + 27] for b in range(bands)) / max(n, 1)))
+print("# per band (XCD): share of the frame's read misses / of its accesses:", "  ".join("%d: %.0f %% / %.0f %%" % (b, 100 * raw[b, :7, 2].sum() / max(raw[:, :7, 2].sum(), 1), 100 * raw[b, :7, 0].sum() / max(raw[:, :7, 0].sum(), 1)) for b in range(bands)))
 try:
     pm = json.load(open(os.path.join(os.path.dirname(here), "profiles", "r5_pmc_summary.json")))
     key = {"c5cloud": "c5cloud", "c4:512": "c4", "c2": "c2", "c5full": "c5full"}.get(cfg)
