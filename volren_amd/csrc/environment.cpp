@@ -1,6 +1,10 @@
 // environment.cpp -- see environment.h.  Follows src/environment.cpp:6-33.
 #include "environment.h"
 
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
 #include "imageio.h"
 #include "vr_device.h"
 
@@ -41,6 +45,36 @@ void Environment::build(const float* rgb, int w, int h) {
         }
     envmap = make_device_buffer(tex.size() * sizeof(float));
     envmap->upload(tex.data(), tex.size() * sizeof(float));
+    // Compact form for the path tracer's texel fetches (round 6): a texel whose three components are m_c * 2^(e - 136) with 8-bit integers m_c and one shared e in
+    // [10, 255] -- every texel of a Radiance file is; e >= 10 keeps the scale a normal float -- packs into one dword that decodes to the same three floats exactly.
+    // One texel that is not such a number (a map handed over as floats usually has some) and the map keeps its float form only.  VR_ENV_RGBE=0 switches it off.
+    {
+        std::vector<uint32_t> packed((size_t)w * h);
+        bool exact = !(std::getenv("VR_ENV_RGBE") && std::getenv("VR_ENV_RGBE")[0] == '0');
+        for (size_t i = 0; exact && i < packed.size(); ++i) {
+            const float* c = &tex[kEnvTexelFloats * i];
+            const float mx = std::max(c[0], std::max(c[1], c[2]));
+            if (!(c[0] >= 0.0f && c[1] >= 0.0f && c[2] >= 0.0f) || std::signbit(c[0]) || std::signbit(c[1]) || std::signbit(c[2]) || !std::isfinite(mx)) { exact = false; break; }
+            if (mx == 0.0f) { packed[i] = 0u; continue; }
+            int k = 0;
+            (void)std::frexp(mx, &k);                                   // mx = f * 2^k, f in [0.5, 1): its mantissa as an integer below 256 needs the scale 2^(k - 8)
+            const int e = k - 8 + 136;
+            if (e < 10 || e > 255) { exact = false; break; }
+            const float scale = std::ldexp(1.0f, e - 136);
+            uint32_t q = (uint32_t)e << 24;
+            for (int j = 0; j < 3; ++j) {
+                const float m = c[j] / scale;                            // exact: a power of two
+                const uint32_t mi = (uint32_t)m;
+                if (m != (float)mi || mi > 255u || (float)mi * scale != c[j]) { exact = false; break; }
+                q |= mi << (8 * j);
+            }
+            packed[i] = q;
+        }
+        if (exact) {
+            envmap_rgbe = make_device_buffer(packed.size() * sizeof(uint32_t));
+            envmap_rgbe->upload(packed.data(), packed.size() * sizeof(uint32_t));
+        }
+    }
     size_t n = 0;
     for (uint32_t d = DIMENSION; d >= 1; d >>= 1) n += (size_t)d * d;
     impmap = make_device_buffer(n * sizeof(float));

@@ -25,6 +25,7 @@ public:
     mat3 transform;
     float strength;
     DeviceBufferPtr envmap;      // RGBA32F texels, row 0 = bottom of the image (GL texture order)
+    DeviceBufferPtr envmap_rgbe; // the same texels, one dword each (vr_scene.h SceneParams::env_rgbe), when every texel is exactly an RGBE number; else null
     DeviceBufferPtr impmap;      // R32F pyramid: 512^2, 256^2, ..., 1
     DeviceBufferPtr cdf;         // per-2x2-block warp thresholds derived from the pyramid (see vr_trace.h sample_environment)
     int width = 0, height = 0;

@@ -413,6 +413,7 @@ void RendererHIP::fill_params(SceneParams& P) {
     u.env_imp_inv_dim[0] = u.env_imp_inv_dim[1] = 1.f / (float)environment->dimension();
     u.env_imp_base_mip = (int)std::floor(std::log2((float)environment->dimension()));
     P.envmap = environment->envmap->as<float>();
+    P.env_rgbe = environment->envmap_rgbe ? environment->envmap_rgbe->as<uint32_t>() : nullptr;
     P.env_w = environment->width; P.env_h = environment->height;
     P.impmap = environment->impmap->as<float>();
     P.imp_dim = (int)environment->dimension();
@@ -559,6 +560,7 @@ void RendererHIP::capture(LaunchInputs& in) {
     in.env = environment; in.tf = transferfunc;
     in.keep[0] = environment->envmap; in.keep[1] = environment->impmap; in.keep[2] = environment->cdf;
     in.keep[3] = transferfunc ? transferfunc->lut_ssbo : DeviceBufferPtr();
+    in.keep[4] = environment->envmap_rgbe;
 }
 
 // samples of one sub-launch as the sample pool and the 32-bit item indices allow (before any sizing by time)

@@ -182,7 +182,7 @@ private:
         hipStream_t stream = nullptr;
         std::shared_ptr<Environment> env;
         std::shared_ptr<TransferFunction> tf;
-        DeviceBufferPtr keep[4];               // envmap, impmap, env_cdf, lut
+        DeviceBufferPtr keep[5];               // envmap, impmap, env_cdf, lut, compact envmap
         bool same_launch_as(const LaunchInputs& o) const;
     };
     void capture(LaunchInputs& in);            // validates, builds the decoded float atlas when a LUT needs it, fills `in` from the current fields

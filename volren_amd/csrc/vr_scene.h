@@ -170,6 +170,9 @@ struct SceneParams {
     int32_t paired;                    // host side only (which kernel variant serves the scene): density.atlas and emission.atlas are ONE paired atlas (kPairBlockBytes per brick)
     const float* tf_lut;               // tf_size x vec4 (std430 SSBO binding 4)
     const float* envmap;               // env_w*env_h texels of kEnvTexelFloats floats (RGB), row 0 = v~0
+    const uint32_t* env_rgbe;          // round 6: the same texels as r | g << 8 | b << 16 | e << 24 (value = float(m) * 2^(e - 136), 0 for e = 0) when EVERY texel of the map
+                                       // is exactly such a number -- a Radiance .hdr file's always are --, else null: a quarter of the bytes behind every texel fetch
+                                       // (the 1024 x 512 map: 2 MiB instead of 8, smaller than an XCD's L2); env_texture decodes to the same floats, bit for bit
     int32_t env_w, env_h;
     const float* impmap;               // importance pyramid, level 0 (dim^2) first, 2x2 box mips after it
     int32_t imp_dim;

@@ -711,6 +711,8 @@ VR_HD int32_t wrap_repeat(int32_t i, int32_t n) {
 }
 VR_HD int32_t clampi(int32_t i, int32_t lo, int32_t hi) { return i < lo ? lo : (i > hi ? hi : i); }
 
+// scale of a compact environment texel: 2^(e - 136) for e >= 10 (exponent field e - 9), 0 for e = 0
+VR_HD float rgbe_scale(uint32_t q) { const uint32_t e = q >> 24; return e ? u2f((e - 9u) << 23) : 0.0f; }
 VR_HD v3 env_texture(const SceneParams& P, float u, float v) {
     const int32_t w = P.env_w, h = P.env_h;
     const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
@@ -719,6 +721,19 @@ VR_HD v3 env_texture(const SceneParams& P, float u, float v) {
     if (ix == kIntMin || iy == kIntMin || ix > (1 << 28) || ix < -(1 << 28)) { ix = 0; iy = 0; fx = 0.0f; fy = 0.0f; }
     const int32_t x0 = wrap_repeat(ix, w), x1 = wrap_repeat(ix + 1, w);
     const int32_t y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
+    if (P.env_rgbe) {
+        // compact form (vr_scene.h SceneParams::env_rgbe): one dword per texel, decoded to the floats the float map holds -- (float)m * 2^(e - 136): an 8-bit integer
+        // times a power of two, exact; texels with e = 0 are 0, texels with 0 < e < 10 (a subnormal scale) do not occur in a map that has this form (Environment::build)
+        const uint32_t q00 = P.env_rgbe[(size_t)y0 * w + x0], q10 = P.env_rgbe[(size_t)y0 * w + x1], q01 = P.env_rgbe[(size_t)y1 * w + x0], q11 = P.env_rgbe[(size_t)y1 * w + x1];
+        VR_TRACE(3, P.env_rgbe, ((size_t)y0 * w + x0) * 4, 4); VR_TRACE(3, P.env_rgbe, ((size_t)y0 * w + x1) * 4, 4);
+        VR_TRACE(3, P.env_rgbe, ((size_t)y1 * w + x0) * 4, 4); VR_TRACE(3, P.env_rgbe, ((size_t)y1 * w + x1) * 4, 4);
+        const float s00 = rgbe_scale(q00), s10 = rgbe_scale(q10), s01 = rgbe_scale(q01), s11 = rgbe_scale(q11);
+        v3 r;
+        r.x = mix_(mix_((float)(q00 & 255u) * s00, (float)(q10 & 255u) * s10, fx), mix_((float)(q01 & 255u) * s01, (float)(q11 & 255u) * s11, fx), fy);
+        r.y = mix_(mix_((float)((q00 >> 8) & 255u) * s00, (float)((q10 >> 8) & 255u) * s10, fx), mix_((float)((q01 >> 8) & 255u) * s01, (float)((q11 >> 8) & 255u) * s11, fx), fy);
+        r.z = mix_(mix_((float)((q00 >> 16) & 255u) * s00, (float)((q10 >> 16) & 255u) * s10, fx), mix_((float)((q01 >> 16) & 255u) * s01, (float)((q11 >> 16) & 255u) * s11, fx), fy);
+        return r;
+    }
     const float* t00 = P.envmap + kEnvTexelFloats * ((size_t)y0 * w + x0);
     const float* t10 = P.envmap + kEnvTexelFloats * ((size_t)y0 * w + x1);
     const float* t01 = P.envmap + kEnvTexelFloats * ((size_t)y1 * w + x0);
