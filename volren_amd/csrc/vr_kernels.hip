@@ -241,7 +241,7 @@ impmap_base_kernel(const float* __restrict__ envmap, int32_t env_w, int32_t env_
     const int32_t px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (px >= dim || py >= dim) return;
     SceneParams P;                    // only the envmap view is used by env_texture
-    P.envmap = envmap; P.env_w = env_w; P.env_h = env_h;
+    P.envmap = envmap; P.env_rgbe = nullptr; P.env_w = env_w; P.env_h = env_h;      // (the pyramid is built from the float map: every other field stays unset)
     const int32_t ns = 8;
     const float inv_samples = 1.0f / (float)(ns * ns);
     const float oss = (float)(dim * ns);
