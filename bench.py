@@ -668,8 +668,9 @@ def main():
         import zlib
         out["fast_math"] = {"value": mf["value"], "unit": "Msamples/s", "kernel_ms": mf["kernel_ms"], "speedup": mf["value"] / m["value"],
                             "rel_l2_vs_bit_exact": rl2, "tolerance": 1e-3, "within_tolerance": bool(rl2 <= 1e-3),
-                            # the tolerance mode is deterministic too: ONE frame per (scene, frame size, spp, build) -- the c2 headline frame: 3971509483 for every
-                            # build since round 5 (tests/tools_determinism.py; test_frames_are_reproducible_on_every_compiled_instance holds every instance to it)
+                            # the tolerance mode is deterministic too: ONE frame per (scene, frame size, spp, build) -- tests/tools_determinism.py, profiles/r6_determinism.txt;
+                            # test_frames_are_reproducible_on_every_compiled_instance holds every instance to it.  (The value belongs to the build: contraction is allowed in
+                            # this mode, so a change of the arithmetic's text -- round 6: the compact environment texels -- moves it; the bit-exact frame_crc32 never moves.)
                             "frame_crc32": zlib.crc32(np.ascontiguousarray(img).tobytes()) & 0xFFFFFFFF,
                             "note": "opt-in mode (vr_set_int fast_math 1): hardware transcendentals and reciprocal-based divisions; the headline value above is the bit-exact default"}
         del bf
