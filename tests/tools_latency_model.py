@@ -18,8 +18,8 @@ wavefront: VR_BLOCKS_PER_CU) -- and the model is then CHECKED against five measu
 With the model in hand the candidates of the verdict are priced: what each could recover if it hid ALL of the latency it addresses, and at half of it.
 
 usage: python tests/tools_latency_model.py [profiles/r6a_occupancy_and_padding.txt] > profiles/r6_latency_model.txt
-Inputs: profiles/r6a_occupancy_and_padding.txt (tests/tools_r6_call1.sh on one MI355X: occupancy and padding A/B of the round's kernels), profiles/r5_pmc_summary.json
-(wave-cycle shares), profiles/r5_issue_budget.json (instructions and executions per iteration), profiles/r6_sched_stats.txt (cycles per event batch)."""
+Inputs: profiles/r6a_occupancy_and_padding.txt (tests/tools_r6_call1.sh on one MI355X: occupancy and padding A/B of the round's kernels), profiles/r6_pmc_summary.json
+(wave-cycle shares), profiles/r6_issue_budget.json (instructions and executions per iteration), profiles/r6_sched_stats.txt (cycles per event batch)."""
 import json
 import os
 import re
@@ -90,8 +90,9 @@ def read_measurements(path):
 def main():
     meas = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles/r6a_occupancy_and_padding.txt")
     occ, ab = read_measurements(meas)
-    pmc = json.load(open(os.path.join(ROOT, "profiles/r5_pmc_summary.json")))
-    bud = json.load(open(os.path.join(ROOT, "profiles/r5_issue_budget.json")))
+    newest = lambda name: next(p for p in (os.path.join(ROOT, "profiles", r + name) for r in ("r6_", "r5_")) if os.path.exists(p))
+    pmc = json.load(open(newest("pmc_summary.json")))
+    bud = json.load(open(newest("issue_budget.json")))
     # cycles per execution of the event batches and lanes (instrumented kernels of this round: profiles/r6_sched_stats.txt), per configuration
     ev = {}
     cur = None
@@ -125,7 +126,7 @@ def main():
         sh = p["wave_cycles_share"]
         print("== %s" % name)
         print("measured: %.0f Msamples/s with 4 wavefronts per SIMD = %.0f cycles per iteration of a wavefront (%.4f iterations per sample); V = %.0f vector instructions per iteration at c = %.2f cycles of the issue port each;" % (x4, T4, b["iterations_per_sample"], V, c))
-        print("          a wavefront's time by the counters (profiles/r5_pmc_summary.json): %.1f %% in vector instructions (4 V / T = %.1f %%), %.1f %% in other instructions, %.1f %% stalled at issue, %.1f %% waiting on memory" % (
+        print("          a wavefront's time by the counters (profiles/r6_pmc_summary.json): %.1f %% in vector instructions (4 V / T = %.1f %%), %.1f %% in other instructions, %.1f %% stalled at issue, %.1f %% waiting on memory" % (
             100 * sh["issuing_valu"], 100 * CPI_WAVE * V / T4, 100 * (sh["issuing"] - sh["issuing_valu"]), 100 * sh["issue_stalled"], 100 * sh["waiting_on_memory"]))
         print("fitted:   M = %.0f cycles of the shared memory path per iteration (its utilisation with 16 wavefronts per CU: %.0f %%), Z = %.0f cycles of private delay per iteration (of which %.0f are the wavefront's own 4-cycle issue cadence beyond the port's %.2f) -- residual of the fit %.4f" % (
             M, 100 * base["util_mem"], base["Z"], V * (CPI_WAVE - c), c, err))
