@@ -244,6 +244,14 @@ long long hk_render(const Uniforms* up, const hk_grid_desc* density, const hk_gr
                         live = true;
                         if (l.state == ST_NEW) for (float& v : cold[i].v) v = nan_();         // a new path must not depend on what its cold line held
                         if (g_trace && (l.state == ST_MARCH || l.state == ST_COLLIDE)) trace_access(l, P);
+#if VR_WORLD_SLOT
+                        // a build with -DVR_WORLD_SLOT=1 (tests/test_host_kernel.py::test_world_slot_*): the kernels of one scene kind that carry the experiment -- DDA trackers,
+                        // no transfer function, no emission grid (the paired atlas of the emission kernels is not built here)
+                        if (!u.use_tf && u.integrator == 0 && !u.has_emission) {
+                            if (P.density.dense) lane_step<TraceCfg<false, 0, 0, 1, 2>>(l, cold[i], P, wu, next_item, stash[i]);
+                            else lane_step<TraceCfg<false, 0, 0, 0, 2>>(l, cold[i], P, wu, next_item, stash[i]);
+                        } else
+#endif
                         if (u.use_tf) lane_step<TraceCfg<true, 2, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]); else lane_step<TraceCfg<false, 2, 2, 2, 2>>(l, cold[i], P, wu, next_item, stash[i]);
                         if (++steps > (1ll << 40)) return -1;
                     }

@@ -177,7 +177,9 @@ template <class K> constexpr int32_t pool_slots() {
 constexpr int32_t NSLOT = 192;             // upper bound of pool_slots (sizes the cold workspace); slot ids are bytes
 constexpr int32_t HOT_COL = VR_HOT_RI ? 12 : 4;         // where the transfer-function kernels keep the colour of a real collision until its event: in the place of
                                                         // 1/dir (15-dword slots) or of dir (12-dword slots) -- both dead between the collision and the set-up of the next segment
-template <int32_t HOT_STRIDE>
+// WORLD (vr_trace.h world_slot, -DVR_WORLD_SLOT=1): dwords 1..6 hold the segment's origin and direction in WORLD space (Hot::wpos / wdir) instead of the index-space
+// ones; load_resume recomputes those with begin_segment's two transforms -- so that the collision event finds position and direction in the slot and reads no cold line
+template <int32_t HOT_STRIDE, bool WORLD = false>
 struct HotStoreT {                     // [slot][field]: a path's parked dwords are adjacent (ds_read2/ds_write2 pairs)
     static constexpr int32_t kStride = HOT_STRIDE;
     uint32_t* base;
@@ -191,8 +193,9 @@ struct HotStoreT {                     // [slot][field]: a path's parked dwords 
     __device__ __forceinline__ void save_new(const Hot& h, int32_t slot) const {
         uint32_t* p = base + slot * HOT_STRIDE;
         p[0] = h.seed;
-        p[1] = f2u(h.ipos.x); p[2] = f2u(h.ipos.y); p[3] = f2u(h.ipos.z);
-        p[4] = f2u(h.idir.x); p[5] = f2u(h.idir.y); p[6] = f2u(h.idir.z);
+        const v3 a = WORLD ? h.wpos : h.ipos, d = WORLD ? h.wdir : h.idir;
+        p[1] = f2u(a.x); p[2] = f2u(a.y); p[3] = f2u(a.z);
+        p[4] = f2u(d.x); p[5] = f2u(d.y); p[6] = f2u(d.z);
         p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
         p[10] = f2u(h.Tr);
         p[11] = flags(h);
@@ -202,8 +205,14 @@ struct HotStoreT {                     // [slot][field]: a path's parked dwords 
     __device__ __forceinline__ void save(const Hot& h, int32_t slot) const {
         uint32_t* p = base + slot * HOT_STRIDE;
         p[0] = h.seed;
+        if (WORLD) {
+            p[1] = f2u(h.wpos.x); p[2] = f2u(h.wpos.y); p[3] = f2u(h.wpos.z);
+            p[4] = f2u(h.wdir.x); p[5] = f2u(h.wdir.y); p[6] = f2u(h.wdir.z);
+            if (!h.first) p[10] = f2u(h.Tr);
+        } else {
         if (!h.first) { p[1] = f2u(h.ipos.x); p[2] = f2u(h.ipos.y); p[3] = f2u(h.ipos.z); p[10] = f2u(h.Tr); }
         p[4] = f2u(h.idir.x); p[5] = f2u(h.idir.y); p[6] = f2u(h.idir.z);
+        }
         p[7] = f2u(h.t); p[8] = f2u(h.far); p[9] = f2u(h.tau);
         p[11] = flags(h);
         if (VR_HOT_RI) { p[12] = f2u(h.ri.x); p[13] = f2u(h.ri.y); p[14] = f2u(h.ri.z); }
@@ -223,6 +232,7 @@ struct HotStoreT {                     // [slot][field]: a path's parked dwords 
         h.seed = p[0];
         h.ipos = v3{ u2f(p[1]), u2f(p[2]), u2f(p[3]) };
         h.idir = v3{ u2f(p[4]), u2f(p[5]), u2f(p[6]) };
+        if (WORLD) { h.wpos = h.ipos; h.wdir = h.idir; }            // (the events read wpos / wdir; a resumed path gets its index-space ray in load_resume)
         h.ri = VR_HOT_RI ? v3{ u2f(p[12 % HOT_STRIDE]), u2f(p[13 % HOT_STRIDE]), u2f(p[14 % HOT_STRIDE]) } : v3{ 0.0f, 0.0f, 0.0f };      // events do not read it (begin_segment sets it)
         h.t = u2f(p[7]); h.far = u2f(p[8]); h.tau = u2f(p[9]);
         h.Tr = u2f(p[10]);
@@ -232,9 +242,14 @@ struct HotStoreT {                     // [slot][field]: a path's parked dwords 
         h.majorant = 0.0f;
     }
     // for marching: a `first` path gets the real values of the two fields (= first_resume, vr_trace.h)
-    __device__ __forceinline__ void load_resume(Hot& h, int32_t slot) const {
+    __device__ __forceinline__ void load_resume(Hot& h, int32_t slot, const float* inv_transform = nullptr) const {
         load(h, slot);
         const bool first = h.first != 0;
+        if (WORLD) {
+            // begin_segment's two transforms on the values it was given (inv_transform = Uniforms::vol_density_inv_transform): the same index-space ray, bit for bit
+            h.ipos = mat4_point(inv_transform, h.wpos);
+            h.idir = mat4_dir(inv_transform, h.wdir);
+        } else
         h.ipos = v3{ first ? cam_ipos[0] : h.ipos.x, first ? cam_ipos[1] : h.ipos.y, first ? cam_ipos[2] : h.ipos.z };
         h.Tr = first ? 1.0f : h.Tr;
         if (!VR_HOT_RI) h.ri = rcp3_exact(h.idir);             // as begin_segment computed it
@@ -465,7 +480,8 @@ pathtrace_kernel(const KernelArgs A) {
     constexpr bool kLazyEm = lazy_emission<K>();
     static_assert(VR_BATCH_REGS || !kLazyEm, "the VR_BATCH_REGS=0 swap path moves a marching path's radiance through its cold line: a `first` path of a lazy-emission kernel has none");
     __shared__ uint32_t lds_hot[kWgWaves * HS * NS];
-    HotStoreT<HS> hs;
+    constexpr bool kWorld = world_slot<K>();
+    HotStoreT<HS, kWorld> hs;
     hs.base = lds_hot + wave * (HS * NS);
     {   // wave-uniform: keep it in scalar registers
         const v3 ci = mat4_point(P.u.vol_density_inv_transform, v3{ P.u.cam_pos[0], P.u.cam_pos[1], P.u.cam_pos[2] });      // == first_resume
@@ -639,9 +655,9 @@ pathtrace_kernel(const KernelArgs A) {
                     if (r < take) {
 #if VR_READY_FIFO
                         int32_t p_ = rdy_head + r; p_ = p_ >= NS ? p_ - NS : p_;
-                        slot = q[Q_READY * NS + p_]; hs.load_resume(l, slot);
+                        slot = q[Q_READY * NS + p_]; hs.load_resume(l, slot, kWorld ? event_args().P.u.vol_density_inv_transform : nullptr);
 #else
-                        slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load_resume(l, slot);
+                        slot = q[Q_READY * NS + cnt_ready - 1 - r]; hs.load_resume(l, slot, kWorld ? event_args().P.u.vol_density_inv_transform : nullptr);
 #endif
                         if (emission_on && !l.shadow) {              // EmissionCache (vr_trace.h Hot): the collisions of this segment add to L
                             if (kLazyEm && l.first) { l.ethr = v3{ 1.0f, 1.0f, 1.0f }; l.eL = hs.load_first_radiance(slot); }      // no cold line yet
@@ -871,7 +887,7 @@ pathtrace_kernel(const KernelArgs A) {
                     const ColdT c = VR_COLD(b.first ? 0 : bs);
                     const KernelArgs& E = event_args();
                     WorkUnit w; w.out = E.sbuf;
-                    do_escape<ColdT, kItemInRegs, kLazyEm>(b, c, E.P, w);          // writes the sample; the slot becomes free
+                    do_escape<ColdT, kItemInRegs, kLazyEm, kWorld>(b, c, E.P, w);          // writes the sample; the slot becomes free
                 }
                 cnt_esc -= n;
                 VR_ROUTE_B(bs);                                            // ST_NEW: the slot is free again

@@ -73,6 +73,16 @@ struct TraceCfg {
     static constexpr bool maj_reuse = VR_MARCH_STEPS == 2 && (VR_MAJ_REUSE == 2 || (VR_MAJ_REUSE == 1 && MAJB == 1));
 };
 
+// VR_WORLD_SLOT (round 6, build-time experiment): a parked path keeps the WORLD origin and direction of its segment in its slot instead of the index-space ones
+// (which the resume recomputes, as begin_segment computed them), so that the collision event needs nothing from the path's cold line -- position and direction are in
+// the slot, and "throughput *= albedo" moves to the scatter event that always follows -- and reads none: one of a bounce's two cold line reads and the first dependent
+// round trip of every collision event gone, for two transforms per resume and one more sector written per bounce.  Kernels of the DDA trackers without a transfer
+// function only (a transfer function's collision colour waits in the slot's direction fields).
+#ifndef VR_WORLD_SLOT
+#define VR_WORLD_SLOT 0
+#endif
+template <class K> constexpr bool world_slot() { return VR_WORLD_SLOT != 0 && !K::tf && K::global == 0 && K::emission == 0; }      // (the emission kernels have no registers for it: 6 VGPRs spilled)
+
 // the pool of work items of one wavefront: pixel p = item & 63 of the 8x8 tile at (px0, py0), sample
 // first_sample + (item >> 6) (1-based like the reference's current_sample)
 struct WorkUnit {
@@ -93,6 +103,7 @@ VR_HD int32_t segment_end_state(int32_t shadow) { return ST_ESCAPE - shadow; }
 struct Hot {
     uint32_t seed;
     v3 ipos, idir, ri;       // index-space ray of the current segment
+    v3 wpos, wdir;           // the same segment's origin and direction in world space (begin_segment's arguments): what a parked path keeps under VR_WORLD_SLOT
     float t, far, tau, majorant, Tr;
     int32_t mipq;            // 4 * mip: the DDA level moves in quarter steps (common.glsl:433,450), kept as an integer
     int32_t shadow;          // 0: sample_volumeDDA segment, 1: transmittanceDDA segment
@@ -929,7 +940,7 @@ VR_HD float step_dda(v3 p, v3 ri, int32_t mip) {
 
 VR_HD void hot_init(Hot& h) {
     h.seed = 0u; h.item = 0u;
-    h.ipos = h.idir = h.ri = h.ethr = h.eL = h.shle = v3{ 0, 0, 0 };
+    h.ipos = h.idir = h.ri = h.ethr = h.eL = h.shle = h.wpos = h.wdir = v3{ 0, 0, 0 };
     h.t = h.far = h.tau = h.majorant = h.Tr = 0.0f;
     h.mipq = 0;
     h.shadow = 0;
@@ -965,6 +976,7 @@ VR_HD void accumulate_sample(float acc[4], const float L[4], int32_t current_sam
 // returns false when the ray misses the volume's box altogether (nothing of the segment has been set up then)
 template <class K>
 VR_HD bool begin_segment(Hot& h, const SceneParams& P, v3 pos, v3 d, int32_t shadow) {
+    h.wpos = pos; h.wdir = d;
     h.shadow = shadow;
     h.Tr = 1.0f;          // both set before the branch on purpose: conditional stores to different fields make the
     h.mipq = 12;          // mip = 3; compiler address-select between them, which forces the state into scratch memory
@@ -1352,13 +1364,24 @@ VR_HD void do_collide(Hot& h, Cold& c, const SceneParams& P) {
 template <class K, class Cold, bool SHLE_IN_HOT = false, bool ITEM_IN_HOT = false, bool FIRST_L_IN_HOT = false>
 VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     const bool first = h.first != 0;
-    v3 dir = ld3(crd, C_DIR), pos0 = ld3(crd, C_POS), thr = ld3(crd, C_THR);
-    dir = v3{ first ? h.ipos.x : dir.x, first ? h.ipos.y : dir.y, first ? h.ipos.z : dir.z };
-    pos0 = v3{ first ? P.u.cam_pos[0] : pos0.x, first ? P.u.cam_pos[1] : pos0.y, first ? P.u.cam_pos[2] : pos0.z };
-    thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
+    constexpr bool WS = world_slot<K>();
+    v3 dir, pos0, thr;
+    if (WS) {
+        // the segment's origin and direction are the path's own (begin_segment's arguments, parked with it): the values C_POS / C_DIR hold, without the line
+        dir = h.wdir; pos0 = h.wpos; thr = v3{ 1.0f, 1.0f, 1.0f };
+    } else {
+        dir = ld3(crd, C_DIR); pos0 = ld3(crd, C_POS); thr = ld3(crd, C_THR);
+        dir = v3{ first ? h.ipos.x : dir.x, first ? h.ipos.y : dir.y, first ? h.ipos.z : dir.z };
+        pos0 = v3{ first ? P.u.cam_pos[0] : pos0.x, first ? P.u.cam_pos[1] : pos0.y, first ? P.u.cam_pos[2] : pos0.z };
+        thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
+    }
     const v3 pos = axpy(pos0, h.t, dir);
     st3(c, C_POS, pos);
     // the real collision that led here: throughput *= albedo [* rgba.rgb] (common.glsl:383-388, 491-495; see collide_finish)
+    if (WS) {
+        // ... is applied by do_postnee, the event that follows every collision event and holds the line anyway; a path's first collision starts the line with throughput 1
+        if (first) st3(c, C_THR, thr);
+    } else
     {
         const v3 alb = v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };
         if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) thr = K::tf ? thr * (ld3(c, C_COL) * alb) : thr * alb;
@@ -1396,6 +1419,8 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
     v3 L = ld3(c, C_L);
     const float sh_pdf = c.ld(C_SHPDF);
     v3 thr = ld3(c, C_THR);
+    constexpr bool WS = world_slot<K>();
+    if (WS) thr = thr * v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };      // the real collision's "throughput *= albedo" (see do_nee): same operands, same product
     if (sh_pdf > 0.0f) {
         // common.glsl:620-626: L += throughput * mis * f_p * Tr * Le / pdf, the factors of the light sample do_nee drew
         const float f_p = c.ld(C_FPL);
@@ -1410,8 +1435,9 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
         const float prob = 1.0f - rr;
         if (rng(h.seed) < prob) { write_sample(wu, ITEM_IN_HOT ? h.item : ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
         thr = thr / (1.0f - prob);
-        st3(c, C_THR, thr);
+        if (!WS) st3(c, C_THR, thr);
     }
+    if (WS) st3(c, C_THR, thr);
     stu(c, C_NPATHS, n_paths);
     const v3 dir = ld3(c, C_DIR);
     const float s0 = rng(h.seed), s1 = rng(h.seed);
@@ -1424,7 +1450,7 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
 // common.glsl:644-651
 // `c` of a `first` path (never scattered: L = 0, throughput 1; direction and sample slot in the stash) is only read and the
 // values discarded: the scheduler points it at a line the batch shares (see do_nee)
-template <class Cold, bool ITEM_IN_HOT = false, bool FIRST_L_IN_HOT = false>
+template <class Cold, bool ITEM_IN_HOT = false, bool FIRST_L_IN_HOT = false, bool WS = false>
 VR_HD void do_escape(Hot& h, const Cold& c, const SceneParams& P, const WorkUnit& wu) {
     const bool first = h.first != 0;
     v3 L = ld3(c, C_L), thr = ld3(c, C_THR), dir = ld3(c, C_DIR);
@@ -1433,7 +1459,8 @@ VR_HD void do_escape(Hot& h, const Cold& c, const SceneParams& P, const WorkUnit
     const v3 L_first = FIRST_L_IN_HOT ? h.eL : v3{ 0.0f, 0.0f, 0.0f };
     L = v3{ first ? L_first.x : L.x, first ? L_first.y : L.y, first ? L_first.z : L.z };
     thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
-    dir = v3{ first ? h.ipos.x : dir.x, first ? h.ipos.y : dir.y, first ? h.ipos.z : dir.z };
+    if (WS) dir = h.wdir;        // (VR_WORLD_SLOT: the escaping segment's own direction, first path or not)
+    else dir = v3{ first ? h.ipos.x : dir.x, first ? h.ipos.y : dir.y, first ? h.ipos.z : dir.z };
     n_paths = first ? 0u : n_paths;
     item = first ? f2u(h.Tr) : item;
     h.first = 0;
@@ -1617,7 +1644,7 @@ VR_HD void lane_step(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu, 
     case ST_COLLIDE: if (seg_clean(h)) do_collide<K, Cold, true>(h, c, P); else do_collide<K, Cold, false>(h, c, P); break;
     case ST_NEE: do_nee<K>(h, c, c, P); break;
     case ST_POSTNEE: do_postnee<K>(h, c, P, wu); break;
-    case ST_ESCAPE: do_escape(h, c, P, wu); break;
+    case ST_ESCAPE: do_escape<Cold, false, false, world_slot<K>()>(h, c, P, wu); break;
     default: break;
     }
 }
