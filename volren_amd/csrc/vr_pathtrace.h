@@ -264,23 +264,28 @@ struct HotStoreT {                     // [slot][field]: a path's parked dwords 
 // pool slots it costs), profiles/r2j_layout_experiments.txt, r2m_cold_state_in_lds_experiments.txt.
 constexpr uint32_t kStatsWaveBase = 32u;                 // statistics buffer: 32 counters, then (begin, queue empty, end) per wavefront of the launch
 constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state workspace is sized for this many resident 4-wavefront units = 8192 wavefronts (launch_pathtrace clamps the grid to it)
-struct ColdGlobal {
+// SWAP (the kernels with VR_WORLD_SLOT, vr_trace.h world_slot): throughput and direction trade places in the slot -- sector 0 = (pos, sh_pdf, dir, f_p of the light
+// sample), sector 1 = (L, n_paths, thr, f_p) -- because those kernels' collision event writes pos, sh_pdf, ITS segment's direction and f_pl and reads nothing, and
+// their scatter event writes L, n_paths, thr, f_p: every event dirties exactly ONE 32-byte sector (do_nee / do_postnee, vr_trace.h)
+template <bool SWAP = false>
+struct ColdGlobalT {
+    static __device__ __forceinline__ constexpr int32_t phys(int32_t f) { return !SWAP ? f : ((f >= C_THR && f < C_THR + 3) ? f + (C_DIR - C_THR) : ((f >= C_DIR && f < C_DIR + 3) ? f - (C_DIR - C_THR) : f)); }
     float* base;                       // this slot's 16 floats in the wavefront's slice of the main array
     float* side;                       // this slot's 4 floats in the wavefront's slice of the side array
     float* col;                        // C_COL: the three dwords of the path's parked hot state (LDS) that hold 1/dir -- dead between a real collision and
                                        // the event that follows it, which is when the transfer-function kernels keep the collision's colour there
     __device__ __forceinline__ float ld(int32_t f) const {     // f is a compile-time constant at every call: the selection folds
         return f >= C_COL ? col[f - C_COL]
-             : f < C_SIDE ? static_cast<const float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[f]
+             : f < C_SIDE ? static_cast<const float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[phys(f)]
                           : static_cast<const float*>(__builtin_assume_aligned(side, C_SIDE_STRIDE * 4))[f - C_SIDE];
     }
     __device__ __forceinline__ void st(int32_t f, float v) {
         if (f >= C_COL) col[f - C_COL] = v;
-        else if (f < C_SIDE) static_cast<float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[f] = v;
+        else if (f < C_SIDE) static_cast<float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[phys(f)] = v;
         else static_cast<float*>(__builtin_assume_aligned(side, C_SIDE_STRIDE * 4))[f - C_SIDE] = v;
     }
 };
-typedef ColdGlobal ColdT;
+typedef ColdGlobalT<false> ColdGlobal;
 constexpr int32_t kColdWaveFloats = C_STRIDE * NSLOT, kColdSideWaveFloats = C_SIDE_STRIDE * NSLOT;
 constexpr size_t kColdMainFloats = (size_t)kMaxWorkgroups * 4u * (size_t)kColdWaveFloats;       // the side arrays follow the main arrays of all wavefronts
 
@@ -452,6 +457,7 @@ pathtrace_kernel(const KernelArgs A) {
     const uint32_t wave_index = blockIdx.x * (uint32_t)kWgWaves + (uint32_t)wave;
     float* const cold_base = A.cold_ws + (size_t)wave_index * (size_t)kColdWaveFloats;
     float* const side_base = A.cold_ws + kColdMainFloats + (size_t)wave_index * (size_t)kColdSideWaveFloats;
+    typedef ColdGlobalT<world_slot<K>()> ColdT;
 #define VR_COLD(SLOT) ColdT{ cold_base + (SLOT) * C_STRIDE, side_base + (SLOT) * C_SIDE_STRIDE, reinterpret_cast<float*>(hs.base + (SLOT) * HS + HOT_COL) }
     // where the radiance of a parked path's pending light sample waits: vector registers (ShleBanks), or -- in the transfer-function
     // variants, which have no registers to spare (126 of 128) -- the side array

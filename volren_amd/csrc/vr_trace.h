@@ -79,9 +79,12 @@ struct TraceCfg {
 // round trip of every collision event gone, for two transforms per resume and one more sector written per bounce.  Kernels of the DDA trackers without a transfer
 // function only (a transfer function's collision colour waits in the slot's direction fields).
 #ifndef VR_WORLD_SLOT
-#define VR_WORLD_SLOT 0
+#define VR_WORLD_SLOT 1
 #endif
-template <class K> constexpr bool world_slot() { return VR_WORLD_SLOT != 0 && !K::tf && K::global == 0 && K::emission == 0; }      // (the emission kernels have no registers for it: 6 VGPRs spilled)
+#ifndef VR_WORLD_SLOT_EMISSION
+#define VR_WORLD_SLOT_EMISSION 0     /* the emission kernels (127 vector registers as they are) spill 6 of them with it: measured separately (profiles/r6g_*) */
+#endif
+template <class K> constexpr bool world_slot() { return VR_WORLD_SLOT != 0 && !K::tf && K::global == 0 && (K::emission == 0 || VR_WORLD_SLOT_EMISSION != 0); }
 
 // the pool of work items of one wavefront: pixel p = item & 63 of the 8x8 tile at (px0, py0), sample
 // first_sample + (item >> 6) (1-based like the reference's current_sample)
@@ -1381,6 +1384,9 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     if (WS) {
         // ... is applied by do_postnee, the event that follows every collision event and holds the line anyway; a path's first collision starts the line with throughput 1
         if (first) st3(c, C_THR, thr);
+        // and the direction the scatter event samples the phase function around -- this segment's -- is written here, next to pos / sh_pdf / f_pl: with the slot's
+        // swapped layout (vr_pathtrace.h ColdGlobalT) this event dirties sector 0 only and the scatter event sector 1 only
+        st3(c, C_DIR, dir);
     } else
     {
         const v3 alb = v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };
@@ -1390,7 +1396,8 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     }
     if (first) {
         // what do_new left unwritten
-        st3(c, C_DIR, dir); stu(c, C_NPATHS, 0u);
+        if (!WS) st3(c, C_DIR, dir);
+        stu(c, C_NPATHS, 0u);
         st3(c, C_L, FIRST_L_IN_HOT ? h.eL : v3{ 0, 0, 0 });
         if (!ITEM_IN_HOT) stu(c, C_ITEM, f2u(h.Tr));       // else the scheduler takes it from the stash (h.Tr) before this call
         c.st(C_FP, 0.0f);
@@ -1443,7 +1450,7 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
     const float s0 = rng(h.seed), s1 = rng(h.seed);
     const v3 sd = sample_phase_hg(dir, P.u.vol_phase_g, s0, s1);
     c.st(C_FP, phase_hg(dot(-dir, sd), P.u.vol_phase_g));
-    st3(c, C_DIR, sd);
+    if (!WS) st3(c, C_DIR, sd);      // (VR_WORLD_SLOT: the next collision event writes its segment's direction itself, an escape reads it from the path's slot)
     begin_segment<K>(h, P, ld3(c, C_POS), sd, 0);
 }
 
