@@ -120,12 +120,16 @@ def main():
         secs = b["sections"]
         passes = secs["march"]["executions_per_iteration"]                    # passes of the hot pair per iteration
         x4 = occ[key_occ][4]
-        T4 = 4.0 * 1024 * 2.4e9 / (x4 * 1e6 * b["iterations_per_sample"])     # cycles per iteration of ONE wavefront: 1024 SIMDs x 2.4 GHz / (wavefront-iterations per second), 4 wavefronts per SIMD
+        # cycles per iteration of ONE wavefront = 4 wavefronts per SIMD x SIMD cycles per sample / iterations per sample.  The absolute rate is the bench line's (whole
+        # frames at the configuration's sample count: what the counters were taken on); the short runs of the occupancy / padding A/B (64-256 spp: more of a launch is
+        # ramp and drain) only contribute RATIOS
+        x_abs = 1024 * 2.4e3 / b["simd_cycles_per_sample"] if "simd_cycles_per_sample" in b else x4
+        T4 = 4.0 * 1024 * 2.4e9 / (x_abs * 1e6 * b["iterations_per_sample"])
         M, Z, err = fit(V, c, occ[key_occ][3] / x4, T4)
         base = mva(V, c, M, Z, 4)
         sh = p["wave_cycles_share"]
         print("== %s" % name)
-        print("measured: %.0f Msamples/s with 4 wavefronts per SIMD = %.0f cycles per iteration of a wavefront (%.4f iterations per sample); V = %.0f vector instructions per iteration at c = %.2f cycles of the issue port each;" % (x4, T4, b["iterations_per_sample"], V, c))
+        print("measured: %.0f Msamples/s with 4 wavefronts per SIMD (bench line; %.0f in the A/B's short launches) = %.0f cycles per iteration of a wavefront (%.4f iterations per sample); V = %.0f vector instructions per iteration at c = %.2f cycles of the issue port each;" % (x_abs, x4, T4, b["iterations_per_sample"], V, c))
         print("          a wavefront's time by the counters (profiles/r6_pmc_summary.json): %.1f %% in vector instructions (4 V / T = %.1f %%), %.1f %% in other instructions, %.1f %% stalled at issue, %.1f %% waiting on memory" % (
             100 * sh["issuing_valu"], 100 * CPI_WAVE * V / T4, 100 * (sh["issuing"] - sh["issuing_valu"]), 100 * sh["issue_stalled"], 100 * sh["waiting_on_memory"]))
         print("fitted:   M = %.0f cycles of the shared memory path per iteration (its utilisation with 16 wavefronts per CU: %.0f %%), Z = %.0f cycles of private delay per iteration (of which %.0f are the wavefront's own 4-cycle issue cadence beyond the port's %.2f) -- residual of the fit %.4f" % (
