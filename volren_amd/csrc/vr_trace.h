@@ -133,6 +133,8 @@ struct Hot {
 // the box) never touches one, and the first scatter event writes the line without having to read it: for the bench scene
 // 0.7 line fetches and 0.7 partial line writes fewer per sample, from memory that sits beyond the L2.
 // On the GPU the stash is the parked path's LDS slot (HotStore, vr_pathtrace.h); the host harness keeps it in a FirstStash.
+// (Kernels with VR_WORLD_SLOT keep every path's world direction in its slot anyway -- Hot::wdir -- and their events read it from there, first path or not: for them the
+// stash is the sample slot in Tr alone.)
 struct FirstStash { v3 dir; uint32_t item; };
 // Cold: path state that only the rare events (new sample, scatter, escape) read or write.  On the GPU it is parked
 // in LDS ([field][lane] dwords, conflict-free) so that it does not occupy registers while the lane marches; the
