@@ -18,7 +18,7 @@ wavefront: VR_BLOCKS_PER_CU) -- and the model is then CHECKED against five measu
 With the model in hand the candidates of the verdict are priced: what each could recover if it hid ALL of the latency it addresses, and at half of it.
 
 usage: python tests/tools_latency_model.py [profiles/r6a_occupancy_and_padding.txt] > profiles/r6_latency_model.txt
-Inputs: profiles/r6a_occupancy_and_padding.txt (tests/tools_r6_call1.sh on one MI355X: occupancy and padding A/B of the round's kernels), profiles/r6_pmc_summary.json
+Inputs: profiles/r6a_occupancy_and_padding.txt (tests/tools_r6_runs.sh call1 on one MI355X: occupancy and padding A/B of the round's kernels), profiles/r6_pmc_summary.json
 (wave-cycle shares), profiles/r6_issue_budget.json (instructions and executions per iteration), profiles/r6_sched_stats.txt (cycles per event batch)."""
 import json
 import os
