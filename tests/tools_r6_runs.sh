@@ -235,7 +235,14 @@ for c in d['configs']: print(c['name'], c.get('value'), c.get('roofline',{}).get
 bash tests/tools_collect_profiles.sh bench 2>&1 | tail -2
 }
 
+# GPU call 12: non-temporal stores for the cold slots and / or the sample pool on the final kernels (with the world slot nobody reads a cold sector back from the L2)
+call12() {
+O=gpurun_out/r6l; mkdir -p $O
+AB_CASES="c2:1024:256 c4:512:1024:64 c4:512:1920x1080:32" bash tests/tools_ab.sh default coldnt snt coldnt_snt > $O/ab_nt.txt 2>&1
+grep "^==" $O/ab_nt.txt
+}
+
 case "$1" in
-  call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check) "$1" ;;
-  *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check}"; exit 2 ;;
+  call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12) "$1" ;;
+  *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12}"; exit 2 ;;
 esac

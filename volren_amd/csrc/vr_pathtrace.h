@@ -267,6 +267,9 @@ constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state worksp
 // SWAP (the kernels with VR_WORLD_SLOT, vr_trace.h world_slot): throughput and direction trade places in the slot -- sector 0 = (pos, sh_pdf, dir, f_p of the light
 // sample), sector 1 = (L, n_paths, thr, f_p) -- because those kernels' collision event writes pos, sh_pdf, ITS segment's direction and f_pl and reads nothing, and
 // their scatter event writes L, n_paths, thr, f_p: every event dirties exactly ONE 32-byte sector (do_nee / do_postnee, vr_trace.h)
+#ifndef VR_COLD_NT_STORES
+#define VR_COLD_NT_STORES 0
+#endif
 template <bool SWAP = false>
 struct ColdGlobalT {
     static __device__ __forceinline__ constexpr int32_t phys(int32_t f) { return !SWAP ? f : ((f >= C_THR && f < C_THR + 3) ? f + (C_DIR - C_THR) : ((f >= C_DIR && f < C_DIR + 3) ? f - (C_DIR - C_THR) : f)); }
@@ -281,7 +284,12 @@ struct ColdGlobalT {
     }
     __device__ __forceinline__ void st(int32_t f, float v) {
         if (f >= C_COL) col[f - C_COL] = v;
+#if VR_COLD_NT_STORES
+        // build-time experiment (round 6): the cold slot's stores as non-temporal ones -- with VR_WORLD_SLOT nobody reads a sector back before it has left the L2 anyway
+        else if (f < C_SIDE) __builtin_nontemporal_store(v, static_cast<float*>(__builtin_assume_aligned(base, C_STRIDE * 4)) + phys(f));
+#else
         else if (f < C_SIDE) static_cast<float*>(__builtin_assume_aligned(base, C_STRIDE * 4))[phys(f)] = v;
+#endif
         else static_cast<float*>(__builtin_assume_aligned(side, C_SIDE_STRIDE * 4))[f - C_SIDE] = v;
     }
 };
