@@ -242,7 +242,17 @@ AB_CASES="c2:1024:256 c4:512:1024:64 c4:512:1920x1080:32" bash tests/tools_ab.sh
 grep "^==" $O/ab_nt.txt
 }
 
+# GPU call 13: the events' cold stores as full sectors (two dwordx4 per event, unconditional) + non-temporal sample stores by default: the suite, then the A/B against the
+# library before both (prev) and with the store change only (nosnt)
+call13() {
+O=gpurun_out/r6m; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" | tee -a $O/summary.txt
+tail -n 4 $O/pytest.log | tee -a $O/summary.txt
+AB_CASES="c2:1024:256 c4:512:1024:64 c4:512:1920x1080:32" bash tests/tools_ab.sh prev nosnt default > $O/ab.txt 2>&1
+grep "^==" $O/ab.txt | tee -a $O/summary.txt
+}
+
 case "$1" in
-  call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12) "$1" ;;
-  *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12}"; exit 2 ;;
+  call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13) "$1" ;;
+  *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13}"; exit 2 ;;
 esac

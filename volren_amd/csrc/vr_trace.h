@@ -954,10 +954,15 @@ VR_HD void hot_init(Hot& h) {
     h.maj_idx = -2; h.maj_raw = 0u;
 }
 
+// VR_SAMPLE_NT (default since round 6): the per-sample radiance is written once and read once, by the accumulation pass, long after it has left the L2: a non-temporal
+// store.  Round 4 measured +0.2 ... +0.5 % ("within the noise"), round 6 on the final kernels c2 +0.8 / +1.2 %, c4 +0.4 / +0.9 % in two rounds (profiles/r6h_*)
+#ifndef VR_SAMPLE_NT
+#define VR_SAMPLE_NT 1
+#endif
 // result of trace_path: vec4(L, clamp(n_paths, 0, 1)) -> the item's slot of the sample buffer
 VR_HD void write_sample(const WorkUnit& wu, uint32_t item, v3 L, uint32_t n_paths) {
     float* o = wu.out + 4u * (size_t)item;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(VR_SAMPLE_NT)
+#if defined(__HIP_DEVICE_COMPILE__) && VR_SAMPLE_NT
     // build-time experiment (profiles/r4d_*): the sample pool is written once and read once by the accumulation pass -- non-temporal stores
     typedef float vr_f4 __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(vr_f4{ L.x, L.y, L.z, n_paths > 0u ? 1.0f : 0.0f }, reinterpret_cast<vr_f4*>(o));
@@ -1381,14 +1386,13 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
         thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
     }
     const v3 pos = axpy(pos0, h.t, dir);
-    st3(c, C_POS, pos);
+    if (!WS) st3(c, C_POS, pos);
     // the real collision that led here: throughput *= albedo [* rgba.rgb] (common.glsl:383-388, 491-495; see collide_finish)
     if (WS) {
         // ... is applied by do_postnee, the event that follows every collision event and holds the line anyway; a path's first collision starts the line with throughput 1
         if (first) st3(c, C_THR, thr);
-        // and the direction the scatter event samples the phase function around -- this segment's -- is written here, next to pos / sh_pdf / f_pl: with the slot's
-        // swapped layout (vr_pathtrace.h ColdGlobalT) this event dirties sector 0 only and the scatter event sector 1 only
-        st3(c, C_DIR, dir);
+        // (pos, sh_pdf) and (this segment's direction, f_pl) are written at the end, unconditionally and side by side: two 16-byte stores that fill sector 0 of the slot's
+        // swapped layout (vr_pathtrace.h ColdGlobalT) -- this event dirties sector 0 only, the scatter event sector 1 only
     } else
     {
         const v3 alb = v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };
@@ -1409,6 +1413,21 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     float pdf;
     v3 w_i, Le;
     sample_environment<K::global != 2, K::global != 2>(P, r0, r1, w_i, Le, pdf);      // (the kernels of one scene kind; the run-time variant loads record by record and divides in full)
+    if (WS) {
+        const bool lit = pdf > 0.0f;                                   // (false for NaN: "no next-event estimate", sh_pdf = 0 for do_postnee)
+        const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);   // (evaluated for every lane: its value is only used where lit)
+        st3(c, C_POS, pos); c.st(C_SHPDF, lit ? pdf : 0.0f);
+        st3(c, C_DIR, dir); c.st(C_FPL, lit ? f_p : 0.0f);
+        if (lit) {
+            if (SHLE_IN_HOT) h.shle = Le; else st3(c, C_SHLE, Le);
+            begin_segment<K>(h, P, pos, w_i, 1);
+        } else {
+            h.wpos = pos;                                              // (do_postnee takes the collision point from the cold line either way; kept consistent)
+            h.shadow = 0;
+            h.state = ST_POSTNEE;
+        }
+        return;
+    }
     c.st(C_SHPDF, pdf);
     if (pdf > 0.0f) {
         const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
@@ -1435,7 +1454,7 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
         const float f_p = c.ld(C_FPL);
         const float mis = P.u.show_environment > 0 ? power_heuristic(sh_pdf, f_p) : 1.0f;
         L = L + ((((thr * mis) * f_p) * h.Tr) * (SHLE_IN_HOT ? h.shle : ld3(c, C_SHLE))) / sh_pdf;
-        st3(c, C_L, L);
+        if (!WS) st3(c, C_L, L);         // (VR_WORLD_SLOT: sector 1 is written once, at the end, by the paths that go on)
     }
     const uint32_t n_paths = ldu(c, C_NPATHS) + 1u;
     if (n_paths >= (uint32_t)P.u.bounces) { write_sample(wu, ITEM_IN_HOT ? h.item : ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
@@ -1446,13 +1465,19 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
         thr = thr / (1.0f - prob);
         if (!WS) st3(c, C_THR, thr);
     }
-    if (WS) st3(c, C_THR, thr);
-    stu(c, C_NPATHS, n_paths);
+    if (!WS) stu(c, C_NPATHS, n_paths);
     const v3 dir = ld3(c, C_DIR);
     const float s0 = rng(h.seed), s1 = rng(h.seed);
     const v3 sd = sample_phase_hg(dir, P.u.vol_phase_g, s0, s1);
-    c.st(C_FP, phase_hg(dot(-dir, sd), P.u.vol_phase_g));
-    if (!WS) st3(c, C_DIR, sd);      // (VR_WORLD_SLOT: the next collision event writes its segment's direction itself, an escape reads it from the path's slot)
+    const float f_p_next = phase_hg(dot(-dir, sd), P.u.vol_phase_g);
+    if (WS) {
+        // (L, n_paths) and (thr, f_p): two 16-byte stores that fill sector 1; the next collision event writes its segment's direction itself, an escape reads it from the path's slot
+        st3(c, C_L, L); stu(c, C_NPATHS, n_paths);
+        st3(c, C_THR, thr); c.st(C_FP, f_p_next);
+    } else {
+        c.st(C_FP, f_p_next);
+        st3(c, C_DIR, sd);
+    }
     begin_segment<K>(h, P, ld3(c, C_POS), sd, 0);
 }
 
