@@ -1386,7 +1386,6 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
         thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
     }
     const v3 pos = axpy(pos0, h.t, dir);
-    if (!WS) st3(c, C_POS, pos);
     // the real collision that led here: throughput *= albedo [* rgba.rgb] (common.glsl:383-388, 491-495; see collide_finish)
     if (WS) {
         // ... is applied by do_postnee, the event that follows every collision event and holds the line anyway; a path's first collision starts the line with throughput 1
@@ -1398,7 +1397,7 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
         const v3 alb = v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };
         if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) thr = K::tf ? thr * (ld3(c, C_COL) * alb) : thr * alb;
         else { thr = thr * alb; if (K::tf) thr = thr * ld3(c, C_COL); }
-        st3(c, C_THR, thr);
+        // (pos, sh_pdf) and (thr, f_pl) are written at the end, as two 16-byte stores that fill sector 0 (profiles/r6i_*)
     }
     if (first) {
         // what do_new left unwritten
@@ -1428,14 +1427,14 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
         }
         return;
     }
-    c.st(C_SHPDF, pdf);
-    if (pdf > 0.0f) {
-        const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);
-        c.st(C_FPL, f_p);               // with sh_pdf and thr: what do_postnee needs for the sample's weight (thr * mis) * f_p
+    const bool lit = pdf > 0.0f;                                       // (false for NaN; sh_pdf = 0 marks "no next-event estimate" for do_postnee)
+    const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);       // with sh_pdf and thr: what do_postnee needs for the sample's weight (thr * mis) * f_p
+    st3(c, C_POS, pos); c.st(C_SHPDF, lit ? pdf : 0.0f);
+    st3(c, C_THR, thr); c.st(C_FPL, lit ? f_p : 0.0f);
+    if (lit) {
         if (SHLE_IN_HOT) h.shle = Le; else st3(c, C_SHLE, Le);
         begin_segment<K>(h, P, pos, w_i, 1);
     } else {
-        c.st(C_SHPDF, 0.0f);           // marks "no next-event estimate" for do_postnee (pdf <= 0 or NaN)
         h.shadow = 0;
         h.state = ST_POSTNEE;
     }
@@ -1449,13 +1448,13 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
     v3 thr = ld3(c, C_THR);
     constexpr bool WS = world_slot<K>();
     if (WS) thr = thr * v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };      // the real collision's "throughput *= albedo" (see do_nee): same operands, same product
+    const float fpl_kept = c.ld(C_FPL);
     if (sh_pdf > 0.0f) {
         // common.glsl:620-626: L += throughput * mis * f_p * Tr * Le / pdf, the factors of the light sample do_nee drew
-        const float f_p = c.ld(C_FPL);
+        const float f_p = fpl_kept;
         const float mis = P.u.show_environment > 0 ? power_heuristic(sh_pdf, f_p) : 1.0f;
         L = L + ((((thr * mis) * f_p) * h.Tr) * (SHLE_IN_HOT ? h.shle : ld3(c, C_SHLE))) / sh_pdf;
-        if (!WS) st3(c, C_L, L);         // (VR_WORLD_SLOT: sector 1 is written once, at the end, by the paths that go on)
-    }
+    }                                    // (sector 1 is written once, at the end, by the paths that go on)
     const uint32_t n_paths = ldu(c, C_NPATHS) + 1u;
     if (n_paths >= (uint32_t)P.u.bounces) { write_sample(wu, ITEM_IN_HOT ? h.item : ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
     const float rr = luma(thr);
@@ -1463,9 +1462,8 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
         const float prob = 1.0f - rr;
         if (rng(h.seed) < prob) { write_sample(wu, ITEM_IN_HOT ? h.item : ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
         thr = thr / (1.0f - prob);
-        if (!WS) st3(c, C_THR, thr);
+        if (!WS) { st3(c, C_THR, thr); c.st(C_FPL, fpl_kept); }       // (16 bytes; only after a roulette: the one write of this event to sector 0)
     }
-    if (!WS) stu(c, C_NPATHS, n_paths);
     const v3 dir = ld3(c, C_DIR);
     const float s0 = rng(h.seed), s1 = rng(h.seed);
     const v3 sd = sample_phase_hg(dir, P.u.vol_phase_g, s0, s1);
@@ -1475,8 +1473,8 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
         st3(c, C_L, L); stu(c, C_NPATHS, n_paths);
         st3(c, C_THR, thr); c.st(C_FP, f_p_next);
     } else {
-        c.st(C_FP, f_p_next);
-        st3(c, C_DIR, sd);
+        st3(c, C_L, L); stu(c, C_NPATHS, n_paths);
+        st3(c, C_DIR, sd); c.st(C_FP, f_p_next);
     }
     begin_segment<K>(h, P, ld3(c, C_POS), sd, 0);
 }
