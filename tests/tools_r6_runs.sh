@@ -261,7 +261,16 @@ AB_CASES="c3:1024:256 c5full:512:2048:8 c5cloud:512:2048:8 c5full:512:1024:32" b
 grep "^==" $O/ab.txt | tee -a $O/summary.txt
 }
 
+# the scatter event's loads as four 16-byte loads issued together: preq = the build before, head = before the full-sector stores of call14
+call15() {
+O=gpurun_out/r6o; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" | tee -a $O/summary.txt
+tail -n 4 $O/pytest.log | tee -a $O/summary.txt
+AB_CASES="c2:1024:256 c3:1024:256 c4:512:1024:64 c5full:512:2048:8 c5cloud:512:2048:8" bash tests/tools_ab.sh preq default > $O/ab.txt 2>&1
+grep "^==" $O/ab.txt | tee -a $O/summary.txt
+}
+
 case "$1" in
-  call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14) "$1" ;;
-  *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14}"; exit 2 ;;
+  call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15) "$1" ;;
+  *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15}"; exit 2 ;;
 esac

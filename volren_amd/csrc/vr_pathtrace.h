@@ -294,6 +294,16 @@ struct ColdGlobalT {
     }
 };
 typedef ColdGlobalT<false> ColdGlobal;
+// vr_trace.h ld4 for a slot in memory: one 16-byte load when the four fields are one aligned group of the (physical) layout -- the arguments are constants at every call
+template <bool SWAP>
+__device__ __forceinline__ Quad ld4(const ColdGlobalT<SWAP>& c, int32_t f3, int32_t f1) {
+    const int32_t p3 = ColdGlobalT<SWAP>::phys(f3), p1 = ColdGlobalT<SWAP>::phys(f1);
+    if (f3 + 2 < C_SIDE && f1 < C_SIDE && (p3 & 3) == 0 && p1 == p3 + 3 && ColdGlobalT<SWAP>::phys(f3 + 2) == p3 + 2) {
+        const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(__builtin_assume_aligned(c.base, C_STRIDE * 4)) + p3);
+        return Quad{ v3{ v.x, v.y, v.z }, v.w };
+    }
+    return Quad{ ld3(c, f3), c.ld(f1) };
+}
 constexpr int32_t kColdWaveFloats = C_STRIDE * NSLOT, kColdSideWaveFloats = C_SIDE_STRIDE * NSLOT;
 constexpr size_t kColdMainFloats = (size_t)kMaxWorkgroups * 4u * (size_t)kColdWaveFloats;       // the side arrays follow the main arrays of all wavefronts
 

@@ -158,6 +158,9 @@ enum ColdField : int32_t {
 template <class Cold> VR_HD v3 ld3(const Cold& c, int32_t f) { return v3{ c.ld(f), c.ld(f + 1), c.ld(f + 2) }; }
 template <class Cold> VR_HD void st3(Cold& c, int32_t f, v3 v) { c.st(f, v.x); c.st(f + 1, v.y); c.st(f + 2, v.z); }
 template <class Cold> VR_HD uint32_t ldu(const Cold& c, int32_t f) { return f2u(c.ld(f)); }
+// three fields and a fourth that share 16 bytes of the slot: ONE load where the slot is in memory (vr_pathtrace.h overloads this for its global-memory slots)
+struct Quad { v3 a; float b; };
+template <class Cold> VR_HD Quad ld4(const Cold& c, int32_t f3, int32_t f1) { return Quad{ ld3(c, f3), c.ld(f1) }; }
 template <class Cold> VR_HD void stu(Cold& c, int32_t f, uint32_t v) { c.st(f, u2f(v)); }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1401,11 +1404,10 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     }
     if (first) {
         // what do_new left unwritten
+        st3(c, C_L, FIRST_L_IN_HOT ? h.eL : v3{ 0, 0, 0 }); stu(c, C_NPATHS, 0u);      // (in the order of the layout: two 16-byte stores)
         if (!WS) st3(c, C_DIR, dir);
-        stu(c, C_NPATHS, 0u);
-        st3(c, C_L, FIRST_L_IN_HOT ? h.eL : v3{ 0, 0, 0 });
-        if (!ITEM_IN_HOT) stu(c, C_ITEM, f2u(h.Tr));       // else the scheduler takes it from the stash (h.Tr) before this call
         c.st(C_FP, 0.0f);
+        if (!ITEM_IN_HOT) stu(c, C_ITEM, f2u(h.Tr));       // else the scheduler takes it from the stash (h.Tr) before this call
     }
     h.first = 0;
     const float r0 = rng(h.seed), r1 = rng(h.seed);
@@ -1443,19 +1445,23 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
 // common.glsl:625-641, then the head of the next sample_volumeDDA call
 template <class K, class Cold, bool SHLE_IN_HOT = false, bool ITEM_IN_HOT = false>
 VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
-    v3 L = ld3(c, C_L);
-    const float sh_pdf = c.ld(C_SHPDF);
-    v3 thr = ld3(c, C_THR);
+    // the whole slot, as the four 16-byte groups its layout puts side by side (with VR_WORLD_SLOT: thr and dir swapped, vr_pathtrace.h ColdGlobalT): four loads,
+    // all in flight at once (round 6; before: seven, the last two -- dir, pos -- issued only after the roulette)
     constexpr bool WS = world_slot<K>();
+    const Quad q_l = ld4(c, C_L, C_NPATHS), q_p = ld4(c, C_POS, C_SHPDF);
+    const Quad q_t = ld4(c, C_THR, WS ? C_FP : C_FPL), q_d = ld4(c, C_DIR, WS ? C_FPL : C_FP);
+    v3 L = q_l.a;
+    const float sh_pdf = q_p.b;
+    v3 thr = q_t.a;
     if (WS) thr = thr * v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };      // the real collision's "throughput *= albedo" (see do_nee): same operands, same product
-    const float fpl_kept = c.ld(C_FPL);
+    const float fpl_kept = WS ? q_d.b : q_t.b;
     if (sh_pdf > 0.0f) {
         // common.glsl:620-626: L += throughput * mis * f_p * Tr * Le / pdf, the factors of the light sample do_nee drew
         const float f_p = fpl_kept;
         const float mis = P.u.show_environment > 0 ? power_heuristic(sh_pdf, f_p) : 1.0f;
         L = L + ((((thr * mis) * f_p) * h.Tr) * (SHLE_IN_HOT ? h.shle : ld3(c, C_SHLE))) / sh_pdf;
     }                                    // (sector 1 is written once, at the end, by the paths that go on)
-    const uint32_t n_paths = ldu(c, C_NPATHS) + 1u;
+    const uint32_t n_paths = f2u(q_l.b) + 1u;
     if (n_paths >= (uint32_t)P.u.bounces) { write_sample(wu, ITEM_IN_HOT ? h.item : ldu(c, C_ITEM), L, n_paths); h.state = ST_NEW; return; }
     const float rr = luma(thr);
     if (rr < 0.1f) {
@@ -1464,7 +1470,7 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
         thr = thr / (1.0f - prob);
         if (!WS) { st3(c, C_THR, thr); c.st(C_FPL, fpl_kept); }       // (16 bytes; only after a roulette: the one write of this event to sector 0)
     }
-    const v3 dir = ld3(c, C_DIR);
+    const v3 dir = q_d.a;
     const float s0 = rng(h.seed), s1 = rng(h.seed);
     const v3 sd = sample_phase_hg(dir, P.u.vol_phase_g, s0, s1);
     const float f_p_next = phase_hg(dot(-dir, sd), P.u.vol_phase_g);
@@ -1476,7 +1482,7 @@ VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu)
         st3(c, C_L, L); stu(c, C_NPATHS, n_paths);
         st3(c, C_DIR, sd); c.st(C_FP, f_p_next);
     }
-    begin_segment<K>(h, P, ld3(c, C_POS), sd, 0);
+    begin_segment<K>(h, P, q_p.a, sd, 0);
 }
 
 // common.glsl:644-651
