@@ -270,7 +270,16 @@ AB_CASES="c2:1024:256 c3:1024:256 c4:512:1024:64 c5full:512:2048:8 c5cloud:512:2
 grep "^==" $O/ab.txt | tee -a $O/summary.txt
 }
 
+# environment lookups with fewer loads (a row's two texels as one 8-byte load; the last warp record with its texels' importances): head2 = the commit before
+call16() {
+O=gpurun_out/r6p; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" | tee -a $O/summary.txt
+tail -n 4 $O/pytest.log | tee -a $O/summary.txt
+AB_CASES="c2:1024:256 c3:1024:256 c4:512:1024:64 c5full:512:2048:8 c5cloud:512:2048:8" bash tests/tools_ab.sh head2 default > $O/ab.txt 2>&1
+grep "^==" $O/ab.txt | tee -a $O/summary.txt
+}
+
 case "$1" in
-  call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15) "$1" ;;
-  *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15}"; exit 2 ;;
+  call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15|call16) "$1" ;;
+  *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15|call16}"; exit 2 ;;
 esac

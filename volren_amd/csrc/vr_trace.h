@@ -730,6 +730,26 @@ VR_HD int32_t wrap_repeat(int32_t i, int32_t n) {
 }
 VR_HD int32_t clampi(int32_t i, int32_t lo, int32_t hi) { return i < lo ? lo : (i > hi ? hi : i); }
 
+// two consecutive dwords (4-byte aligned) as one load
+VR_HD void ld_pair(const uint32_t* p, uint32_t& a, uint32_t& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t Pair __attribute__((ext_vector_type(2), aligned(4)));
+    const Pair v = *reinterpret_cast<const Pair*>(p);
+    a = v.x; b = v.y;
+#else
+    a = p[0]; b = p[1];
+#endif
+}
+// four consecutive floats (4-byte aligned) as one load
+VR_HD void ld_quad(const float* p, float out[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float Quad4 __attribute__((ext_vector_type(4), aligned(4)));
+    const Quad4 v = *reinterpret_cast<const Quad4*>(p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+#else
+    out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = p[3];
+#endif
+}
 // scale of a compact environment texel: 2^(e - 136) for e >= 10 (exponent field e - 9), 0 for e = 0
 VR_HD float rgbe_scale(uint32_t q) { const uint32_t e = q >> 24; return e ? u2f((e - 9u) << 23) : 0.0f; }
 VR_HD v3 env_texture(const SceneParams& P, float u, float v) {
@@ -743,7 +763,15 @@ VR_HD v3 env_texture(const SceneParams& P, float u, float v) {
     if (P.env_rgbe) {
         // compact form (vr_scene.h SceneParams::env_rgbe): one dword per texel, decoded to the floats the float map holds -- (float)m * 2^(e - 136): an 8-bit integer
         // times a power of two, exact; texels with e = 0 are 0, texels with 0 < e < 10 (a subnormal scale) do not occur in a map that has this form (Environment::build)
-        const uint32_t q00 = P.env_rgbe[(size_t)y0 * w + x0], q10 = P.env_rgbe[(size_t)y0 * w + x1], q01 = P.env_rgbe[(size_t)y1 * w + x0], q11 = P.env_rgbe[(size_t)y1 * w + x1];
+        // the two texels of a row are neighbours in memory unless the lookup wraps around the map's seam: one 8-byte load per row then (two loads instead of four --
+        // what a lookup costs the vector memory path is its number of (lane, instruction) pairs, profiles/r6i_*)
+        uint32_t q00, q10, q01, q11;
+        if (x1 == x0 + 1) {
+            ld_pair(P.env_rgbe + ((size_t)y0 * w + x0), q00, q10);
+            ld_pair(P.env_rgbe + ((size_t)y1 * w + x0), q01, q11);
+        } else {
+            q00 = P.env_rgbe[(size_t)y0 * w + x0]; q10 = P.env_rgbe[(size_t)y0 * w + x1]; q01 = P.env_rgbe[(size_t)y1 * w + x0]; q11 = P.env_rgbe[(size_t)y1 * w + x1];
+        }
         VR_TRACE(3, P.env_rgbe, ((size_t)y0 * w + x0) * 4, 4); VR_TRACE(3, P.env_rgbe, ((size_t)y0 * w + x1) * 4, 4);
         VR_TRACE(3, P.env_rgbe, ((size_t)y1 * w + x0) * 4, 4); VR_TRACE(3, P.env_rgbe, ((size_t)y1 * w + x1) * 4, 4);
         const float s00 = rgbe_scale(q00), s10 = rgbe_scale(q10), s01 = rgbe_scale(q01), s11 = rgbe_scale(q11);
@@ -854,8 +882,12 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
         VR_TRACE(2, P.env_cdf, (b - P.env_cdf) * 4, 128);
         const int32_t c = env_warp_level<ENVDC>(b, px, py, posx, posy);
         const float* child = b + kEnvCdfLastChild0 + kEnvCdfLastChildFloats * c;
+        // the child's record AND its four texels' importances in one go (28 bytes: a 12- and a 16-byte load), the texel picked in registers: the importance no longer
+        // waits for a third dependent round trip
+        float w4[4];
+        ld_quad(child + 3, w4);
         const int32_t c2 = env_warp_level<ENVDC>(child, px, py, posx, posy);
-        w_texel = child[3 + c2];
+        w_texel = c2 == 0 ? w4[0] : (c2 == 1 ? w4[1] : (c2 == 2 ? w4[2] : w4[3]));
     }
     const float u = ((float)posx + px) * P.u.env_imp_inv_dim[0];
     const float v = ((float)posy + py) * P.u.env_imp_inv_dim[1];
