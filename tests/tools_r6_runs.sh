@@ -279,7 +279,15 @@ AB_CASES="c2:1024:256 c3:1024:256 c4:512:1024:64 c5full:512:2048:8 c5cloud:512:2
 grep "^==" $O/ab.txt | tee -a $O/summary.txt
 }
 
+# generic A/B of library variants (each is first checked against the oracle by smoke()): bash tests/tools_r6_runs.sh ab <out dir> <variant> ...
+ab() {
+O=gpurun_out/$1; shift; mkdir -p $O
+AB_CASES=${AB_CASES:-"c2:1024:256 c3:1024:256 c4:512:1024:64 c5full:512:2048:8 c5cloud:512:2048:8"} bash tests/tools_ab.sh "$@" > $O/ab.txt 2>&1
+grep -E "^==|smoke" $O/ab.txt | tee -a $O/summary.txt
+}
+
 case "$1" in
+  ab) shift; ab "$@"; exit $? ;;
   call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15|call16) "$1" ;;
   *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15|call16}"; exit 2 ;;
 esac

@@ -834,8 +834,29 @@ VR_HD int32_t env_warp_level(const float* rec, float& px, float& py, int32_t& po
     posy = 2 * posy + (up ? 1 : 0);
     return (up ? 2 : 0) + (right ? 1 : 0);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// two levels from a 64-byte block held in registers: the parent's record, then the chosen child's, picked with selects
+// children: c0 = (q0.w q1.x q1.y)  c1 = (q1.z q1.w q2.x)  c2 = (q2.y q2.z q2.w)  c3 = (q3.x q3.y q3.z)
+template <bool ENVDC>
+__device__ __forceinline__ void env_warp_block(float4 q0, float4 q1, float4 q2, float4 q3, float& px, float& py, int32_t& posx, int32_t& posy) {
+    const float parent[3] = { q0.x, q0.y, q0.z };
+    const int32_t c = env_warp_level<ENVDC>(parent, px, py, posx, posy);
+    const bool c_right = (c & 1) != 0, c_up = (c & 2) != 0;
+    const float lo_d = c_right ? q1.z : q0.w, lo_e0 = c_right ? q1.w : q1.x, lo_e1 = c_right ? q2.x : q1.y;
+    const float hi_d = c_right ? q3.x : q2.y, hi_e0 = c_right ? q3.y : q2.z, hi_e1 = c_right ? q3.z : q2.w;
+    const float child[3] = { c_up ? hi_d : lo_d, c_up ? hi_e0 : lo_e0, c_up ? hi_e1 : lo_e1 };
+    env_warp_level<ENVDC>(child, px, py, posx, posy);
+}
+#endif
 #ifndef VR_ENV_BLOCK_LOADS
 #define VR_ENV_BLOCK_LOADS 1
+#endif
+// build-time experiments (round 6, profiles/r6j_*): levels 0 and 1 through the scalar cache; block loads only for the levels below VR_ENV_BLOCK_BELOW
+#ifndef VR_ENV_SCALAR_TOP
+#define VR_ENV_SCALAR_TOP 0
+#endif
+#ifndef VR_ENV_BLOCK_BELOW
+#define VR_ENV_BLOCK_BELOW 64
 #endif
 // BLOCK: load a pair of levels' 64-byte block at once (below); off in the everything-at-run-time kernel, which has no registers for it
 // ENVDC: the warp's quotients by div_core (env_warp_level<true>): only for an environment whose table passed the check (SceneParams::env_div_safe)
@@ -853,21 +874,27 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
         if (top == 0) w_texel = blk[3 + c];
         blk += kEnvCdfBlockFloats; k = 1;
     }
+#if VR_ENV_BLOCK_LOADS && VR_ENV_SCALAR_TOP && defined(__HIP_DEVICE_COMPILE__)
+    if (BLOCK && k == 0 && 1 < top) {
+        // levels 0 and 1: the block is the same for every lane -- read through the scalar cache (a load in the constant address space: the table is not written while
+        // the kernel runs) into scalar registers, no vector-memory round trip
+        typedef const float4 __attribute__((address_space(4))) * ConstQ;
+        uint64_t addr = reinterpret_cast<uint64_t>(blk);
+        asm("" : "+s"(addr));                                   // (keeps the optimiser from folding the pointer back into the global address space and the load into a vector one)
+        ConstQ cb = (ConstQ)(addr);
+        env_warp_block<ENVDC>(cb[0], cb[1], cb[2], cb[3], px, py, posx, posy);
+        blk += kEnvCdfBlockFloats; k = 2;
+    }
+#endif
     for (; k + 1 < top; k += 2) {                               // levels k and k + 1: parent record, then the chosen child's in the same block
         const float* b = blk + kEnvCdfBlockFloats * (size_t)((posy << k) + posx);
         VR_TRACE(2, P.env_cdf, (b - P.env_cdf) * 4, 64);
 #if VR_ENV_BLOCK_LOADS && defined(__HIP_DEVICE_COMPILE__)
-        if (BLOCK) {
+        if (BLOCK && k < VR_ENV_BLOCK_BELOW) {
         // the whole 64-byte block at once -- parent record and all four children's -- and the child picked in registers: one memory round trip per pair of
         // levels instead of two dependent ones (the second was a hit in the line the first had fetched, but a round trip all the same)
         const float4 q0 = reinterpret_cast<const float4*>(b)[0], q1 = reinterpret_cast<const float4*>(b)[1], q2 = reinterpret_cast<const float4*>(b)[2], q3 = reinterpret_cast<const float4*>(b)[3];
-        const float parent[3] = { q0.x, q0.y, q0.z };
-        const int32_t c = env_warp_level<ENVDC>(parent, px, py, posx, posy);
-        const bool c_right = (c & 1) != 0, c_up = (c & 2) != 0;          // children: c0 = (q0.w q1.x q1.y)  c1 = (q1.z q1.w q2.x)  c2 = (q2.y q2.z q2.w)  c3 = (q3.x q3.y q3.z)
-        const float lo_d = c_right ? q1.z : q0.w, lo_e0 = c_right ? q1.w : q1.x, lo_e1 = c_right ? q2.x : q1.y;
-        const float hi_d = c_right ? q3.x : q2.y, hi_e0 = c_right ? q3.y : q2.z, hi_e1 = c_right ? q3.z : q2.w;
-        const float child[3] = { c_up ? hi_d : lo_d, c_up ? hi_e0 : lo_e0, c_up ? hi_e1 : lo_e1 };
-        env_warp_level<ENVDC>(child, px, py, posx, posy);
+        env_warp_block<ENVDC>(q0, q1, q2, q3, px, py, posx, posy);
         } else
 #endif
         {
