@@ -279,6 +279,13 @@ AB_CASES="c2:1024:256 c3:1024:256 c4:512:1024:64 c5full:512:2048:8 c5cloud:512:2
 grep "^==" $O/ab.txt | tee -a $O/summary.txt
 }
 
+# full GPU suite, then an A/B: bash tests/tools_r6_runs.sh test_ab <out dir> <variant> ...
+test_ab() {
+O=gpurun_out/$1; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" | tee -a $O/summary.txt
+tail -n 4 $O/pytest.log | tee -a $O/summary.txt
+ab "$@"
+}
 # generic A/B of library variants (each is first checked against the oracle by smoke()): bash tests/tools_r6_runs.sh ab <out dir> <variant> ...
 ab() {
 O=gpurun_out/$1; shift; mkdir -p $O
@@ -288,6 +295,7 @@ grep -E "^==|smoke" $O/ab.txt | tee -a $O/summary.txt
 
 case "$1" in
   ab) shift; ab "$@"; exit $? ;;
+  test_ab) shift; test_ab "$@"; exit $? ;;
   call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15|call16) "$1" ;;
   *) echo "usage: bash tests/tools_r6_runs.sh {call1|call2|call3|call4|call5|call6|call7|call8|call9|call10|call11|final_check|call12|call13|call14|call15|call16}"; exit 2 ;;
 esac

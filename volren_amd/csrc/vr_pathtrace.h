@@ -272,7 +272,11 @@ constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state worksp
 #endif
 template <bool SWAP = false>
 struct ColdGlobalT {
-    static __device__ __forceinline__ constexpr int32_t phys(int32_t f) { return !SWAP ? f : ((f >= C_THR && f < C_THR + 3) ? f + (C_DIR - C_THR) : ((f >= C_DIR && f < C_DIR + 3) ? f - (C_DIR - C_THR) : f)); }
+    // SWAP (the kernels with VR_WORLD_SLOT): [ -, - ][ dir, sh_pdf ][ L, n_paths ][ thr, f_p ] -- the collision event writes the second 16 bytes, the scatter event the
+    // upper sector; pos and f_pl are not kept (vr_trace.h do_nee)
+    static __device__ __forceinline__ constexpr int32_t phys(int32_t f) {
+        return !SWAP ? f : ((f >= C_THR && f < C_THR + 3) ? f + (C_DIR - C_THR) : ((f >= C_DIR && f < C_DIR + 3) ? f - (C_DIR - C_THR) : (f == C_SHPDF ? C_FPL : (f == C_FPL ? C_SHPDF : f))));
+    }
     float* base;                       // this slot's 16 floats in the wavefront's slice of the main array
     float* side;                       // this slot's 4 floats in the wavefront's slice of the side array
     float* col;                        // C_COL: the three dwords of the path's parked hot state (LDS) that hold 1/dir -- dead between a real collision and

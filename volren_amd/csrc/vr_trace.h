@@ -1475,14 +1475,14 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     sample_environment<K::global != 2, K::global != 2>(P, r0, r1, w_i, Le, pdf);      // (the kernels of one scene kind; the run-time variant loads record by record and divides in full)
     if (WS) {
         const bool lit = pdf > 0.0f;                                   // (false for NaN: "no next-event estimate", sh_pdf = 0 for do_postnee)
-        const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);   // (evaluated for every lane: its value is only used where lit)
-        st3(c, C_POS, pos); c.st(C_SHPDF, lit ? pdf : 0.0f);
-        st3(c, C_DIR, dir); c.st(C_FPL, lit ? f_p : 0.0f);
+        // ONE 16-byte store: this segment's direction and sh_pdf.  The collision point stays with the path (the shadow segment starts there: h.wpos), and the phase
+        // function's value for the light sample is evaluated by do_postnee, from this direction and the shadow segment's (h.wdir = w_i): same operands, same value
+        st3(c, C_DIR, dir); c.st(C_SHPDF, lit ? pdf : 0.0f);
         if (lit) {
             if (SHLE_IN_HOT) h.shle = Le; else st3(c, C_SHLE, Le);
             begin_segment<K>(h, P, pos, w_i, 1);
         } else {
-            h.wpos = pos;                                              // (do_postnee takes the collision point from the cold line either way; kept consistent)
+            h.wpos = pos;                                              // (do_postnee takes the collision point from here)
             h.shadow = 0;
             h.state = ST_POSTNEE;
         }
@@ -1504,19 +1504,20 @@ VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
 // common.glsl:625-641, then the head of the next sample_volumeDDA call
 template <class K, class Cold, bool SHLE_IN_HOT = false, bool ITEM_IN_HOT = false>
 VR_HD void do_postnee(Hot& h, Cold& c, const SceneParams& P, const WorkUnit& wu) {
-    // the whole slot, as the four 16-byte groups its layout puts side by side (with VR_WORLD_SLOT: thr and dir swapped, vr_pathtrace.h ColdGlobalT): four loads,
-    // all in flight at once (round 6; before: seven, the last two -- dir, pos -- issued only after the roulette)
+    // the whole slot, as the 16-byte groups its layout puts side by side: four loads (with VR_WORLD_SLOT three -- (dir, sh_pdf), (L, n_paths), (thr, f_p); vr_pathtrace.h
+    // ColdGlobalT), all in flight at once (round 6; before: seven, the last two -- dir, pos -- issued only after the roulette)
     constexpr bool WS = world_slot<K>();
-    const Quad q_l = ld4(c, C_L, C_NPATHS), q_p = ld4(c, C_POS, C_SHPDF);
-    const Quad q_t = ld4(c, C_THR, WS ? C_FP : C_FPL), q_d = ld4(c, C_DIR, WS ? C_FPL : C_FP);
+    const Quad q_l = ld4(c, C_L, C_NPATHS), q_p = WS ? Quad{ h.wpos, 0.0f } : ld4(c, C_POS, C_SHPDF);
+    const Quad q_t = ld4(c, C_THR, WS ? C_FP : C_FPL), q_d = ld4(c, C_DIR, WS ? C_SHPDF : C_FP);
     v3 L = q_l.a;
-    const float sh_pdf = q_p.b;
+    const float sh_pdf = WS ? q_d.b : q_p.b;
     v3 thr = q_t.a;
     if (WS) thr = thr * v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };      // the real collision's "throughput *= albedo" (see do_nee): same operands, same product
-    const float fpl_kept = WS ? q_d.b : q_t.b;
+    const float fpl_kept = WS ? 0.0f : q_t.b;
     if (sh_pdf > 0.0f) {
         // common.glsl:620-626: L += throughput * mis * f_p * Tr * Le / pdf, the factors of the light sample do_nee drew
-        const float f_p = fpl_kept;
+        // (VR_WORLD_SLOT: f_p from the incoming direction and the shadow segment's, which the path still carries -- the expression do_nee's other form evaluates)
+        const float f_p = WS ? phase_hg(dot(-q_d.a, h.wdir), P.u.vol_phase_g) : fpl_kept;
         const float mis = P.u.show_environment > 0 ? power_heuristic(sh_pdf, f_p) : 1.0f;
         L = L + ((((thr * mis) * f_p) * h.Tr) * (SHLE_IN_HOT ? h.shle : ld3(c, C_SHLE))) / sh_pdf;
     }                                    // (sector 1 is written once, at the end, by the paths that go on)
