@@ -149,11 +149,14 @@ struct FirstStash { v3 dir; uint32_t item; };
 // weight thr * mis * f_p of that sample is recomputed by the scatter event from thr, sh_pdf and f_p (same operations on the same
 // values as when the collision event stored it).  History: one 128-byte line per path with all 24 floats (c4: 2.11x the
 // algorithmic bytes moved), fields ordered by writer (1.80x), 64-byte slots (profiles/r2y_*).
+#ifndef VR_C_STRIDE
+#define VR_C_STRIDE 16          // floats between two slots of the cold workspace (a build-time experiment of round 6 spreads them: profiles/r6k_*)
+#endif
 enum ColdField : int32_t {
     C_POS = 0, C_SHPDF = 3, C_THR = 4, C_FPL = 7, C_L = 8, C_NPATHS = 11, C_DIR = 12, C_FP = 15,
     C_SIDE = 16, C_SHLE = 16, C_ITEM = 19,
     C_COL = 20,                 // transfer-function kernels: colour of the real collision, collide_finish -> do_nee (device: the parked path's LDS slot)
-    C_COUNT = 23, C_STRIDE = 16, C_SIDE_STRIDE = 4
+    C_COUNT = 23, C_STRIDE = VR_C_STRIDE, C_SIDE_STRIDE = 4
 };
 template <class Cold> VR_HD v3 ld3(const Cold& c, int32_t f) { return v3{ c.ld(f), c.ld(f + 1), c.ld(f + 2) }; }
 template <class Cold> VR_HD void st3(Cold& c, int32_t f, v3 v) { c.st(f, v.x); c.st(f + 1, v.y); c.st(f + 2, v.z); }
@@ -255,7 +258,11 @@ VR_HD TapData tap_load(const GridView& g, TapAddr a) {
     }
     if (grid_is_dense<DENSE>(g)) {
         d.rmin = 0.0f; d.rdiff = 0.0f;
+#if defined(VR_DENSE_TAP_NT) && defined(__HIP_DEVICE_COMPILE__)
+        d.raw = __builtin_nontemporal_load(g.dense + ((size_t)a.cell * 64u + a.off));      // build-time experiment (round 6, profiles/r6k_*): the dense grid's taps streaming through the L2
+#else
         d.raw = g.dense[(size_t)a.cell * 64u + a.off];
+#endif
     } else {
 #if VR_BRICK_HEADERS
         // the voxel's line of the brick's block: [rmin, rdiff | 120 voxels] -- range and voxel come from one cache line
