@@ -752,7 +752,19 @@ pathtrace_kernel(const KernelArgs A) {
 #endif
         constexpr bool kCleanForms = VR_CLEAN_FORMS && ((K::tf && K::emission == 1) ? VR_CLEAN_FORMS_TF_EMISSION != 0 : true);
         const bool all_clean = kCleanForms && (holds_path & wave_ballot((int32_t)f2u(l.far) < 0)) == 0ull;
-        auto hot_pair = [&](auto clean_tag, const int hot_rep_) __attribute__((always_inline)) -> bool {
+        // VR_EARLY_MARCH (round 6, build-time experiment, profiles/r6l_*): the NEXT copy's march loads are issued between this copy's tap loads and the code that consumes
+        // the taps.  After collide_prep a path's next DDA steps are known whatever the tap says -- a null collision leaves it where it stands, one level finer
+        // (collide_finish: mip = max(0, mip - 2)); a real one takes it out of the hot pair, and its steps are dropped -- so march_prep runs on that state and both
+        // majorants travel while the tap does: one exposed round trip per pass instead of two.  The same values by the same operations (all tests green); only where
+        // the loads are issued changes.  1: as described; 2: without the pin that keeps the tap's decode below the majorant loads.  Measured: -5 % c2, -5 ... -7 % c4
+        // either way -- the pair does not run at the speed of its round trips.  Off.
+#ifndef VR_EARLY_MARCH
+#define VR_EARLY_MARCH 0
+#endif
+        constexpr bool kEarlyMarch = VR_EARLY_MARCH != 0 && VR_MARCH_SPECULATIVE && VR_MARCH_STEPS == 2 && K::global == 0 && !K::tf && K::emission == 0 && !K::maj_reuse && maj_lds_cells<K>() == 0;
+        MarchIO pre;                       // kEarlyMarch: the next copy's steps and (in flight) majorants
+        march_idle(pre); pre.maj1 = pre.maj2 = 0u;
+        auto hot_pair = [&](auto clean_tag, const int hot_rep_, const int n_copies_) __attribute__((always_inline)) -> bool {
             constexpr bool CLEAN = decltype(clean_tag)::value;
 #if VR_BALLOT_VALID
             if (hot_rep_ > 0 && popc_s(holds_path & wave_ballot((uint32_t)(l.state - ST_MARCH) < 2u)) < (VR_DRAIN && exhausted ? 1 : VR_HOT_PAIR_MIN)) return false;
@@ -763,6 +775,8 @@ pathtrace_kernel(const KernelArgs A) {
             const bool is_m = slot >= 0 && l.state == ST_MARCH;
 #if VR_MARCH_SPECULATIVE
             MarchIO mio;
+            if (kEarlyMarch && hot_rep_ > 0) mio = pre;      // prepared and loaded by the copy before this one (below), for every lane that is marching now
+            else {
             march_idle(mio);
             if (is_m) march_prep<K::dense, K::majb, CLEAN>(l, P, mio);
             if constexpr (kMajCells > 0) march_load_lds<K::tf, MajT>(P, mio, lds_maj, maj_first);
@@ -774,6 +788,7 @@ pathtrace_kernel(const KernelArgs A) {
             // empty asm that takes both values as operands keeps the two loads above it, back to back.
             asm volatile("" : "+v"(mio.maj1), "+v"(mio.maj2));
 #endif
+            }
             if (is_m) march_finish<K::tf, K::maj_reuse, CLEAN>(l, P, mio);
 #else
             for (int32_t k = 0; k < 2; ++k)            // diagnostic: two plain steps, one majorant load each, only where a step runs
@@ -806,7 +821,35 @@ pathtrace_kernel(const KernelArgs A) {
             const int32_t n_c = popc(wave_ballot(is_c));
             const int32_t n_m = popc(wave_ballot(slot >= 0 && l.state == ST_MARCH));
 #endif
-            if (n_c > 0 && n_c >= min(VR_THR_COLLIDE, (n_c + n_m + 1) >> 1)) {
+            const bool run_c = n_c > 0 && n_c >= min(VR_THR_COLLIDE, (n_c + n_m + 1) >> 1);
+            if (kEarlyMarch) {
+                // the pipelined form of the block below: tap loads, then the next copy's march loads, then the code that waits for the taps
+                CollideIO<K> cio;
+                collide_idle<K>(cio);
+                if (run_c) {
+                    if (is_c) collide_prep<K, CLEAN>(l, P, P, cio);
+                    collide_load<K>(P, P, cio);
+                }
+                const bool early = hot_rep_ + 1 < n_copies_;
+                if (early) {
+                    const bool spec = run_c && is_c;                                   // the tentative collision this pass resolves: assume it is a null one
+                    Hot ls = l;
+                    ls.mipq = spec ? (l.mipq > 8 ? l.mipq - 8 : 0) : l.mipq;             // collide_finish: mip = max(0, mip - 2)
+                    march_idle(pre);
+                    if (slot >= 0 && (l.state == ST_MARCH || spec)) march_prep<K::dense, K::majb, CLEAN>(ls, P, pre);
+                    march_load<K::tf>(P, pre);
+                    // the tap is used from HERE on as far as the compiler is concerned: left alone it hoists the tap's decode (a conversion and a select) up to the
+                    // tap's load -- and waits for it there, before the majorants above have been requested
+                    if (VR_EARLY_MARCH == 1) asm volatile("" : "+v"(cio.d.raw), "+v"(cio.d.rmin), "+v"(cio.d.rdiff));
+                }
+                if (run_c) {
+                    if (is_c) { ColdT c = VR_COLD(slot); collide_finish<K, ColdT, true>(l, c, P, P, cio, P.tf_lut); }
+                    if (STATS) { stat_add(2 * ST_COLLIDE, 1u); stat_add(2 * ST_COLLIDE + 1, (uint32_t)n_c); }
+                }
+                // (the majorants are used HERE as far as the compiler is concerned: it may neither sink the loads into the next copy's march_finish nor drop them)
+                if (early) asm volatile("" : "+v"(pre.maj1), "+v"(pre.maj2));
+            } else
+            if (run_c) {
                 CollideIO<K> cio;
                 collide_idle<K>(cio);
                 const SceneParams& PE = VR_EMISSION_BY_POINTER && K::emission != 0 ? event_args().P : P;      // see collide_prep
@@ -834,11 +877,11 @@ pathtrace_kernel(const KernelArgs A) {
         if constexpr (kCleanForms) {
             if (all_clean) {
 #pragma unroll
-                for (int hot_rep_ = 0; hot_rep_ < kHotPairs; ++hot_rep_) if (!hot_pair(std::true_type{}, hot_rep_)) break;
-            } else hot_pair(std::false_type{}, 0);
+                for (int hot_rep_ = 0; hot_rep_ < kHotPairs; ++hot_rep_) if (!hot_pair(std::true_type{}, hot_rep_, kHotPairs)) break;
+            } else hot_pair(std::false_type{}, 0, 1);
         } else {
 #pragma unroll
-            for (int hot_rep_ = 0; hot_rep_ < kHotPairs; ++hot_rep_) if (!hot_pair(std::false_type{}, hot_rep_)) break;
+            for (int hot_rep_ = 0; hot_rep_ < kHotPairs; ++hot_rep_) if (!hot_pair(std::false_type{}, hot_rep_, kHotPairs)) break;
         }
         VR_SECTION(1);                                                   // hot pair (also in st_cyc[MARCH] + st_cyc[COLLIDE])
         // (3) park paths that reached an event
