@@ -104,7 +104,8 @@ int vr_set_transferfunc(vr_renderer* r, const float* rgba, int n);
  *     emission grid, 3 everything decided at run time -- correct for every scene, up to an order of magnitude slower) and "kernel_variant_reason" (what sent the
  *     scene to variant 3, a mask: 1 integrator != 0, 2 the environment's warp table has thresholds below 2^-76 ("env_div_safe" = 0), 4 density scale outside
  *     [2^-16, 2^24], 8 emission grid with a dense grid / brick grids of different layouts; 0: the scene has a kernel of its own kind).  Reasons 2 and 4 are also
- *     said once per process on stderr: a caller cannot see them coming */
+ *     said once per process on stderr: a caller cannot see them coming;  "env_compact" (1: every texel of the environment map is exactly an RGBE number -- a
+ *     Radiance file's always are -- and the path tracer fetches them as one dword each; the values are the float map's, bit for bit) */
 int vr_set_int(vr_renderer* r, const char* name, int value);
 int vr_get_int(vr_renderer* r, const char* name, int* value);
 int vr_set_float(vr_renderer* r, const char* name, const float* values, int count);

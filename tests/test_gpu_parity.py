@@ -1825,6 +1825,47 @@ def test_nan_ray_parameter_on_a_clean_segment():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size", [(1, 1), (2, 1), (3, 2), (5, 4), (16, 8), (33, 17)])
+def test_small_environment_maps_in_compact_form(size):
+    """Round 6: a map whose texels are all exactly RGBE numbers is fetched as one dword per texel, a row's two texels of a bilinear lookup as ONE 8-byte load when they are
+    neighbours in memory (vr_trace.h env_texture) -- which they are not at the map's seam (the lookup wraps to column 0), and never in a map one texel wide.  Maps of 1 to
+    33 columns, odd and even, send a large share of the lookups across the seam; a float map of the same values (one texel nudged off the RGBE grid) takes the other
+    branch.  Both must give the oracle's frame bit for bit, in the scene's own kernel and in the run-time one."""
+    w, h = size
+    rs = np.random.RandomState(w * 100 + h)
+    m = rs.randint(0, 256, (h, w, 3)).astype(np.float32)
+    m[..., 0] = rs.randint(128, 256, (h, w))                       # the largest component's 8-bit mantissa has its top bit set: the texel IS its own RGBE encoding
+    m[..., 1:] = np.minimum(m[..., 1:], m[..., :1])
+    env = (m * np.exp2(rs.randint(-12, 2, (h, w, 1)).astype(np.float32))).astype(np.float32)
+    env[0, 0] = 0.0                                                # (an exactly black texel: e = 0)
+    o = scenes.oracle_scene("c2", 72, 48)
+    r = scenes.hip_scene("c2", 72, 48)
+    for x in (o, r):
+        x.set_envmap(env)
+    assert r.env_compact == 1
+    want = o.render(6).copy()
+    r.render(6)
+    _assert_same(r.framebuffer(), want, "compact %dx%d environment" % (w, h))
+    r.integrator = 1; o.integrator = 1                             # the run-time variant (global-majorant trackers): its own copy of the lookup
+    for x in (o, r):
+        x.reset()
+    want = o.render(3).copy()
+    r.render(3)
+    assert r.kernel_variant == 3
+    _assert_same(r.framebuffer(), want, "compact %dx%d environment, run-time variant" % (w, h))
+    env2 = env.copy()
+    env2[h - 1, w - 1, 1] = np.float32(1.0 / 3.0)                   # not an RGBE number: the whole map keeps its float form
+    r.integrator = 0; o.integrator = 0
+    for x in (o, r):
+        x.set_envmap(env2)
+        x.reset()
+    assert r.env_compact == 0
+    want = o.render(4).copy()
+    r.render(4)
+    _assert_same(r.framebuffer(), want, "float %dx%d environment" % (w, h))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scene", ["c2", "c5:64"])
 def test_environment_whose_warp_table_fails_the_division_check(scene):
     """The kernels compiled for one scene kind take the environment warp's quotients -- and the march's step back -- by vr_math.h div_core, the IEEE sequence

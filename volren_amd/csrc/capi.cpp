@@ -324,6 +324,7 @@ int vr_get_int(vr_renderer* r, const char* name, int* v) {
             *v = n == "kernel_variant" ? variant : why;
         }
         else if (n == "env_div_safe") *v = R.environment && R.environment->cdf_div_safe ? 1 : 0;      // the environment's warp table passed env_cdf_kernel's check (vr_math.h div_core)
+        else if (n == "env_compact") *v = R.environment && R.environment->envmap_rgbe ? 1 : 0;      // the path tracer fetches the map's texels as RGBE dwords (vr_scene.h SceneParams::env_rgbe)
         else if (n == "pending_samples") *v = R.pending_samples();
         else if (n == "tf_float_atlas") *v = R.tf_float_atlas ? 1 : 0;
         else if (n == "gpu_encoder") *v = R.gpu_encoder ? 1 : 0;

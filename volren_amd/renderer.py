@@ -49,7 +49,7 @@ class Renderer:
 
     # ---- fields ----
     def __getattr__(self, name):
-        if name in _INT_FIELDS or name in ("n_grid_frames", "last_launches", "pending_samples", "majorant_blocked", "env_div_safe", "kernel_variant", "kernel_variant_reason"):
+        if name in _INT_FIELDS or name in ("n_grid_frames", "last_launches", "pending_samples", "majorant_blocked", "env_div_safe", "env_compact", "kernel_variant", "kernel_variant_reason"):
             v = C.c_int()
             _lib.check(self._L.vr_get_int(self._h, name.encode(), C.byref(v)))
             return bool(v.value) if name in ("show_environment", "tonemapping") else v.value
