@@ -89,6 +89,11 @@ void Environment::build(const float* rgb, int w, int h) {
     uint32_t flag = 1u;
     unsafe->download(&flag, sizeof flag);
     cdf_div_safe = flag == 0u;
+    {
+        const int32_t base_mip = (int32_t)std::floor(std::log2((float)DIMENSION));      // = Uniforms::env_imp_base_mip (renderer.cpp)
+        const size_t at = (size_t)(4 * (int32_t)DIMENSION * (int32_t)DIMENSION - 4 * ((int32_t)DIMENSION >> base_mip) * ((int32_t)DIMENSION >> base_mip)) / 3;      // vr_trace.h imp_level_offset
+        VR_HIP(hipMemcpy(&avg_importance, impmap->as<float>() + at, sizeof(float), hipMemcpyDeviceToHost));
+    }
 }
 
 uint32_t Environment::num_mip_levels() const { return 1 + (uint32_t)std::floor(std::log2((float)DIMENSION)); }

@@ -29,6 +29,8 @@ public:
     DeviceBufferPtr impmap;      // R32F pyramid: 512^2, 256^2, ..., 1
     DeviceBufferPtr cdf;         // per-2x2-block warp thresholds derived from the pyramid (see vr_trace.h sample_environment)
     int width = 0, height = 0;
+    float avg_importance = 0.0f; // the pyramid's coarsest value (what the kernels' MIS weights divide by: common.glsl:147's textureLod at the base mip), read back once so that
+                                 // the kernels get it as an argument instead of fetching it at the end of every light sample and escape (round 6)
     bool cdf_div_safe = false;   // every threshold of `cdf` is NaN, 0 or in [2^-76, 1]: the kernels' warp may use the division without its guard instructions (vr_math.h div_core)
 
     std::vector<float> download_impmap() const;

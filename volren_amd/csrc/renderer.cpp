@@ -415,6 +415,7 @@ void RendererHIP::fill_params(SceneParams& P) {
     P.envmap = environment->envmap->as<float>();
     P.env_rgbe = environment->envmap_rgbe ? environment->envmap_rgbe->as<uint32_t>() : nullptr;
     P.env_w = environment->width; P.env_h = environment->height;
+    P.env_avg_w = environment->avg_importance; P.env_avg_w_set = 1;
     P.impmap = environment->impmap->as<float>();
     P.imp_dim = (int)environment->dimension();
     P.env_cdf = environment->cdf->as<float>();

@@ -174,6 +174,8 @@ struct SceneParams {
                                        // is exactly such a number -- a Radiance .hdr file's always are --, else null: a quarter of the bytes behind every texel fetch
                                        // (the 1024 x 512 map: 2 MiB instead of 8, smaller than an XCD's L2); env_texture decodes to the same floats, bit for bit
     int32_t env_w, env_h;
+    float env_avg_w;                   // round 6: impmap's coarsest value, imp_fetch(0, 0, base mip) -- the divisor of every light sample's pdf and MIS weight -- as an argument
+    int32_t env_avg_w_set;             // (1: env_avg_w is that value; 0 -- a SceneParams filled by other code: the lane code fetches it)
     const float* impmap;               // importance pyramid, level 0 (dim^2) first, 2x2 box mips after it
     int32_t imp_dim;
     const float* env_cdf;              // warp table: (d, e0, e1) per 2x2 block of every pyramid level, two levels per block; the finest with its texels (env_cdf_index)

@@ -807,6 +807,9 @@ VR_HD float imp_fetch(const SceneParams& P, int32_t x, int32_t y, int32_t mip) {
     if (x < 0 || y < 0 || x >= d || y >= d) return 0.0f;
     return P.impmap[imp_level_offset(P.imp_dim, mip) + y * d + x];
 }
+// imp_fetch(P, 0, 0, base mip): the pyramid's coarsest value.  The renderer passes it along (SceneParams::env_avg_w: read back when the environment is built) -- fetched
+// here it was one more dependent round trip at the end of every light sample and every escape, for a constant of the scene
+VR_HD float env_average_importance(const SceneParams& P) { return P.env_avg_w_set ? P.env_avg_w : imp_fetch(P, 0, 0, P.u.env_imp_base_mip); }
 VR_HD v3 lookup_environment(const SceneParams& P, v3 dir) {
     const v3 idir = mat3_mul(P.u.env_inv_transform, dir);
     const float u = atan2_(idir.z, idir.x) / (2.0f * kPi) + 0.5f;
@@ -933,7 +936,7 @@ VR_HD void sample_environment(const SceneParams& P, float r0, float r1, v3& w_i,
     w_i = mat3_mul(P.u.env_transform, v3{ sin_t * cos_p, cos_t, sin_t * sin_p });
     const v3 c = env_texture(P, u, v);
     Le = v3{ P.u.env_strength * c.x, P.u.env_strength * c.y, P.u.env_strength * c.z };
-    const float avg_w = imp_fetch(P, 0, 0, P.u.env_imp_base_mip);
+    const float avg_w = env_average_importance(P);
     pdf_out = (w_texel / avg_w) * kInv4Pi;
 }
 
@@ -1573,7 +1576,7 @@ VR_HD void do_escape(Hot& h, const Cold& c, const SceneParams& P, const WorkUnit
         const v3 Le = lookup_environment(P, dir);
         float mis = 1.0f;
         if (n_paths > 0u) {
-            const float avg_w = imp_fetch(P, 0, 0, P.u.env_imp_base_mip);
+            const float avg_w = env_average_importance(P);
             const float pdf_env = (luma(Le) / avg_w) * kInv4Pi;
             mis = power_heuristic(f_p, pdf_env);
         }
@@ -1725,7 +1728,7 @@ VR_HD void raymarch_path_sample(const SceneParams& P, int32_t px, int32_t py, in
         const v3 Le = lookup_environment(P, dir);
         float mis = 1.0f;
         if (n_paths > 0u) {
-            const float avg_w = imp_fetch(P, 0, 0, u.env_imp_base_mip);
+            const float avg_w = env_average_importance(P);
             mis = power_heuristic(f_p, (luma(Le) / avg_w) * kInv4Pi);
         }
         L = L + (thr * mis) * Le;
