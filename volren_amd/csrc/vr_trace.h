@@ -1564,6 +1564,10 @@ VR_HD void do_escape(Hot& h, const Cold& c, const SceneParams& P, const WorkUnit
     v3 L = ld3(c, C_L), thr = ld3(c, C_THR), dir = ld3(c, C_DIR);
     uint32_t n_paths = ldu(c, C_NPATHS), item = ITEM_IN_HOT ? h.item : ldu(c, C_ITEM);
     const float f_p = c.ld(C_FP);
+    // VR_WORLD_SLOT: the lookup needs nothing of the slot -- it runs BEFORE the slot's values are touched, the line's latency under the lookup's arithmetic and texel fetch
+    // (round 6; before, the selects below waited for the line first: two round trips one after the other)
+    v3 Le_early = v3{ 0.0f, 0.0f, 0.0f };
+    if (WS && P.u.show_environment > 0) Le_early = lookup_environment(P, h.wdir);
     const v3 L_first = FIRST_L_IN_HOT ? h.eL : v3{ 0.0f, 0.0f, 0.0f };
     L = v3{ first ? L_first.x : L.x, first ? L_first.y : L.y, first ? L_first.z : L.z };
     thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
@@ -1573,7 +1577,7 @@ VR_HD void do_escape(Hot& h, const Cold& c, const SceneParams& P, const WorkUnit
     item = first ? f2u(h.Tr) : item;
     h.first = 0;
     if (P.u.show_environment > 0) {
-        const v3 Le = lookup_environment(P, dir);
+        const v3 Le = WS ? Le_early : lookup_environment(P, dir);
         float mis = 1.0f;
         if (n_paths > 0u) {
             const float avg_w = env_average_importance(P);
