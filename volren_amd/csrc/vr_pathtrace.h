@@ -264,9 +264,10 @@ struct HotStoreT {                     // [slot][field]: a path's parked dwords 
 // pool slots it costs), profiles/r2j_layout_experiments.txt, r2m_cold_state_in_lds_experiments.txt.
 constexpr uint32_t kStatsWaveBase = 32u;                 // statistics buffer: 32 counters, then (begin, queue empty, end) per wavefront of the launch
 constexpr int32_t kMaxWorkgroups = 2048;                // the cold-state workspace is sized for this many resident 4-wavefront units = 8192 wavefronts (launch_pathtrace clamps the grid to it)
-// SWAP (the kernels with VR_WORLD_SLOT, vr_trace.h world_slot): throughput and direction trade places in the slot -- sector 0 = (pos, sh_pdf, dir, f_p of the light
-// sample), sector 1 = (L, n_paths, thr, f_p) -- because those kernels' collision event writes pos, sh_pdf, ITS segment's direction and f_pl and reads nothing, and
-// their scatter event writes L, n_paths, thr, f_p: every event dirties exactly ONE 32-byte sector (do_nee / do_postnee, vr_trace.h)
+// SWAP (the kernels with VR_WORLD_SLOT, vr_trace.h world_slot): throughput and direction trade places in the slot and sh_pdf moves next to the direction -- sector 0 =
+// [ unused | dir, sh_pdf ], sector 1 = [ L, n_paths | thr, f_p ] -- because those kernels' collision event reads nothing and writes ITS segment's direction and sh_pdf (the
+// collision point stays with the path, the light sample's phase value is re-evaluated by the scatter event), and their scatter event writes L, n_paths, thr, f_p:
+// every event dirties exactly ONE 32-byte sector, in whole 16-byte groups (do_nee / do_postnee, vr_trace.h)
 #ifndef VR_COLD_NT_STORES
 #define VR_COLD_NT_STORES 0
 #endif
