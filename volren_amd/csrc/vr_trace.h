@@ -1447,6 +1447,45 @@ template <class K, class Cold, bool SHLE_IN_HOT = false, bool ITEM_IN_HOT = fals
 VR_HD void do_nee(Hot& h, Cold& c, const Cold& crd, const SceneParams& P) {
     const bool first = h.first != 0;
     constexpr bool WS = world_slot<K>();
+    if (!WS) {
+        // The slot's values are REQUESTED first and touched last: the light sample below -- nine table levels and the texels, seven dependent round trips -- needs none of
+        // them, so the line's latency (it has left the L2 since the path's last event, as a rule) passes under the sample's instead of in front of it (round 6).  No draw
+        // moves: the code between here and the sample never drew.
+        v3 dir = ld3(crd, C_DIR), pos0 = ld3(crd, C_POS), thr = ld3(crd, C_THR);
+        h.first = 0;
+        const float r0 = rng(h.seed), r1 = rng(h.seed);
+        float pdf;
+        v3 w_i, Le;
+        sample_environment<K::global != 2, K::global != 2>(P, r0, r1, w_i, Le, pdf);      // (the kernels of one scene kind; the run-time variant loads record by record and divides in full)
+        dir = v3{ first ? h.ipos.x : dir.x, first ? h.ipos.y : dir.y, first ? h.ipos.z : dir.z };
+        pos0 = v3{ first ? P.u.cam_pos[0] : pos0.x, first ? P.u.cam_pos[1] : pos0.y, first ? P.u.cam_pos[2] : pos0.z };
+        thr = v3{ first ? 1.0f : thr.x, first ? 1.0f : thr.y, first ? 1.0f : thr.z };
+        const v3 pos = axpy(pos0, h.t, dir);
+        // the real collision that led here: throughput *= albedo [* rgba.rgb] (common.glsl:383-388, 491-495; see collide_finish)
+        const v3 alb = v3{ P.u.vol_albedo[0], P.u.vol_albedo[1], P.u.vol_albedo[2] };
+        if (K::global == 2 ? P.u.integrator != 0 : K::global == 1) thr = K::tf ? thr * (ld3(c, C_COL) * alb) : thr * alb;
+        else { thr = thr * alb; if (K::tf) thr = thr * ld3(c, C_COL); }
+        if (first) {
+            // what do_new left unwritten
+            st3(c, C_L, FIRST_L_IN_HOT ? h.eL : v3{ 0, 0, 0 }); stu(c, C_NPATHS, 0u);      // (in the order of the layout: two 16-byte stores)
+            st3(c, C_DIR, dir);
+            c.st(C_FP, 0.0f);
+            if (!ITEM_IN_HOT) stu(c, C_ITEM, f2u(h.Tr));       // else the scheduler takes it from the stash (h.Tr) before this call
+        }
+        const bool lit = pdf > 0.0f;                                       // (false for NaN; sh_pdf = 0 marks "no next-event estimate" for do_postnee)
+        const float f_p = phase_hg(dot(-dir, w_i), P.u.vol_phase_g);       // with sh_pdf and thr: what do_postnee needs for the sample's weight (thr * mis) * f_p
+        // (pos, sh_pdf) and (thr, f_pl): two 16-byte stores that fill sector 0 (profiles/r6i_*)
+        st3(c, C_POS, pos); c.st(C_SHPDF, lit ? pdf : 0.0f);
+        st3(c, C_THR, thr); c.st(C_FPL, lit ? f_p : 0.0f);
+        if (lit) {
+            if (SHLE_IN_HOT) h.shle = Le; else st3(c, C_SHLE, Le);
+            begin_segment<K>(h, P, pos, w_i, 1);
+        } else {
+            h.shadow = 0;
+            h.state = ST_POSTNEE;
+        }
+        return;
+    }
     v3 dir, pos0, thr;
     if (WS) {
         // the segment's origin and direction are the path's own (begin_segment's arguments, parked with it): the values C_POS / C_DIR hold, without the line
